@@ -1,0 +1,329 @@
+// efts_gemm.hip -- the MFMA contraction of the EFTS-CNN path on gfx950 (CDNA4).
+//
+//   out[row, col] = epi( alpha * sum_{tap} sum_{k} A[row + tap - pad, k] * Bw[tap][col, k] )
+//
+// One kernel serves the residual Conv1d stacks (taps 5; reference
+// nntts/layers/efts_modules.py:48-51), the duration-predictor convs (taps 3;
+// nntts/layers/duration_predictor.py:57), the Linears (taps 1; efficient_tts.py:149-153,161,198)
+// and the two batched matrix products of the alignment block (efficient_tts.py:190,390).
+//
+// Design (MI355X-first):
+//   * activations are channel-last in a padded row space, so a k-tap convolution is a GEMM
+//     whose A tile is ONE (128+4)-row LDS window read at `taps` row shifts: the window is
+//     staged once per K-chunk and re-used by every tap (LDS-staged conv window).
+//   * 128x128 output tile per 256-thread workgroup, 2x2 waves of 64x64, 32x32x16 bf16 MFMA,
+//     fp32 accumulators (64 VGPR/lane), 2 workgroups per CU (66 KiB LDS each).
+//   * operands arrive by LDS-DMA (global_load_lds, 16 B/lane).  The LDS image is lane-linear,
+//     so the bank-conflict swizzle is applied on the per-lane SOURCE address and again on the
+//     ds_read_b128 address (same involution on both sides).
+//   * K is consumed in 128-byte chunks: 64 bf16 ("bf16"), or 32 hi + 32 lo bf16 ("bf16x3":
+//     x = hi + lo, product = hi*hi + hi*lo + lo*hi, fp32 accumulate -> fp32-class accuracy at
+//     3 MFMAs per product instead of the 16x slower f32 MFMA).
+//   * epilogue fused: bias, LeakyReLU/ReLU, residual add, row mask (gap rows / padded
+//     positions), fp32 store and bf16 operand planes for the next contraction.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "efts_internal.h"
+
+namespace efts {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int BM = 128;
+constexpr int BN = 128;
+constexpr int A_ROWS = 136;               // 128 + 4 halo rows, rounded up to 8 (one DMA piece = 8 rows)
+constexpr int A_BYTES = A_ROWS * 128;     // 17408
+constexpr int W_BYTES = BN * 128;         // 16384
+constexpr int LDS_BYTES = 2 * A_BYTES + 2 * W_BYTES;  // 67584
+
+// Swizzled LDS byte offset of (row, 16-byte slot) inside a [rows][128 B] tile.  A ds_read_b128
+// lane group holds 16 different rows at one logical slot; rows r and r+2 share banks, so the
+// physical slot is XORed with (r >> 1) & 7 (conflict-free for every tap shift).
+__device__ __forceinline__ int lds_off(int row, int slot) {
+    return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
+}
+
+struct GemmKernelArgs {
+    const char* a;
+    const char* b;
+    const float* bias;
+    const float* resid;
+    const float* rowmask;
+    float* out_f32;
+    char* out_bf16;
+    long lda, ldb, b_tap_stride, ldr, ldo, ldob;
+    long a_bs, b_bs, r_bs, m_bs, o_bs, ob_bs;
+    int m, n, nchunk, pad;
+    int mtiles, ntiles;
+    float alpha, slope;
+    int act, out_split;
+    int vec_ok;   // all fp32 row strides / pointers allow float4 access
+    int dbg;   // ablation switches (EFTS_GEMM_DBG): 1 = skip epilogue stores, 2 = no DMA in loop, 4 = no MFMA
+};
+
+// One DMA piece = one wave instruction = 8 tile rows x 128 B.  Lane l lands at LDS
+// piece_base + 16*l, i.e. tile row 8*piece + l/8, physical slot l%8.
+__device__ __forceinline__ void dma_piece(const char* rowbase0, long ld, int first_row, int max_row,
+                                          int piece, int lane, char* lds_tile) {
+    const int r = piece * 8 + (lane >> 3);
+    const int ps = lane & 7;
+    const int s = ps ^ ((r >> 1) & 7);
+    int gr = first_row + r;
+    gr = gr > max_row ? max_row : gr;
+    const char* src = rowbase0 + (long)gr * ld + (s << 4);
+    __builtin_amdgcn_global_load_lds((const void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds_tile + piece * 1024),
+                                     16, 0, 0);
+}
+
+template <int TAPS, int SPLIT>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // all LDS in one array, buffers addressed arithmetically (no runtime-indexed pointer arrays)
+#define EFTS_ABUF(i) (smem + ((i) & 1) * A_BYTES)
+#define EFTS_WBUF(i) (smem + 2 * A_BYTES + ((i) & 1) * W_BYTES)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware tile order: block b runs on XCD b % 8; give each XCD a contiguous range of
+    // tiles (n fastest) so the workgroups sharing an A window hit the same L2.
+    const int ntot = p.mtiles * p.ntiles;
+    int bid = blockIdx.x;
+    {
+        const int q = ntot >> 3, r = ntot & 7;
+        const int xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = bid / p.ntiles, nt = bid - mt * p.ntiles;
+    const int z = blockIdx.y;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const char* A = p.a + (long)z * p.a_bs;
+    const char* Bw = p.b + (long)z * p.b_bs;
+    const int a_first = m0 - p.pad;            // may be negative: guard rows exist
+    const int a_max = 0x7fffffff;              // A rows are never clamped (guards)
+    const int b_max = p.n - 1 - n0;            // clamp B rows to the last real row
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    constexpr int A_PIECES = (TAPS == 1) ? 16 : 17;
+
+    // prologue: chunk 0 window + tap-0 weights
+    for (int pc = wave; pc < A_PIECES; pc += 4) dma_piece(A, p.lda, a_first, a_max, pc, lane, EFTS_ABUF(0));
+    {
+        const char* wb = Bw + (long)n0 * p.ldb;
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) dma_piece(wb, p.ldb, 0, b_max, wave * 4 + pc, lane, EFTS_WBUF(0));
+    }
+    __syncthreads();
+
+    const int lrow = lane & 31;
+    const int lhalf = lane >> 5;
+    const int nsteps = p.nchunk * TAPS;
+    int s = 0;
+    for (int c = 0; c < p.nchunk; ++c) {
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k, ++s) {
+            // ---- stage the next step's operands (lands while this step computes)
+            if (s + 1 < nsteps && !(p.dbg & 2)) {
+                const int kn = (k + 1 == TAPS) ? 0 : k + 1;
+                const int cn = (k + 1 == TAPS) ? c + 1 : c;
+                const char* wb = Bw + (long)kn * p.b_tap_stride + (long)n0 * p.ldb + (long)cn * 128;
+#pragma unroll
+                for (int pc = 0; pc < 4; ++pc)
+                    dma_piece(wb, p.ldb, 0, b_max, wave * 4 + pc, lane, EFTS_WBUF(s + 1));
+            }
+            if (k == 0 && c + 1 < p.nchunk && !(p.dbg & 2)) {
+                const char* ab = A + (long)(c + 1) * 128;
+                for (int pc = wave; pc < A_PIECES; pc += 4)
+                    dma_piece(ab, p.lda, a_first, a_max, pc, lane, EFTS_ABUF(c + 1));
+            }
+            // ---- MFMAs of this (chunk, tap)
+            const char* at = EFTS_ABUF(c);
+            const char* wt = EFTS_WBUF(s);
+            const int arow = wm * 64 + lrow + k;   // tile row of output row r at tap k is r + k
+            const int brow = wn * 64 + lrow;
+            if (p.dbg & 4) {
+            } else if constexpr (SPLIT == 1) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int slot = kk * 2 + lhalf;
+                    bf16x8 af[2], bfr[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8*)(at + lds_off(arow + i * 32, slot));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bfr[j] = *(const bf16x8*)(wt + lds_off(brow + j * 32, slot));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int slot = kk * 2 + lhalf;
+                    bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        ah[i] = *(const bf16x8*)(at + lds_off(arow + i * 32, slot));
+                        al[i] = *(const bf16x8*)(at + lds_off(arow + i * 32, slot + 4));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        bh[j] = *(const bf16x8*)(wt + lds_off(brow + j * 32, slot));
+                        bl[j] = *(const bf16x8*)(wt + lds_off(brow + j * 32, slot + 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        }
+                }
+            }
+            __syncthreads();   // next operands landed (vmcnt(0)) and this step's reads are done
+        }
+    }
+
+    // ---- fused epilogue, staged through LDS so that every global access is a full-row vector.
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); each
+    // wave drops its 64x64 block (bias + activation applied) into a [128][128] fp32 LDS tile,
+    // then 32 consecutive threads sweep one 512-byte tile row: float4 residual load, float4
+    // store, and 8-byte bf16 (hi / lo) operand-plane stores.
+    float* cs = (float*)smem;   // 64 KiB; the main loop's last barrier has retired all LDS reads
+    {
+        const float* bias = p.bias;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cl = wn * 64 + j * 32 + lrow;
+            const float bv = (bias && n0 + cl < p.n) ? bias[n0 + cl] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                    float v = acc[i][j][r] * p.alpha + bv;
+                    if (p.act == EFTS_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                    else if (p.act == EFTS_ACT_RELU) v = v > 0.f ? v : 0.f;
+                    cs[rl * 128 + cl] = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (p.dbg & 1) return;
+    const float* resid = p.resid ? p.resid + (long)z * p.r_bs : nullptr;
+    const float* rowmask = p.rowmask ? p.rowmask + (long)z * p.m_bs : nullptr;
+    float* of = p.out_f32 ? p.out_f32 + (long)z * p.o_bs : nullptr;
+    char* ob = p.out_bf16 ? p.out_bf16 + (long)z * p.ob_bs : nullptr;
+    const int c4 = (tid & 31) << 2;
+    const int col = n0 + c4;
+    const bool vec = p.vec_ok && (col + 3 < p.n);
+    if (col < p.n) {
+#pragma unroll 4
+        for (int ps = 0; ps < 16; ++ps) {
+            const int rl = ps * 8 + (tid >> 5);
+            const int row = m0 + rl;
+            if (row >= p.m) break;
+            float4 v = *(const float4*)(cs + rl * 128 + c4);
+            const float rm = rowmask ? rowmask[row] : 1.f;
+            if (vec) {
+                if (resid) {
+                    const float4 x = *(const float4*)(resid + (long)row * p.ldr + col);
+                    v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                }
+                v.x *= rm; v.y *= rm; v.z *= rm; v.w *= rm;
+                if (of) *(float4*)(of + (long)row * p.ldo + col) = v;
+                if (ob) plane_store4(ob + (long)row * p.ldob, col, v.x, v.y, v.z, v.w, p.out_split);
+            } else {
+                float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (col + u >= p.n) break;
+                    float t = vv[u];
+                    if (resid) t += resid[(long)row * p.ldr + col + u];
+                    t *= rm;
+                    if (of) of[(long)row * p.ldo + col + u] = t;
+                    if (ob) {
+                        const unsigned short hi = f32_to_bf16(t);
+                        char* d = ob + (long)row * p.ldob + plane_off_hi(col + u, p.out_split);
+                        *(unsigned short*)d = hi;
+                        if (p.out_split == 2) *(unsigned short*)(d + 64) = f32_to_bf16(t - bf16_to_f32(hi));
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace efts
+
+using namespace efts;
+
+extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
+    if (!a) return efts_fail(EFTS_EINVAL, "efts_gemm: null args");
+    if (!(a->split == 1 || a->split == 2)) return efts_fail(EFTS_EINVAL, "efts_gemm: split must be 1 or 2");
+    if (!(a->taps == 1 || a->taps == 3 || a->taps == 5)) return efts_fail(EFTS_EINVAL, "efts_gemm: taps must be 1, 3 or 5");
+    if (a->m <= 0 || a->n <= 0 || a->nchunk <= 0 || a->batch <= 0) return efts_fail(EFTS_ESHAPE, "efts_gemm: m, n, nchunk, batch must be positive");
+    if (!a->a || !a->b) return efts_fail(EFTS_EINVAL, "efts_gemm: null operand");
+    if (((uintptr_t)a->a & 15) || ((uintptr_t)a->b & 15) || (a->lda & 15) || (a->ldb & 15) || (a->b_tap_stride & 15) ||
+        (a->a_batch_stride & 15) || (a->b_batch_stride & 15))
+        return efts_fail(EFTS_EALIGN, "efts_gemm: operand planes must be 16-byte aligned (pointer, row, tap and batch strides)");
+    if (a->lda < (int64_t)a->nchunk * 128 || a->ldb < (int64_t)a->nchunk * 128)
+        return efts_fail(EFTS_ESHAPE, "efts_gemm: row stride smaller than nchunk*128 bytes");
+    if (a->out_bf16 && !(a->out_split == 1 || a->out_split == 2)) return efts_fail(EFTS_EINVAL, "efts_gemm: out_split must be 1 or 2");
+    if (!a->out_f32 && !a->out_bf16) return efts_fail(EFTS_EINVAL, "efts_gemm: no output");
+
+    GemmKernelArgs k;
+    k.a = (const char*)a->a; k.b = (const char*)a->b;
+    k.bias = a->bias; k.resid = a->resid; k.rowmask = a->rowmask;
+    k.out_f32 = a->out_f32; k.out_bf16 = (char*)a->out_bf16;
+    k.lda = a->lda; k.ldb = a->ldb; k.b_tap_stride = a->b_tap_stride; k.ldr = a->ldr; k.ldo = a->ldo; k.ldob = a->ldob;
+    k.a_bs = a->a_batch_stride; k.b_bs = a->b_batch_stride; k.r_bs = a->resid_batch_stride;
+    k.m_bs = a->rowmask_batch_stride; k.o_bs = a->out_batch_stride; k.ob_bs = a->outb_batch_stride;
+    k.m = a->m; k.n = a->n; k.nchunk = a->nchunk; k.pad = (a->taps - 1) / 2;
+    k.mtiles = (a->m + BM - 1) / BM; k.ntiles = (a->n + BN - 1) / BN;
+    k.alpha = a->alpha; k.slope = a->slope; k.act = a->act; k.out_split = a->out_split;
+    k.vec_ok = (!a->out_f32 || ((a->ldo & 3) == 0 && ((uintptr_t)a->out_f32 & 15) == 0 && (a->out_batch_stride & 3) == 0)) &&
+               (!a->resid || ((a->ldr & 3) == 0 && ((uintptr_t)a->resid & 15) == 0 && (a->resid_batch_stride & 3) == 0)) &&
+               (!a->out_bf16 || ((a->ldob & 7) == 0 && ((uintptr_t)a->out_bf16 & 7) == 0 && (a->outb_batch_stride & 7) == 0));
+    { const char* e = getenv("EFTS_GEMM_DBG"); k.dbg = e ? atoi(e) : 0; }
+
+    dim3 grid(k.mtiles * k.ntiles, a->batch), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define EFTS_LAUNCH(T, S) hipLaunchKernelGGL((gemm_kernel<T, S>), grid, block, LDS_BYTES, st, k)
+    if (a->split == 1) {
+        if (a->taps == 5) EFTS_LAUNCH(5, 1); else if (a->taps == 3) EFTS_LAUNCH(3, 1); else EFTS_LAUNCH(1, 1);
+    } else {
+        if (a->taps == 5) EFTS_LAUNCH(5, 2); else if (a->taps == 3) EFTS_LAUNCH(3, 2); else EFTS_LAUNCH(1, 2);
+    }
+#undef EFTS_LAUNCH
+    return efts_check_launch("efts_gemm");
+}
+
+// Opt every instantiation into > 64 KiB of dynamic LDS once, at library load.
+namespace {
+struct GemmInit {
+    GemmInit() {
+#define EFTS_ATTR(T, S) (void)hipFuncSetAttribute((const void*)gemm_kernel<T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)
+        EFTS_ATTR(5, 1); EFTS_ATTR(3, 1); EFTS_ATTR(1, 1); EFTS_ATTR(5, 2); EFTS_ATTR(3, 2); EFTS_ATTR(1, 2);
+#undef EFTS_ATTR
+    }
+};
+}  // namespace
+extern "C" void efts_gemm_init(void) { static GemmInit once; }

@@ -1,0 +1,563 @@
+// efts_ops.hip -- the HBM-bound kernels of the EFTS-CNN path on gfx950: parameter packing,
+// row-space producers, the alignment (IMV) block, LayerNorm tails and the masked losses.
+// All fp32 VALU work on 64-lane wavefronts; every kernel reads/writes coalesced rows and
+// derives masks from the int32 length vectors in-kernel (the reference builds them on the
+// host from lengths.tolist(): nntts/utils/nets_utils.py:145-166).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "efts_internal.h"
+
+namespace efts {
+
+// ----------------------------------------------------------------------------------------
+// block-level helpers (256 threads = 4 waves)
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum256(float v, float* sh /* >= 4 floats */) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ float block_max256(float v, float* sh) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+// inclusive prefix sum across the 64 lanes of a wave
+__device__ __forceinline__ float wave_scan_incl(float v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+// exclusive prefix of one value per thread over a 256-thread block; *total = block sum
+__device__ __forceinline__ float block_scan_excl256(float v, float* sh /* >= 4 */, float* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float incl = wave_scan_incl(v);
+    __syncthreads();
+    if (lane == 63) sh[w] = incl;
+    __syncthreads();
+    float base = 0.f;
+    for (int i = 0; i < w; ++i) base += sh[i];
+    *total = sh[0] + sh[1] + sh[2] + sh[3];
+    return base + incl - v;
+}
+
+// ----------------------------------------------------------------------------------------
+// efts_pack_weight
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, const float* __restrict__ g,
+                                                          float* __restrict__ wout, char* __restrict__ plane,
+                                                          long ldb, int cout, int cin, int taps, int kp, int split) {
+    __shared__ float sh[4];
+    const int co = blockIdx.x;
+    const float* wr = w + (long)co * cin * taps;
+    float scale = 1.f;
+    if (g) {
+        float ss = 0.f;
+        for (int i = threadIdx.x; i < cin * taps; i += 256) ss += wr[i] * wr[i];
+        ss = block_sum256(ss, sh);
+        scale = g[co] / sqrtf(ss);
+    }
+    if (wout)
+        for (int i = threadIdx.x; i < cin * taps; i += 256) wout[(long)co * cin * taps + i] = wr[i] * scale;
+    for (int q = threadIdx.x; q < (kp >> 2) * taps; q += 256) {
+        const int k = q / (kp >> 2), c4 = (q - k * (kp >> 2)) << 2;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (c4 + u < cin) ? wr[(long)(c4 + u) * taps + k] * scale : 0.f;
+        plane_store4(plane + ((long)k * cout + co) * ldb, c4, v[0], v[1], v[2], v[3], split);
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// row-space producers
+// ----------------------------------------------------------------------------------------
+__global__ void row_masks_kernel(const int* __restrict__ len, float* gap, float* lm, int B, int T, int Tp) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= B * Tp) return;
+    const int b = row / Tp, t = row - b * Tp;
+    if (gap) gap[row] = t < T ? 1.f : 0.f;
+    if (lm) lm[row] = (t < T && t < len[b]) ? 1.f : 0.f;
+}
+
+__global__ void embed_kernel(const long* __restrict__ ids, const float* __restrict__ table, float* __restrict__ f32o,
+                             char* __restrict__ plane, long ldp, int T, int Tp, int c, int nsym, int split) {
+    const int row = blockIdx.x;
+    const int b = row / Tp, t = row - b * Tp;
+    const int c4 = threadIdx.x << 2;
+    if (c4 >= c) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < T) {
+        long id = ids[(long)b * T + t];
+        id = id < 0 ? 0 : (id >= nsym ? nsym - 1 : id);
+        v = *(const float4*)(table + id * c + c4);
+    }
+    if (f32o) *(float4*)(f32o + (long)row * c + c4) = v;
+    if (plane) plane_store4(plane + (long)row * ldp, c4, v.x, v.y, v.z, v.w, split);
+}
+
+__global__ void pack_rows_kernel(const float* __restrict__ x, float* __restrict__ f32o, char* __restrict__ plane,
+                                 long ldp, int T, int Tp, int c, int kp, int split) {
+    const int row = blockIdx.x;
+    const int b = row / Tp, t = row - b * Tp;
+    const int c4 = threadIdx.x << 2;
+    if (c4 >= kp) return;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t < T) {
+        const float* xr = x + ((long)b * T + t) * c;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c4 + u < c) v[u] = xr[c4 + u];
+    }
+    if (f32o)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c4 + u < c) f32o[(long)row * c + c4 + u] = v[u];
+    if (plane) plane_store4(plane + (long)row * ldp, c4, v[0], v[1], v[2], v[3], split);
+}
+
+// ----------------------------------------------------------------------------------------
+// alignment block
+// ----------------------------------------------------------------------------------------
+// one wave per (b, j): softmax over the valid keys + expected key index
+__global__ __launch_bounds__(256) void attn_soft_index_kernel(const float* __restrict__ sc, long ld,
+                                                              const int* __restrict__ tlen, const int* __restrict__ mlen,
+                                                              float* __restrict__ sidx, float* __restrict__ alpha,
+                                                              int B, int T1, int T2) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= (long)B * T2) return;
+    const int b = (int)(r / T2), j = (int)(r - (long)b * T2);
+    const int tl = min(tlen[b], T1);
+    const bool live = j < mlen[b];
+    const float* row = sc + r * ld;
+    float mx = -INFINITY;
+    for (int i = lane; i < tl; i += 64) mx = fmaxf(mx, row[i]);
+    mx = wave_max(mx);
+    float se = 0.f, si = 0.f;
+    for (int i = lane; i < tl; i += 64) {
+        const float e = __expf(row[i] - mx);
+        se += e;
+        si += e * (float)i;
+    }
+    se = wave_sum(se);
+    si = wave_sum(si);
+    if (lane == 0) sidx[r] = live ? si / se : 0.f;
+    if (alpha) {
+        const float inv = live ? 1.f / se : 0.f;
+        for (int i = lane; i < T1; i += 64)
+            alpha[((long)b * T1 + i) * T2 + j] = (i < tl) ? __expf(row[i] - mx) * inv : 0.f;
+    }
+}
+
+// One wavefront per item: relu-diff, prefix scan over T2, mask, max, normalise
+// (imv_generator, efficient_tts.py:314-323).  Lane l owns the contiguous segment
+// [l*chunk, (l+1)*chunk): serial sums inside the lane, a 64-lane shuffle scan of the lane totals
+// for the carry.  The parallel association differs from a serial cumsum by rounding only; a
+// prefix-max (exact in any association) restores the monotonicity a serial cumsum of
+// non-negative terms guarantees.
+__global__ __launch_bounds__(64) void imv_scan_kernel(const float* __restrict__ sidx, const int* __restrict__ tlen,
+                                                      const int* __restrict__ mlen, float* __restrict__ imv, int T2) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* s = sidx + (long)b * T2;
+    float* o = imv + (long)b * T2;
+    const int ml = min(mlen[b], T2);
+    const int chunk = (T2 + 63) / 64;
+    const int j0 = lane * chunk, j1 = min(j0 + chunk, T2);
+    float loc = 0.f;
+    for (int j = j0; j < j1; ++j) loc += (j > 0) ? fmaxf(s[j] - s[j - 1], 0.f) : 0.f;
+    const float incl = wave_scan_incl(loc);
+    const float excl = incl - loc;                // exclusive carry of this lane
+    float fin = excl;                             // the value this lane will actually write last
+    for (int j = j0; j < j1; ++j) fin += (j > 0) ? fmaxf(s[j] - s[j - 1], 0.f) : 0.f;
+    // prefix-max carry: everything in this lane must be >= what the previous lanes wrote
+    float carry = __shfl_up(fin, 1);
+    if (lane == 0) carry = 0.f;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float t = __shfl_up(carry, off);
+        if (lane >= off) carry = fmaxf(carry, t);
+    }
+    float run = excl, last = carry;
+    for (int j = j0; j < j1; ++j) {
+        run += (j > 0) ? fmaxf(s[j] - s[j - 1], 0.f) : 0.f;
+        last = fmaxf(last, run);
+        o[j] = j < ml ? last : 0.f;
+    }
+    // max over the masked prefix = value at the last valid frame (monotone), taken by reduction
+    float mx = 0.f;
+    for (int j = j0; j < j1; ++j) mx = fmaxf(mx, o[j]);
+    mx = fmaxf(wave_max(mx), 1e-8f);
+    const float scale = (float)tlen[b] - 1.f;
+    for (int j = j0; j < j1; ++j) o[j] = o[j] / mx * scale;
+}
+
+// one wave per (b, i): e_i = sum_j softmax_j(-sigma_e (pi_j - i)^2) * j over valid frames
+__global__ __launch_bounds__(256) void aligned_pos_kernel(const float* __restrict__ imv, const int* __restrict__ tlen,
+                                                          const int* __restrict__ mlen, float sigma_e,
+                                                          float* __restrict__ e, int T1, int T2) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= T1) return;
+    const int tl = tlen[b], ml = min(mlen[b], T2);
+    float out = 0.f;
+    if (i < tl && ml > 0) {
+        const float* pi = imv + (long)b * T2;
+        const float p = (float)i;
+        float mx = -INFINITY;
+        for (int j = lane; j < ml; j += 64) {
+            const float d = pi[j] - p;
+            mx = fmaxf(mx, -sigma_e * d * d);
+        }
+        mx = wave_max(mx);
+        float se = 0.f, sj = 0.f;
+        for (int j = lane; j < ml; j += 64) {
+            const float d = pi[j] - p;
+            const float w = __expf(-sigma_e * d * d - mx);
+            se += w;
+            sj += w * (float)j;
+        }
+        se = wave_sum(se);
+        sj = wave_sum(sj);
+        out = sj / se;
+    }
+    if (lane == 0) e[(long)b * T1 + i] = out;
+}
+
+__global__ void dur_target_kernel(const float* __restrict__ e, const int* __restrict__ tlen, float offset,
+                                  float* __restrict__ lde, int B, int T1) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * T1) return;
+    const int b = idx / T1, i = idx - b * T1;
+    float v = 0.f;
+    if (i < tlen[b]) v = logf(e[idx] - (i > 0 ? e[idx - 1] : 0.f) + offset);
+    lde[idx] = v;
+}
+
+// one thread per (b, j) column: softmax over the T1 keys of -sigma (q_j - e_i)^2
+__global__ __launch_bounds__(128) void reconst_alpha_kernel(const float* __restrict__ e, const int* __restrict__ tlen,
+                                                            const int* __restrict__ mlen, float sigma,
+                                                            float* __restrict__ alpha, char* __restrict__ plane,
+                                                            long ldp, int T1, int T2, int T2p) {
+    extern __shared__ float es[];   // e[b, :]
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < T1; i += blockDim.x) es[i] = e[(long)b * T1 + i];
+    __syncthreads();
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= T2) return;
+    const int tl = tlen ? min(tlen[b], T1) : T1;
+    const bool live = mlen ? (j < mlen[b]) : true;
+    const float q = live ? (float)j : 0.f;
+    float mx = -INFINITY;
+    for (int i = 0; i < tl; ++i) {
+        const float d = q - es[i];
+        mx = fmaxf(mx, -sigma * d * d);
+    }
+    float se = 0.f;
+    for (int i = 0; i < tl; ++i) {
+        const float d = q - es[i];
+        se += __expf(-sigma * d * d - mx);
+    }
+    const float inv = (live && tl > 0) ? 1.f / se : 0.f;
+    const int kp = (T1 + 31) & ~31;
+    char* prow = plane ? plane + ((long)b * T2p + j) * ldp : nullptr;
+    for (int i0 = 0; i0 < kp; i0 += 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u;
+            float a = 0.f;
+            if (i < tl) {
+                const float d = q - es[i];
+                a = __expf(-sigma * d * d - mx) * inv;
+            }
+            v[u] = a;
+            if (alpha && i < T1) alpha[((long)b * T1 + i) * T2 + j] = a;
+        }
+        if (prow) plane_store4(prow, i0, v[0], v[1], v[2], v[3], 2);
+    }
+}
+
+// V [B*T1p][c] fp32 -> V^T split-2 planes [B][c][K = i]; one block = 32 i x 32 c
+__global__ __launch_bounds__(256) void pack_vt_kernel(const float* __restrict__ v, long ldv, char* __restrict__ plane,
+                                                      long ldp, int T1, int T1p, int c) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, c0 = blockIdx.y * 32, i0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + r;
+        tile[r][tx] = (i < T1 && c0 + tx < c) ? v[((long)b * T1p + i) * ldv + c0 + tx] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        if (c0 + r >= c) continue;
+        const float x = tile[tx][r];
+        const unsigned short hi = f32_to_bf16(x);
+        const unsigned short lo = f32_to_bf16(x - bf16_to_f32(hi));
+        char* d = plane + ((long)b * c + c0 + r) * ldp + (long)blockIdx.x * 128 + tx * 2;
+        *(unsigned short*)d = hi;
+        *(unsigned short*)(d + 64) = lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void cumsum_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int T) {
+    __shared__ float sh[4];
+    const float* xr = x + (long)blockIdx.x * T;
+    float* yr = y + (long)blockIdx.x * T;
+    const int chunk = (T + 255) / 256;
+    const int j0 = threadIdx.x * chunk, j1 = min(j0 + chunk, T);
+    float loc = 0.f;
+    for (int j = j0; j < j1; ++j) loc += xr[j];
+    float total;
+    float run = block_scan_excl256(loc, sh, &total);
+    for (int j = j0; j < j1; ++j) {
+        run += xr[j];
+        yr[j] = run;
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// LayerNorm over channels, one wave per row (c <= 2048, c % 4 == 0)
+// ----------------------------------------------------------------------------------------
+template <bool DOT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        const float* __restrict__ rowmask, float* __restrict__ f32o,
+                                                        char* __restrict__ plane, long ldp, int rows, int c, int split,
+                                                        const float* __restrict__ w, const float* __restrict__ bptr,
+                                                        int mode, float offset, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long)row * c;
+    float4 v[8];
+    const int nv = c >> 8;   // float4 per lane (c = 512 -> 2)
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (u < nv) {
+            v[u] = *(const float4*)(xr + u * 256 + lane * 4);
+            s += v[u].x + v[u].y + v[u].z + v[u].w;
+        }
+    const float mean = wave_sum(s) / (float)c;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (u < nv) {
+            v[u].x -= mean; v[u].y -= mean; v[u].z -= mean; v[u].w -= mean;
+            q += v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z + v[u].w * v[u].w;
+        }
+    const float rstd = 1.f / sqrtf(wave_sum(q) / (float)c + eps);
+    const float rm = rowmask ? rowmask[row] : 1.f;
+    float dot = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (u < nv) {
+            const int c4 = u * 256 + lane * 4;
+            const float4 g = *(const float4*)(gamma + c4), bb = *(const float4*)(beta + c4);
+            float4 y;
+            y.x = v[u].x * rstd * g.x + bb.x; y.y = v[u].y * rstd * g.y + bb.y;
+            y.z = v[u].z * rstd * g.z + bb.z; y.w = v[u].w * rstd * g.w + bb.w;
+            if constexpr (DOT) {
+                const float4 ww = *(const float4*)(w + c4);
+                dot += y.x * ww.x + y.y * ww.y + y.z * ww.z + y.w * ww.w;
+            } else {
+                y.x *= rm; y.y *= rm; y.z *= rm; y.w *= rm;
+                if (f32o) *(float4*)(f32o + (long)row * c + c4) = y;
+                if (plane) plane_store4(plane + (long)row * ldp, c4, y.x, y.y, y.z, y.w, split);
+            }
+        }
+    if constexpr (DOT) {
+        dot = wave_sum(dot) + bptr[0];
+        if (mode == 1) dot = fmaxf(expf(dot) - offset, 0.f);
+        if (lane == 0) out[row] = dot * rm;
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// masked losses: stage 1 partial sums per block, stage 2 one block finalises (deterministic)
+// ----------------------------------------------------------------------------------------
+constexpr int LOSS_BLOCKS = 512;
+
+__global__ __launch_bounds__(256) void losses_stage1(const float* __restrict__ mp, long ldm, const float* __restrict__ sp,
+                                                     const int* __restrict__ mlen, const float* __restrict__ dp,
+                                                     const float* __restrict__ lde, const int* __restrict__ tlen,
+                                                     float* __restrict__ part, int B, int T1, int T1p, int T2, int T2p,
+                                                     int odim) {
+    __shared__ float sh[4];
+    const long nmel = (long)B * T2 * odim;
+    float sm = 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nmel; idx += (long)LOSS_BLOCKS * 256) {
+        const long fr = idx / odim;
+        const int o = (int)(idx - fr * odim);
+        const int b = (int)(fr / T2), j = (int)(fr - (long)b * T2);
+        if (j < mlen[b]) {
+            const float d = mp[((long)b * T2p + j) * ldm + o] - sp[idx];
+            sm += d * d;
+        }
+    }
+    float sd = 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < (long)B * T1; idx += (long)LOSS_BLOCKS * 256) {
+        const int b = (int)(idx / T1), i = (int)(idx - (long)b * T1);
+        if (i < tlen[b]) sd += fabsf(dp[(long)b * T1p + i] - lde[idx]);
+    }
+    sm = block_sum256(sm, sh);
+    sd = block_sum256(sd, sh);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2] = sm;
+        part[blockIdx.x * 2 + 1] = sd;
+    }
+}
+
+__global__ __launch_bounds__(256) void losses_stage2(const float* __restrict__ part, const int* __restrict__ mlen,
+                                                     const int* __restrict__ tlen, float* __restrict__ out3, int B,
+                                                     int T1, int T2, int odim) {
+    __shared__ float sh[4];
+    float sm = 0.f, sd = 0.f, nm = 0.f, nt = 0.f;
+    for (int i = threadIdx.x; i < LOSS_BLOCKS; i += 256) {
+        sm += part[i * 2];
+        sd += part[i * 2 + 1];
+    }
+    for (int b = threadIdx.x; b < B; b += 256) {
+        nm += (float)min(mlen[b], T2);
+        nt += (float)min(tlen[b], T1);
+    }
+    sm = block_sum256(sm, sh);
+    sd = block_sum256(sd, sh);
+    nm = block_sum256(nm, sh);
+    nt = block_sum256(nt, sh);
+    if (threadIdx.x == 0) {
+        const float ml = sm / (nm * (float)odim), dl = sd / nt;
+        out3[0] = ml + dl;
+        out3[1] = ml;
+        out3[2] = dl;
+    }
+}
+
+}  // namespace efts
+
+using namespace efts;
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int efts_pack_weight(const float* w, const float* g, float* w_f32_out, void* plane, int64_t ldb,
+                                int32_t cout, int32_t cin, int32_t taps, int32_t split, void* stream) {
+    if (!w || !plane) return efts_fail(EFTS_EINVAL, "efts_pack_weight: null pointer");
+    if (!(split == 1 || split == 2) || cout <= 0 || cin <= 0 || taps <= 0) return efts_fail(EFTS_ESHAPE, "efts_pack_weight: bad shape/split");
+    const int kp = split == 1 ? (cin + 63) & ~63 : (cin + 31) & ~31;
+    if (ldb < (split == 1 ? kp * 2 : kp * 4) || (ldb & 15)) return efts_fail(EFTS_EALIGN, "efts_pack_weight: ldb too small or not 16-byte aligned");
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(cout), dim3(256), 0, ST, w, g, w_f32_out, (char*)plane, (long)ldb, cout, cin, taps, kp, split);
+    return efts_check_launch("efts_pack_weight");
+}
+
+extern "C" int efts_row_masks(const int32_t* lengths, float* gapmask, float* lenmask, int32_t B, int32_t T, int32_t Tp, void* stream) {
+    if (!lengths || B <= 0 || T <= 0 || Tp < T) return efts_fail(EFTS_EINVAL, "efts_row_masks: bad arguments");
+    hipLaunchKernelGGL(row_masks_kernel, dim3((B * Tp + 255) / 256), dim3(256), 0, ST, lengths, gapmask, lenmask, B, T, Tp);
+    return efts_check_launch("efts_row_masks");
+}
+
+extern "C" int efts_embed(const int64_t* ids, const float* table, float* f32_out, void* plane, int64_t ld_plane, int32_t B,
+                          int32_t T, int32_t Tp, int32_t c, int32_t num_symbols, int32_t split, void* stream) {
+    if (!ids || !table || (!f32_out && !plane)) return efts_fail(EFTS_EINVAL, "efts_embed: null pointer");
+    if (c % 4 || c > 4096 || B <= 0 || T <= 0 || Tp < T) return efts_fail(EFTS_ESHAPE, "efts_embed: c must be a multiple of 4 (<= 4096)");
+    hipLaunchKernelGGL(embed_kernel, dim3(B * Tp), dim3(((c / 4) + 63) & ~63), 0, ST, (const long*)ids, table, f32_out, (char*)plane,
+                       (long)ld_plane, T, Tp, c, num_symbols, split);
+    return efts_check_launch("efts_embed");
+}
+
+extern "C" int efts_pack_rows(const float* x, float* f32_out, void* plane, int64_t ld_plane, int32_t B, int32_t T, int32_t Tp,
+                              int32_t c, int32_t kp, int32_t split, void* stream) {
+    if (!x || (!f32_out && !plane)) return efts_fail(EFTS_EINVAL, "efts_pack_rows: null pointer");
+    if (kp % 4 || kp < c || kp > 4096) return efts_fail(EFTS_ESHAPE, "efts_pack_rows: kp must be a multiple of 4, >= c");
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(B * Tp), dim3(((kp / 4) + 63) & ~63), 0, ST, x, f32_out, (char*)plane, (long)ld_plane, T, Tp, c, kp, split);
+    return efts_check_launch("efts_pack_rows");
+}
+
+extern "C" int efts_attn_soft_index(const float* scores, int64_t ld, const int32_t* text_len, const int32_t* mel_len,
+                                    float* soft_idx, float* alpha_out, int32_t B, int32_t T1, int32_t T2, void* stream) {
+    if (!scores || !text_len || !mel_len || !soft_idx) return efts_fail(EFTS_EINVAL, "efts_attn_soft_index: null pointer");
+    if (ld < T1) return efts_fail(EFTS_ESHAPE, "efts_attn_soft_index: ld < T1");
+    const long rows = (long)B * T2;
+    hipLaunchKernelGGL(attn_soft_index_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST, scores, (long)ld, text_len, mel_len, soft_idx, alpha_out, B, T1, T2);
+    return efts_check_launch("efts_attn_soft_index");
+}
+
+extern "C" int efts_imv_scan(const float* soft_idx, const int32_t* text_len, const int32_t* mel_len, float* imv, int32_t B, int32_t T2, void* stream) {
+    if (!soft_idx || !text_len || !mel_len || !imv) return efts_fail(EFTS_EINVAL, "efts_imv_scan: null pointer");
+    hipLaunchKernelGGL(imv_scan_kernel, dim3(B), dim3(64), 0, ST, soft_idx, text_len, mel_len, imv, T2);
+    return efts_check_launch("efts_imv_scan");
+}
+
+extern "C" int efts_aligned_positions(const float* imv, const int32_t* text_len, const int32_t* mel_len, float sigma_e, float offset,
+                                      float* e, float* log_delta_e, int32_t B, int32_t T1, int32_t T2, void* stream) {
+    if (!imv || !text_len || !mel_len || !e) return efts_fail(EFTS_EINVAL, "efts_aligned_positions: null pointer");
+    hipLaunchKernelGGL(aligned_pos_kernel, dim3((T1 + 3) / 4, B), dim3(256), 0, ST, imv, text_len, mel_len, sigma_e, e, T1, T2);
+    if (log_delta_e)
+        hipLaunchKernelGGL(dur_target_kernel, dim3((B * T1 + 255) / 256), dim3(256), 0, ST, (const float*)e, text_len, offset, log_delta_e, B, T1);
+    return efts_check_launch("efts_aligned_positions");
+}
+
+extern "C" int efts_reconst_alpha(const float* e, const int32_t* text_len, const int32_t* mel_len, float sigma, float* alpha_out,
+                                  void* plane, int64_t ld_plane, int32_t B, int32_t T1, int32_t T2, int32_t T2p, void* stream) {
+    if (!e || (!alpha_out && !plane)) return efts_fail(EFTS_EINVAL, "efts_reconst_alpha: null pointer");
+    if (T1 <= 0 || T2 <= 0 || T2p < T2 || T1 > 8192) return efts_fail(EFTS_ESHAPE, "efts_reconst_alpha: bad shape");
+    if (plane && ld_plane < (int64_t)((T1 + 31) / 32) * 128) return efts_fail(EFTS_ESHAPE, "efts_reconst_alpha: ld_plane too small");
+    hipLaunchKernelGGL(reconst_alpha_kernel, dim3((T2 + 127) / 128, B), dim3(128), T1 * sizeof(float), ST, e, text_len, mel_len, sigma,
+                       alpha_out, (char*)plane, (long)ld_plane, T1, T2, T2p);
+    return efts_check_launch("efts_reconst_alpha");
+}
+
+extern "C" int efts_pack_vt(const float* v, int64_t ldv, void* plane, int64_t ld_plane, int32_t B, int32_t T1, int32_t T1p, int32_t c, void* stream) {
+    if (!v || !plane) return efts_fail(EFTS_EINVAL, "efts_pack_vt: null pointer");
+    if (ld_plane < (int64_t)((T1 + 31) / 32) * 128) return efts_fail(EFTS_ESHAPE, "efts_pack_vt: ld_plane too small");
+    hipLaunchKernelGGL(pack_vt_kernel, dim3((T1 + 31) / 32, (c + 31) / 32, B), dim3(256), 0, ST, v, (long)ldv, (char*)plane, (long)ld_plane, T1, T1p, c);
+    return efts_check_launch("efts_pack_vt");
+}
+
+extern "C" int efts_cumsum_rows(const float* x, float* y, int32_t B, int32_t T, void* stream) {
+    if (!x || !y || B <= 0 || T <= 0) return efts_fail(EFTS_EINVAL, "efts_cumsum_rows: bad arguments");
+    hipLaunchKernelGGL(cumsum_rows_kernel, dim3(B), dim3(256), 0, ST, x, y, T);
+    return efts_check_launch("efts_cumsum_rows");
+}
+
+extern "C" int efts_layernorm_rows(const float* x, const float* gamma, const float* beta, float eps, const float* rowmask,
+                                   float* f32_out, void* plane, int64_t ld_plane, int32_t rows, int32_t c, int32_t split, void* stream) {
+    if (!x || !gamma || !beta || (!f32_out && !plane)) return efts_fail(EFTS_EINVAL, "efts_layernorm_rows: null pointer");
+    if (c % 256 || c > 2048 || rows <= 0) return efts_fail(EFTS_ESHAPE, "efts_layernorm_rows: c must be a multiple of 256, <= 2048");
+    hipLaunchKernelGGL((layernorm_kernel<false>), dim3((rows + 3) / 4), dim3(256), 0, ST, x, gamma, beta, eps, rowmask, f32_out, (char*)plane,
+                       (long)ld_plane, rows, c, split, (const float*)nullptr, (const float*)nullptr, 0, 0.f, (float*)nullptr);
+    return efts_check_launch("efts_layernorm_rows");
+}
+
+extern "C" int efts_layernorm_dot(const float* x, const float* gamma, const float* beta, float eps, const float* w, const float* b,
+                                  const float* rowmask, int32_t mode, float offset, float* out, int32_t rows, int32_t c, void* stream) {
+    if (!x || !gamma || !beta || !w || !b || !out) return efts_fail(EFTS_EINVAL, "efts_layernorm_dot: null pointer");
+    if (c % 256 || c > 2048 || rows <= 0) return efts_fail(EFTS_ESHAPE, "efts_layernorm_dot: c must be a multiple of 256, <= 2048");
+    hipLaunchKernelGGL((layernorm_kernel<true>), dim3((rows + 3) / 4), dim3(256), 0, ST, x, gamma, beta, eps, rowmask, (float*)nullptr, (char*)nullptr,
+                       0L, rows, c, 1, w, b, mode, offset, out);
+    return efts_check_launch("efts_layernorm_dot");
+}
+
+extern "C" size_t efts_losses_workspace_bytes(void) { return (size_t)LOSS_BLOCKS * 2 * sizeof(float); }
+
+extern "C" int efts_masked_losses(const float* mel_pred, int64_t ldm, const float* speech, const int32_t* mel_len, const float* dur_pred,
+                                  const float* log_delta_e, const int32_t* text_len, float* out3, void* workspace, int32_t B, int32_t T1,
+                                  int32_t T1p, int32_t T2, int32_t T2p, int32_t odim, void* stream) {
+    if (!mel_pred || !speech || !mel_len || !dur_pred || !log_delta_e || !text_len || !out3 || !workspace)
+        return efts_fail(EFTS_EINVAL, "efts_masked_losses: null pointer");
+    hipLaunchKernelGGL(losses_stage1, dim3(LOSS_BLOCKS), dim3(256), 0, ST, mel_pred, (long)ldm, speech, mel_len, dur_pred, log_delta_e, text_len,
+                       (float*)workspace, B, T1, T1p, T2, T2p, odim);
+    hipLaunchKernelGGL(losses_stage2, dim3(1), dim3(256), 0, ST, (const float*)workspace, mel_len, text_len, out3, B, T1, T2, odim);
+    return efts_check_launch("efts_masked_losses");
+}

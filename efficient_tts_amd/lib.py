@@ -1,0 +1,104 @@
+"""ctypes binding of libefts_hip.so (the C ABI declared in include/efts_abi.h).
+
+The library is the product: there is NO CPU / PyTorch fallback.  If the shared object is
+missing or a call fails, an exception is raised with ``efts_last_error()``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libefts_hip.so")
+
+GAP = 2
+GUARD_LO = 8
+GUARD_HI = 144
+TILE_M = 128
+ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    """mirror of `struct efts_gemm_args` (include/efts_abi.h)"""
+    _fields_ = [
+        ("a", vp), ("lda", i64), ("a_batch_stride", i64),
+        ("b", vp), ("ldb", i64), ("b_tap_stride", i64), ("b_batch_stride", i64),
+        ("split", i32), ("taps", i32), ("m", i32), ("n", i32), ("nchunk", i32), ("batch", i32),
+        ("alpha", f32), ("act", i32), ("slope", f32),
+        ("bias", vp), ("resid", vp), ("ldr", i64), ("resid_batch_stride", i64),
+        ("rowmask", vp), ("rowmask_batch_stride", i64),
+        ("out_f32", vp), ("ldo", i64), ("out_batch_stride", i64),
+        ("out_bf16", vp), ("ldob", i64), ("outb_batch_stride", i64),
+        ("out_split", i32), ("reserved", i32),
+    ]
+
+
+_SIGS = {
+    "efts_version": (i32, []),
+    "efts_last_error": (C.c_char_p, []),
+    "efts_device_check": (i32, []),
+    "efts_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+    "efts_pack_weight": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "efts_row_masks": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "efts_embed": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
+    "efts_pack_rows": (i32, [vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
+    "efts_attn_soft_index": (i32, [vp, i64, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "efts_imv_scan": (i32, [vp, vp, vp, vp, i32, i32, vp]),
+    "efts_aligned_positions": (i32, [vp, vp, vp, f32, f32, vp, vp, i32, i32, i32, vp]),
+    "efts_reconst_alpha": (i32, [vp, vp, vp, f32, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "efts_pack_vt": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, vp]),
+    "efts_cumsum_rows": (i32, [vp, vp, i32, i32, vp]),
+    "efts_layernorm_rows": (i32, [vp, vp, vp, f32, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "efts_layernorm_dot": (i32, [vp, vp, vp, f32, vp, vp, vp, i32, f32, vp, i32, i32, vp]),
+    "efts_losses_workspace_bytes": (C.c_size_t, []),
+    "efts_masked_losses": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class EftsError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen libefts_hip.so and bind every symbol of include/efts_abi.h (no GPU needed)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EftsError(
+            f"{LIB_PATH} is missing: the HIP extension is the product path and has no fallback. "
+            "Build it with `python -m efficient_tts_amd.build` (needs hipcc, gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return list(_SIGS)
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().efts_last_error().decode(errors="replace")
+        if rc in (-1, -2, -3):
+            raise ValueError(f"{what}: {msg} (code {rc})")
+        raise EftsError(f"{what}: {msg} (code {rc})")
+
+
+_device_ok = False
+
+
+def require_device() -> None:
+    """Fail loudly unless a gfx950 device is current (also opts kernels into large LDS)."""
+    global _device_ok
+    if not _device_ok:
+        check(load().efts_device_check(), "efts_device_check")
+        _device_ok = True

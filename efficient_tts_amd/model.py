@@ -1,0 +1,415 @@
+"""EfficientTTSCNN on MI355X: the host-side mirror of the reference model class.
+
+Same class name, ctor kwargs, ``forward`` / ``inference`` signatures and returns, and
+``state_dict`` keys as ``nntts.models.EfficientTTSCNN`` (reference
+nntts/models/efficient_tts.py:23-418), so ``getattr(pkg.models, config["model_name"])(**config["model_params"])``
+(nntts/bin/train.py:173-185) and reference checkpoints work unchanged.  All arithmetic runs in
+hand-written HIP kernels behind the C ABI of ``libefts_hip.so`` (include/efts_abi.h); PyTorch
+only owns device memory, streams and the parameter containers.  There is no torch/CPU
+fallback: without the library or a gfx950 device the model raises.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import lib as L
+from . import ops as O
+from .ops import F32Rows, PackedWeight, Plane, Rows
+
+
+# --------------------------------------------------------------------------------------
+# Parameter containers.  torch.nn modules are used ONLY to hold/initialise parameters
+# with the reference's names and default init order; their forward() is never called.
+# --------------------------------------------------------------------------------------
+class _ResConv1d(torch.nn.Module):                     # efts_modules.py:19-51 (names only)
+    def __init__(self, n_channels, k_size, act, act_params, dropout_rate):
+        super().__init__()
+        mods = [torch.nn.Conv1d(n_channels, n_channels, kernel_size=k_size, padding=(k_size - 1) // 2),
+                getattr(torch.nn, act)(**act_params)]
+        if dropout_rate >= 1e-5:
+            mods.append(torch.nn.Dropout(dropout_rate))
+        self.conv = torch.nn.Sequential(*mods)
+
+
+class _ResConvBlock(torch.nn.Module):                  # efts_modules.py:54-99 (names only)
+    def __init__(self, num_layers, n_channels, k_size, act, act_params, dropout_rate, use_weight_norm):
+        super().__init__()
+        self.num_layers = num_layers
+        self.layers = torch.nn.Sequential(*[_ResConv1d(n_channels, k_size, act, act_params, dropout_rate)
+                                            for _ in range(num_layers)])
+        if use_weight_norm:
+            for m in self.modules():
+                if isinstance(m, torch.nn.Conv1d):
+                    torch.nn.utils.weight_norm(m)
+
+
+class _DurationPredictor(torch.nn.Module):             # duration_predictor.py:28-64 (names only)
+    def __init__(self, idim, n_layers, n_chans, kernel_size=3, dropout_rate=0.1, offset=1.0):
+        super().__init__()
+        self.offset, self.n_layers = offset, n_layers
+        self.conv = torch.nn.ModuleList()
+        for _ in range(n_layers):
+            self.conv.append(torch.nn.Sequential(
+                torch.nn.Conv1d(n_chans, n_chans, kernel_size, stride=1, padding=(kernel_size - 1) // 2),
+                torch.nn.ReLU(),
+                torch.nn.LayerNorm(n_chans, eps=1e-12),       # layer_norm.py:14-17
+                torch.nn.Dropout(dropout_rate)))
+        self.linear = torch.nn.Linear(n_chans, 1)
+
+
+class LazyStats(dict):
+    """``stats`` of the reference forward (efficient_tts.py:225-227) without the three
+    per-step host syncs: values stay on the device until a key is read."""
+
+    def __init__(self, out3: torch.Tensor):
+        super().__init__(loss=None, mel_loss=None, duration_loss=None)
+        self._t, self._v = out3, None
+
+    def _vals(self):
+        if self._v is None:
+            self._v = self._t.tolist()
+        return dict(loss=self._v[0], mel_loss=self._v[1], duration_loss=self._v[2])
+
+    def __getitem__(self, k):
+        return self._vals()[k]
+
+    def items(self):
+        return self._vals().items()
+
+    def values(self):
+        return self._vals().values()
+
+    def __repr__(self):
+        return repr(self._vals())
+
+
+class _Workspace:
+    """Named device buffers for one (B, T1, T2) shape; zero-initialised once, so guard and gap
+    rows stay zero (kernels never write them with non-zero values)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs: Dict[str, object] = {}
+
+    def f32(self, name: str, rs: Rows, c: int) -> F32Rows:
+        key = ("f", name, rs.B, rs.T, c)
+        if key not in self.bufs:
+            self.bufs[key] = F32Rows(rs, c, self.device)
+        return self.bufs[key]
+
+    def plane(self, name: str, rs: Rows, k: int, split: int) -> Plane:
+        key = ("p", name, rs.B, rs.T, k, split)
+        if key not in self.bufs:
+            self.bufs[key] = Plane.for_rows(rs, k, split, self.device)
+        return self.bufs[key]
+
+    def raw_plane(self, name: str, nrows: int, k: int, split: int) -> Plane:
+        key = ("rp", name, nrows, k, split)
+        if key not in self.bufs:
+            self.bufs[key] = Plane(nrows, k, split, self.device)
+        return self.bufs[key]
+
+    def tensor(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
+        key = ("t", name, tuple(shape), dtype)
+        if key not in self.bufs:
+            self.bufs[key] = torch.zeros(*shape, dtype=dtype, device=self.device)
+        return self.bufs[key]
+
+
+PRECISIONS = {"bf16": 1, "bf16x3": 2}
+
+
+class EfficientTTSCNN(torch.nn.Module):
+    """EFTS-CNN acoustic model (drop-in for nntts.models.EfficientTTSCNN).
+
+    Extra keyword (not in the reference): ``precision`` selects the MFMA operand mode of the
+    Conv1d/Linear stacks: "bf16x3" (split-bf16, fp32-class accuracy; default) or "bf16".
+    The alignment block (QK^T, expand) always runs in bf16x3 / fp32.
+    """
+
+    def __init__(self, num_symbols: int, odim: int = 80, symbol_embedding_dim: int = 512, n_channels: int = 512,
+                 n_text_encoder_layer: int = 5, n_mel_encoder_layer: int = 3, n_decoder_layer: int = 6,
+                 n_duration_layer: int = 2, k_size: int = 5, nonlinear_activation="LeakyReLU",
+                 nonlinear_activation_params={"negative_slope": 0.1}, use_weight_norm=True, dropout_rate=0.1,
+                 use_masking: bool = False, use_weighted_masking: bool = False, duration_offset=1.0, sigma=0.01,
+                 sigma_e=0.5, delta_e_method_1=True, share_text_encoder_key_value=False, use_mel_query_fc=False,
+                 precision: str = "bf16x3"):
+        super().__init__()
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {list(PRECISIONS)}")
+        if nonlinear_activation != "LeakyReLU":
+            raise NotImplementedError("the HIP conv epilogue implements LeakyReLU (the only activation any reference config uses)")
+        if symbol_embedding_dim != n_channels:
+            raise ValueError("symbol_embedding_dim must equal n_channels (the reference adds them residually)")
+        if k_size != 5:
+            raise NotImplementedError("k_size must be 5 (row-space gap = 2)")
+        if not delta_e_method_1 or share_text_encoder_key_value or use_mel_query_fc:
+            raise NotImplementedError("only the shipped configuration (delta_e_method_1, separate K/V, no mel_query_fc) is implemented")
+        if not use_masking or use_weighted_masking:
+            raise NotImplementedError("FastSpeechLoss is implemented for use_masking=True (the egs/lj YAML)")
+        if n_channels % 256 or odim > 128:
+            raise NotImplementedError("n_channels must be a multiple of 256 and odim <= 128")
+        self.precision = precision
+        self.split = PRECISIONS[precision]
+        self.odim, self.n_channels, self.num_symbols = odim, n_channels, num_symbols
+        self.duration_offset, self.sigma, self.sigma_e = duration_offset, sigma, sigma_e
+        self.delta_e_method_1 = delta_e_method_1
+        self.share_text_encoder_key_value = share_text_encoder_key_value
+        self.slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
+        self.dropout_rate = dropout_rate
+        a, ap = nonlinear_activation, nonlinear_activation_params
+        # construction order == reference (efficient_tts.py:57-112) so a given torch seed
+        # yields the reference's default initialisation
+        self.text_embedding_table = torch.nn.Embedding(num_symbols, symbol_embedding_dim)
+        self.text_encoder = _ResConvBlock(n_text_encoder_layer, n_channels, k_size, a, ap, dropout_rate, use_weight_norm)
+        self.text_encoder_key = torch.nn.Linear(n_channels, n_channels)
+        self.text_encoder_value = torch.nn.Linear(n_channels, n_channels)
+        self.mel_prenet = torch.nn.Sequential(torch.nn.Linear(odim, n_channels), getattr(torch.nn, a)(**ap),
+                                              torch.nn.Dropout(dropout_rate))
+        self.mel_encoder = _ResConvBlock(n_mel_encoder_layer, n_channels, k_size, a, ap, dropout_rate, use_weight_norm)
+        self.mel_query_fc = None
+        self.decoder = _ResConvBlock(n_decoder_layer, n_channels, k_size, a, ap, dropout_rate, use_weight_norm)
+        self.mel_output_layer = torch.nn.Linear(n_channels, odim)
+        self.duration_predictor = _DurationPredictor(n_channels, n_duration_layer, n_channels, offset=duration_offset)
+        self._packed: Dict[str, PackedWeight] = {}
+        self._packed_sig = None
+        self._ws: Dict[Tuple, _Workspace] = {}
+
+    # ------------------------------------------------------------------ weight norm (efficient_tts.py:400-418)
+    def remove_weight_norm(self):
+        for m in self.modules():
+            if isinstance(m, torch.nn.Conv1d) and hasattr(m, "weight_g"):
+                torch.nn.utils.remove_weight_norm(m)
+                logging.debug(f"Weight norm is removed from {m}.")
+        self._packed_sig = None
+
+    def apply_weight_norm(self):
+        for m in self.modules():
+            if isinstance(m, torch.nn.Conv1d) and not hasattr(m, "weight_g"):
+                torch.nn.utils.weight_norm(m)
+        self._packed_sig = None
+
+    # ------------------------------------------------------------------ packed weights
+    def _conv_modules(self):
+        out = []
+        for blk in ("text_encoder", "mel_encoder", "decoder"):
+            for i, layer in enumerate(getattr(self, blk).layers):
+                out.append((f"{blk}.{i}", layer.conv[0]))
+        for i, seq in enumerate(self.duration_predictor.conv):
+            out.append((f"dur.{i}", seq[0]))
+        return out
+
+    def _weights(self) -> Dict[str, PackedWeight]:
+        """B operand planes of every Conv1d/Linear; repacked (weight-norm fold fused) whenever
+        a parameter changed (optimizer step, load_state_dict, .to())."""
+        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if sig == self._packed_sig:
+            return self._packed
+        dev = self.text_embedding_table.weight.device
+        pk = self._packed
+        for name, conv in self._conv_modules():
+            taps = conv.kernel_size[0]
+            if name not in pk or pk[name].buf.device != dev:
+                pk[name] = PackedWeight(conv.out_channels, conv.in_channels, taps, self.split, dev)
+            if hasattr(conv, "weight_g"):
+                pk[name].pack(conv.weight_v.detach().contiguous(), conv.weight_g.detach().contiguous())
+            else:
+                pk[name].pack(conv.weight.detach().contiguous())
+        lin_split = {"key": self.split, "value": self.split, "prenet": self.split, "head": self.split}
+        lins = {"key": self.text_encoder_key, "value": self.text_encoder_value, "prenet": self.mel_prenet[0],
+                "head": self.mel_output_layer}
+        for name, lin in lins.items():
+            if name not in pk or pk[name].buf.device != dev:
+                pk[name] = PackedWeight(lin.out_features, lin.in_features, 1, lin_split[name], dev)
+            pk[name].pack(lin.weight.detach().contiguous())
+        self._packed_sig = sig
+        return pk
+
+    def _workspace(self, key, device) -> _Workspace:
+        if key not in self._ws:
+            if len(self._ws) >= 4:                      # bound cached shapes (each holds full activations)
+                self._ws.pop(next(iter(self._ws)))
+            self._ws[key] = _Workspace(device)
+        return self._ws[key]
+
+    # ------------------------------------------------------------------ building blocks
+    def _res_stack(self, ws, tag, blk, pk, rs: Rows, x_f32: F32Rows, x_pl: Plane, gap_ptr, last_split: int,
+                   last_f32: bool):
+        """n x ( x + LeakyReLU(conv1d_k5(x)) ) on the row space (efts_modules.py:48-51,77-79)."""
+        n = len(getattr(self, blk).layers)
+        C = self.n_channels
+        for i in range(n):
+            last = i == n - 1
+            w = pk[f"{blk}.{i}"]
+            o_split = last_split if last else self.split
+            o_f32 = ws.f32(f"{tag}_f{i & 1}", rs, C) if (not last or last_f32) else None
+            o_pl = ws.plane(f"{tag}_p{i & 1}", rs, C, o_split)
+            O.gemm(a=x_pl, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=5, m=rs.rows, n=C,
+                   act=L.ACT_LEAKY, slope=self.slope, bias=getattr(self, blk).layers[i].conv[0].bias,
+                   resid_ptr=x_f32.ptr, ldr=C, rowmask_ptr=gap_ptr,
+                   out_f32_ptr=None if o_f32 is None else o_f32.ptr, ldo=C, out_plane=o_pl)
+            x_f32, x_pl = o_f32, o_pl
+        return x_f32, x_pl
+
+    def _text_side(self, ws, pk, text, rs1: Rows, gap1, len1):
+        """embed -> text encoder -> key (split-2 plane, masked), value (fp32 + plane, masked)
+        (efficient_tts.py:144-157 / :246-255)."""
+        C = self.n_channels
+        x_f = ws.f32("emb_f", rs1, C)
+        x_p = ws.plane("emb_p", rs1, C, self.split)
+        O.embed(text, self.text_embedding_table.weight.detach(), x_f, x_p, rs1)
+        _, h_p = self._res_stack(ws, "te", "text_encoder", pk, rs1, x_f, x_p, gap1.data_ptr(), self.split, False)
+        key_p = ws.plane("key_p", rs1, C, 2)
+        val_f = ws.f32("val_f", rs1, C)
+        val_p = ws.plane("val_p", rs1, C, self.split)
+        lm = None if len1 is None else len1.data_ptr()
+        wk, wv = pk["key"], pk["value"]
+        O.gemm(a=h_p, b_ptr=wk.ptr, ldb=wk.ld, m=rs1.rows, n=C, bias=self.text_encoder_key.bias,
+               rowmask_ptr=lm if lm is not None else gap1.data_ptr(), out_plane=key_p)
+        O.gemm(a=h_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=self.text_encoder_value.bias,
+               rowmask_ptr=lm if lm is not None else gap1.data_ptr(), out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p)
+        return key_p, val_f, val_p
+
+    def _duration(self, ws, pk, rs1: Rows, val_p: Plane, gap1, out_mask_ptr, mode: int) -> torch.Tensor:
+        """DurationPredictor._forward (duration_predictor.py:66-88); eval-mode (Dropout = identity)."""
+        C = self.n_channels
+        dp = self.duration_predictor
+        h_f = ws.f32("dur_f", rs1, C)
+        x_p = val_p
+        out = ws.tensor("dur_out", (rs1.rows,))
+        for i, seq in enumerate(dp.conv):
+            w = pk[f"dur.{i}"]
+            O.gemm(a=x_p, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=3, m=rs1.rows, n=C, act=L.ACT_RELU,
+                   bias=seq[0].bias, out_f32_ptr=h_f.ptr, ldo=C)
+            ln = seq[2]
+            if i + 1 < len(dp.conv):
+                x_p = ws.plane(f"dur_p{i}", rs1, C, self.split)
+                O.layernorm_rows(h_f.ptr, ln.weight.detach(), ln.bias.detach(), ln.eps, gap1.data_ptr(), None, x_p,
+                                 rs1.rows, C)
+            else:
+                O.layernorm_dot(h_f.ptr, ln.weight.detach(), ln.bias.detach(), ln.eps, dp.linear.weight.detach(),
+                                dp.linear.bias.detach(), out_mask_ptr, mode, float(dp.offset), out, rs1.rows, C)
+        return out
+
+    def _expand_decode(self, ws, pk, B, T1, rs1: Rows, rs2: Rows, val_f: F32Rows, ra_plane: Plane, len2_ptr, gap2):
+        """bmm(V^T, alpha') -> decoder -> mel head (efficient_tts.py:190-200 / :278-284)."""
+        C = self.n_channels
+        vt = ws.raw_plane("vt", B * C, T1, 2)
+        O.pack_vt(val_f, vt, B, T1, rs1.Tp, C)
+        h_f = ws.f32("exp_f", rs2, C)
+        h_p = ws.plane("exp_p", rs2, C, self.split)
+        O.gemm(a=ra_plane, b_ptr=vt.ptr, ldb=vt.ld, m=rs2.T, n=C, batch=B, a_batch_stride=rs2.Tp * ra_plane.ld,
+               b_batch_stride=C * vt.ld, rowmask_ptr=len2_ptr, rowmask_batch_stride=rs2.Tp,
+               out_f32_ptr=h_f.ptr, ldo=C, out_batch_stride=rs2.Tp * C, out_plane=h_p,
+               outb_batch_stride=rs2.Tp * h_p.ld)
+        _, d_p = self._res_stack(ws, "dec", "decoder", pk, rs2, h_f, h_p, gap2.data_ptr(), self.split, False)
+        mel = ws.f32("mel_pred", rs2, self.odim)
+        wh = pk["head"]
+        O.gemm(a=d_p, b_ptr=wh.ptr, ldb=wh.ld, m=rs2.rows, n=self.odim, bias=self.mel_output_layer.bias,
+               rowmask_ptr=len2_ptr if len2_ptr is not None else gap2.data_ptr(), out_f32_ptr=mel.ptr, ldo=self.odim)
+        return mel
+
+    def _require(self, t: torch.Tensor):
+        if not t.is_cuda:
+            raise L.EftsError("EfficientTTSCNN runs on an MI355X only: inputs/parameters must be on a ROCm device "
+                              "(there is no CPU fallback)")
+        L.require_device()
+
+    # ------------------------------------------------------------------ forward (efficient_tts.py:120-228)
+    def forward(self, text: torch.Tensor, text_lengths: torch.Tensor, speech: torch.Tensor,
+                speech_lengths: torch.Tensor):
+        """Teacher-forced forward.  Returns (loss, stats, imv[B,T2], reconst_alpha[B,T1,T2],
+        mel_pred[B,T2,odim], speech) exactly like the reference (:228)."""
+        self._require(text)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .autograd import training_forward
+            return training_forward(self, text, text_lengths, speech, speech_lengths)
+        return self._forward_impl(text, text_lengths, speech, speech_lengths)[0]
+
+    def _forward_impl(self, text, text_lengths, speech, speech_lengths, keep: bool = False):
+        dev = text.device
+        B, T1 = text.shape
+        T2 = speech.shape[1]
+        C = self.n_channels
+        text = text.contiguous()
+        speech = speech.contiguous().float()
+        tl = text_lengths.to(device=dev, dtype=torch.int32)
+        ml = speech_lengths.to(device=dev, dtype=torch.int32)
+        pk = self._weights()
+        ws = self._workspace(("fwd", B, T1, T2), dev)
+        rs1, rs2 = Rows(B, T1), Rows(B, T2)
+        gap1, len1 = ws.tensor("gap1", (rs1.rows,)), ws.tensor("len1", (rs1.rows,))
+        gap2, len2 = ws.tensor("gap2", (rs2.rows,)), ws.tensor("len2", (rs2.rows,))
+        O.row_masks(tl, rs1, gap1, len1)                                          # :137
+        O.row_masks(ml, rs2, gap2, len2)                                          # :139
+
+        key_p, val_f, val_p = self._text_side(ws, pk, text, rs1, gap1, len1)      # :144-157
+
+        mel_in = ws.plane("mel_in", rs2, self.odim, self.split)                   # :161 prenet
+        O.pack_rows(speech, None, mel_in, rs2)
+        pre_f, pre_p = ws.f32("pre_f", rs2, C), ws.plane("pre_p", rs2, C, self.split)
+        wp = pk["prenet"]
+        O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, act=L.ACT_LEAKY, slope=self.slope,
+               bias=self.mel_prenet[0].bias, rowmask_ptr=gap2.data_ptr(), out_f32_ptr=pre_f.ptr, ldo=C, out_plane=pre_p)
+        _, q_p = self._res_stack(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2, False)   # :162
+
+        scores = ws.tensor("scores", (B, T2, T1))                                 # :390 q.k/sqrt(D)
+        O.gemm(a=q_p, b_ptr=key_p.ptr, ldb=key_p.ld, m=T2, n=T1, batch=B, a_batch_stride=rs2.Tp * q_p.ld,
+               b_batch_stride=rs1.Tp * key_p.ld, alpha=O.INV_SQRT(C), out_f32_ptr=scores.data_ptr(), ldo=T1,
+               out_batch_stride=T2 * T1)
+        sidx, imv = ws.tensor("sidx", (B, T2)), ws.tensor("imv", (B, T2))
+        alpha = ws.tensor("alpha", (B, T1, T2)) if keep else None
+        O.attn_soft_index(scores, T1, tl, ml, sidx, alpha, B, T1, T2)             # :391-398, :168, :312
+        O.imv_scan(sidx, tl, ml, imv, B, T2)                                      # :314-323
+        e, lde = ws.tensor("e", (B, T1)), ws.tensor("lde", (B, T1))
+        O.aligned_positions(imv, tl, ml, float(self.sigma_e), float(self.duration_offset), e, lde, B, T1, T2)  # :178-180, :203-216
+        ralpha = torch.empty(B, T1, T2, dtype=torch.float32, device=dev)
+        ra_p = ws.plane("ra_p", rs2, T1, 2)
+        O.reconst_alpha(e, tl, ml, float(self.sigma), ralpha, ra_p, B, T1, T2, rs2.Tp)   # :184-186
+
+        mel = self._expand_decode(ws, pk, B, T1, rs1, rs2, val_f, ra_p, len2.data_ptr(), gap2)   # :190-200
+        dur = self._duration(ws, pk, rs1, val_p, gap1, len1.data_ptr(), 0)        # :219
+
+        out3 = torch.empty(3, dtype=torch.float32, device=dev)                     # :220-227
+        O.masked_losses(mel.ptr, self.odim, speech, ml, dur, lde, tl, out3, ws.tensor("loss_ws", (1024,)), B, T1,
+                        rs1.Tp, T2, rs2.Tp, self.odim)
+        mel_pred = mel.view().clone()
+        ret = (out3[0], LazyStats(out3), imv.clone(), ralpha, mel_pred, speech)
+        extra = dict(e=e, log_delta_e=lde, dur_pred=dur.view(B, rs1.Tp)[:, :T1], ws=ws) if keep else None
+        return ret, extra
+
+    # ------------------------------------------------------------------ inference (efficient_tts.py:230-285)
+    @torch.no_grad()
+    def inference(self, text: torch.Tensor, text_lengths: torch.Tensor = None):
+        """Free-running synthesis of ONE utterance: returns (mel_pred[1,T2,odim], reconst_alpha[1,T1,T2])."""
+        self._require(text)
+        if text.shape[0] != 1:
+            raise ValueError("inference() takes one utterance, like the reference (efficient_tts.py:361); "
+                             "use inference_batch() for B > 1")
+        dev = text.device
+        T1, C = text.shape[1], self.n_channels
+        pk = self._weights()
+        ws = self._workspace(("inf", 1, T1), dev)
+        rs1 = Rows(1, T1)
+        full = torch.full((1,), T1, dtype=torch.int32, device=dev)
+        gap1 = ws.tensor("gap1", (rs1.rows,))
+        O.row_masks(full, rs1, gap1, None)
+        _, val_f, val_p = self._text_side(ws, pk, text.contiguous(), rs1, gap1, None)         # :246-255
+        delta = self._duration(ws, pk, rs1, val_p, gap1, gap1.data_ptr(), 1)      # :258  clamp(exp(.)-offset, 0)
+        e = ws.tensor("e", (1, T1))
+        O.cumsum_rows(delta[:T1], e, 1, T1)                                       # :260
+        t2 = int(torch.round(e[0, -1]).item())                                    # :361 (host sync, as the reference)
+        if t2 <= 0:
+            raise ValueError("predicted total duration rounds to 0 frames")
+        rs2 = Rows(1, t2)
+        ws2 = self._workspace(("inf2", 1, T1, t2), dev)
+        gap2 = ws2.tensor("gap2", (rs2.rows,))
+        O.row_masks(torch.full((1,), t2, dtype=torch.int32, device=dev), rs2, gap2, None)
+        ralpha = torch.empty(1, T1, t2, dtype=torch.float32, device=dev)
+        ra_p = ws2.plane("ra_p", rs2, T1, 2)
+        O.reconst_alpha(e, None, None, float(self.sigma), ralpha, ra_p, 1, T1, t2, rs2.Tp)   # :270-274
+        mel = self._expand_decode(ws2, pk, 1, T1, rs1, rs2, val_f, ra_p, None, gap2)         # :278-284
+        return mel.view().clone(), ralpha

@@ -1,0 +1,187 @@
+"""Thin typed wrappers: torch tensors (device memory + stream plumbing) -> C-ABI calls.
+
+Nothing here computes: every function marshals pointers/sizes into libefts_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def roundup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def chunk_k(split: int) -> int:
+    """k's per 128-byte chunk of an operand plane"""
+    return 64 if split == 1 else 32
+
+
+class Rows:
+    """Geometry of a padded row space (include/efts_abi.h "Row space")."""
+
+    def __init__(self, B: int, T: int):
+        self.B, self.T, self.Tp = B, T, T + L.GAP
+        self.rows = B * self.Tp
+        self.alloc = L.GUARD_LO + roundup(self.rows, L.TILE_M) + L.GUARD_HI
+
+
+class F32Rows:
+    """fp32 [rows, C] stream with zero guard rows; `.ptr` points at row 0."""
+
+    def __init__(self, rs: Rows, c: int, device):
+        self.rs, self.c = rs, c
+        self.buf = torch.zeros(rs.alloc, c, dtype=torch.float32, device=device)
+        self.ptr = self.buf.data_ptr() + L.GUARD_LO * c * 4
+
+    def view(self) -> torch.Tensor:
+        """[B, T, C] strided view of the valid rows (no copy)."""
+        rs = self.rs
+        return self.buf[L.GUARD_LO:L.GUARD_LO + rs.rows].view(rs.B, rs.Tp, self.c)[:, :rs.T]
+
+
+class Plane:
+    """bf16 MFMA operand plane [rows, nchunk*128 B] (split 1: bf16; split 2: hi/lo interleaved)."""
+
+    def __init__(self, nrows_alloc: int, k: int, split: int, device, guard_lo: int = 0):
+        self.split, self.k = split, k
+        self.nchunk = (k + chunk_k(split) - 1) // chunk_k(split)
+        self.ld = self.nchunk * 128
+        self.buf = torch.zeros(nrows_alloc, self.ld, dtype=torch.uint8, device=device)
+        self.ptr = self.buf.data_ptr() + guard_lo * self.ld
+
+    @staticmethod
+    def for_rows(rs: Rows, k: int, split: int, device) -> "Plane":
+        return Plane(rs.alloc, k, split, device, guard_lo=L.GUARD_LO)
+
+
+def gemm(*, a: Plane, a_ptr: Optional[int] = None, b_ptr: int, ldb: int, b_tap_stride: int = 0, taps: int = 1,
+         m: int, n: int, batch: int = 1, a_batch_stride: int = 0, b_batch_stride: int = 0, alpha: float = 1.0,
+         act: int = L.ACT_NONE, slope: float = 0.0, bias: Optional[torch.Tensor] = None,
+         resid_ptr: Optional[int] = None, ldr: int = 0, resid_batch_stride: int = 0,
+         rowmask_ptr: Optional[int] = None, rowmask_batch_stride: int = 0,
+         out_f32_ptr: Optional[int] = None, ldo: int = 0, out_batch_stride: int = 0,
+         out_plane: Optional[Plane] = None, out_plane_ptr: Optional[int] = None, outb_batch_stride: int = 0,
+         nchunk: Optional[int] = None) -> None:
+    g = L.GemmArgs()
+    g.a, g.lda, g.a_batch_stride = (a_ptr if a_ptr is not None else a.ptr), a.ld, a_batch_stride
+    g.b, g.ldb, g.b_tap_stride, g.b_batch_stride = b_ptr, ldb, b_tap_stride, b_batch_stride
+    g.split, g.taps, g.m, g.n = a.split, taps, m, n
+    g.nchunk, g.batch = (a.nchunk if nchunk is None else nchunk), batch
+    g.alpha, g.act, g.slope = alpha, act, slope
+    g.bias = _p(bias)
+    g.resid, g.ldr, g.resid_batch_stride = resid_ptr, ldr, resid_batch_stride
+    g.rowmask, g.rowmask_batch_stride = rowmask_ptr, rowmask_batch_stride
+    g.out_f32, g.ldo, g.out_batch_stride = out_f32_ptr, ldo, out_batch_stride
+    if out_plane is not None:
+        g.out_bf16 = out_plane_ptr if out_plane_ptr is not None else out_plane.ptr
+        g.ldob, g.out_split = out_plane.ld, out_plane.split
+    g.outb_batch_stride = outb_batch_stride
+    L.check(L.load().efts_gemm(C.byref(g), _stream()), "efts_gemm")
+
+
+class PackedWeight:
+    """B operand plane [taps][cout][ld] of one Conv1d / Linear weight."""
+
+    def __init__(self, cout: int, cin: int, taps: int, split: int, device):
+        self.cout, self.cin, self.taps, self.split = cout, cin, taps, split
+        self.nchunk = (cin + chunk_k(split) - 1) // chunk_k(split)
+        self.ld = self.nchunk * 128
+        self.buf = torch.zeros(taps, cout, self.ld, dtype=torch.uint8, device=device)
+        self.ptr = self.buf.data_ptr()
+        self.tap_stride = cout * self.ld
+
+    def pack(self, w: torch.Tensor, g: Optional[torch.Tensor] = None, w_out: Optional[torch.Tensor] = None) -> None:
+        """w: fp32 [cout, cin, taps] or [cout, cin] contiguous; g: weight-norm gain [cout,1,1] or None."""
+        assert w.is_contiguous() and w.dtype == torch.float32
+        L.check(L.load().efts_pack_weight(w.data_ptr(), _p(g), _p(w_out), self.ptr, self.ld, self.cout, self.cin,
+                                          self.taps, self.split, _stream()), "efts_pack_weight")
+
+
+def row_masks(lengths_i32: torch.Tensor, rs: Rows, gap: Optional[torch.Tensor], lenmask: Optional[torch.Tensor]) -> None:
+    L.check(L.load().efts_row_masks(lengths_i32.data_ptr(), _p(gap), _p(lenmask), rs.B, rs.T, rs.Tp, _stream()),
+            "efts_row_masks")
+
+
+def embed(ids: torch.Tensor, table: torch.Tensor, out: Optional[F32Rows], plane: Optional[Plane], rs: Rows) -> None:
+    c = table.shape[1]
+    L.check(L.load().efts_embed(ids.data_ptr(), table.data_ptr(), None if out is None else out.ptr,
+                                None if plane is None else plane.ptr, 0 if plane is None else plane.ld,
+                                rs.B, rs.T, rs.Tp, c, table.shape[0], 1 if plane is None else plane.split, _stream()),
+            "efts_embed")
+
+
+def pack_rows(x: torch.Tensor, out: Optional[F32Rows], plane: Optional[Plane], rs: Rows) -> None:
+    c = x.shape[-1]
+    kp = roundup(c, 4) if plane is None else plane.nchunk * chunk_k(plane.split)
+    L.check(L.load().efts_pack_rows(x.data_ptr(), None if out is None else out.ptr,
+                                    None if plane is None else plane.ptr, 0 if plane is None else plane.ld,
+                                    rs.B, rs.T, rs.Tp, c, kp, 1 if plane is None else plane.split, _stream()),
+            "efts_pack_rows")
+
+
+def attn_soft_index(scores, ld, tl, ml, soft_idx, alpha_out, B, T1, T2) -> None:
+    L.check(L.load().efts_attn_soft_index(scores.data_ptr(), ld, tl.data_ptr(), ml.data_ptr(), soft_idx.data_ptr(),
+                                          _p(alpha_out), B, T1, T2, _stream()), "efts_attn_soft_index")
+
+
+def imv_scan(soft_idx, tl, ml, imv, B, T2) -> None:
+    L.check(L.load().efts_imv_scan(soft_idx.data_ptr(), tl.data_ptr(), ml.data_ptr(), imv.data_ptr(), B, T2, _stream()),
+            "efts_imv_scan")
+
+
+def aligned_positions(imv, tl, ml, sigma_e, offset, e, lde, B, T1, T2) -> None:
+    L.check(L.load().efts_aligned_positions(imv.data_ptr(), tl.data_ptr(), ml.data_ptr(), sigma_e, offset,
+                                            e.data_ptr(), _p(lde), B, T1, T2, _stream()), "efts_aligned_positions")
+
+
+def reconst_alpha(e, tl, ml, sigma, alpha_out, plane: Optional[Plane], B, T1, T2, T2p) -> None:
+    L.check(L.load().efts_reconst_alpha(e.data_ptr(), _p(tl), _p(ml), sigma, _p(alpha_out),
+                                        None if plane is None else plane.ptr, 0 if plane is None else plane.ld,
+                                        B, T1, T2, T2p, _stream()), "efts_reconst_alpha")
+
+
+def pack_vt(v: F32Rows, plane: Plane, B, T1, T1p, c) -> None:
+    L.check(L.load().efts_pack_vt(v.ptr, v.c, plane.ptr, plane.ld, B, T1, T1p, c, _stream()), "efts_pack_vt")
+
+
+def cumsum_rows(x, y, B, T) -> None:
+    L.check(L.load().efts_cumsum_rows(x.data_ptr(), y.data_ptr(), B, T, _stream()), "efts_cumsum_rows")
+
+
+def layernorm_rows(x_ptr, gamma, beta, eps, rowmask_ptr, out_f32_ptr, plane: Optional[Plane], rows, c) -> None:
+    L.check(L.load().efts_layernorm_rows(x_ptr, gamma.data_ptr(), beta.data_ptr(), eps, rowmask_ptr, out_f32_ptr,
+                                         None if plane is None else plane.ptr, 0 if plane is None else plane.ld,
+                                         rows, c, 1 if plane is None else plane.split, _stream()), "efts_layernorm_rows")
+
+
+def layernorm_dot(x_ptr, gamma, beta, eps, w, b, rowmask_ptr, mode, offset, out, rows, c) -> None:
+    L.check(L.load().efts_layernorm_dot(x_ptr, gamma.data_ptr(), beta.data_ptr(), eps, w.data_ptr(), b.data_ptr(),
+                                        rowmask_ptr, mode, offset, out.data_ptr(), rows, c, _stream()),
+            "efts_layernorm_dot")
+
+
+def losses_workspace(device) -> torch.Tensor:
+    return torch.zeros(L.load().efts_losses_workspace_bytes() // 4, dtype=torch.float32, device=device)
+
+
+def masked_losses(mel_pred_ptr, ldm, speech, ml, dur_pred, lde, tl, out3, ws, B, T1, T1p, T2, T2p, odim) -> None:
+    L.check(L.load().efts_masked_losses(mel_pred_ptr, ldm, speech.data_ptr(), ml.data_ptr(), dur_pred.data_ptr(),
+                                        lde.data_ptr(), tl.data_ptr(), out3.data_ptr(), ws.data_ptr(),
+                                        B, T1, T1p, T2, T2p, odim, _stream()), "efts_masked_losses")
+
+
+INV_SQRT = lambda d: 1.0 / math.sqrt(float(d))  # noqa: E731

@@ -1,0 +1,196 @@
+/*
+ * efts_abi.h -- C ABI of libefts_hip.so: the MI355X (gfx950) implementation of the
+ * EFTS-CNN acoustic-model hot path.
+ *
+ * The reference (liusongxiang/efficient_tts) is pure Python/PyTorch and has NO FFI or
+ * plugin interface; its boundary for this path is the Python class
+ * nntts.models.EfficientTTSCNN (nntts/models/efficient_tts.py:23) resolved by name at
+ * nntts/bin/train.py:173-185.  This header therefore defines the C entry points a
+ * maintainer would bind (ctypes) to replace the stock torch ops that class calls; each
+ * entry cites the reference op(s) it replaces.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers + explicit sizes; no torch types, no hidden allocation,
+ *     no retained pointers.  The caller owns every buffer.
+ *   - every launch goes to the hipStream_t passed as `void* stream`; no device sync.
+ *   - return 0 on success, negative EFTS_E* on error; efts_last_error() gives the text
+ *     (thread-local).  Nothing throws across the ABI.
+ *
+ * Row space.  Activations of B items x T steps live in a padded, item-major row space:
+ *   row(b, t) = b * Tp + t,  Tp = T + EFTS_GAP, rows t >= T of every item are zero ("gap").
+ * With a gap of (k-1)/2 = 2 zero rows between items a 1-D convolution over the whole
+ * row space equals B independent zero-padded convolutions, so tiles may straddle items.
+ * Buffers carry EFTS_GUARD_LO zero rows before row 0 and EFTS_GUARD_HI rows after the
+ * last 128-row tile; pointers passed in point at row 0.
+ *
+ * MFMA operand planes.  Matrices consumed by the MFMA GEMM are bf16, row-major, K in
+ * 128-byte chunks:
+ *   split 1 ("bf16")   : row = [Kp] bf16,            Kp = roundup(K, 64); chunk = 64 k's
+ *   split 2 ("bf16x3") : row = [Kp/32][hi32 | lo32], Kp = roundup(K, 32); chunk = 32 k's,
+ *                        x = hi + lo (two bf16), product = hi*hi + hi*lo + lo*hi in fp32.
+ */
+#ifndef EFTS_ABI_H
+#define EFTS_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EFTS_GAP 2
+#define EFTS_GUARD_LO 8
+#define EFTS_GUARD_HI 144
+#define EFTS_TILE_M 128
+
+#define EFTS_OK 0
+#define EFTS_EINVAL (-1)
+#define EFTS_ESHAPE (-2)
+#define EFTS_EALIGN (-3)
+#define EFTS_ELAUNCH (-4)
+#define EFTS_EDEVICE (-5)
+
+#define EFTS_ACT_NONE 0
+#define EFTS_ACT_LEAKY 1 /* LeakyReLU, slope in args */
+#define EFTS_ACT_RELU 2
+
+int efts_version(void);
+const char* efts_last_error(void);
+/* 0 when the current HIP device is gfx950. */
+int efts_device_check(void);
+
+/* ------------------------------------------------------------------------------------
+ * The MFMA contraction: out = epilogue( alpha * sum_tap A[row + tap - pad, :] . Bw[tap][col, :] )
+ * Replaces torch Conv1d (nntts/layers/efts_modules.py:32-35,48-51; duration_predictor.py:57),
+ * Linear (efficient_tts.py:149-153,161,198) and bmm (efficient_tts.py:190,390).
+ * epilogue: + bias[col]; activation; + resid[row, col]; * rowmask[row]; store fp32 and/or
+ * bf16 operand plane(s) for the next contraction.
+ * ---------------------------------------------------------------------------------- */
+typedef struct efts_gemm_args {
+    /* A operand plane (activations): row 0 pointer, row stride in bytes */
+    const void* a;
+    int64_t lda;
+    int64_t a_batch_stride; /* bytes between batch items (batched mode), else 0 */
+    /* B operand plane ("weights"): [taps][N rows][K], row stride / tap stride in bytes */
+    const void* b;
+    int64_t ldb;
+    int64_t b_tap_stride;
+    int64_t b_batch_stride;
+    int32_t split;  /* 1 = bf16, 2 = bf16x3 (hi/lo interleaved) */
+    int32_t taps;   /* 1, 3 or 5 */
+    int32_t m;      /* rows per batch item */
+    int32_t n;      /* output columns */
+    int32_t nchunk; /* 128-byte K chunks per row */
+    int32_t batch;  /* >= 1 */
+    float alpha;
+    int32_t act;
+    float slope;
+    const float* bias;    /* [n] or NULL */
+    const float* resid;   /* fp32 [m, ldr] or NULL */
+    int64_t ldr;          /* elements */
+    int64_t resid_batch_stride;
+    const float* rowmask; /* fp32 [m] (per batch item: + z*m_mask_stride) or NULL */
+    int64_t rowmask_batch_stride;
+    float* out_f32; /* or NULL */
+    int64_t ldo;    /* elements */
+    int64_t out_batch_stride;
+    void* out_bf16;    /* operand plane for the next contraction, or NULL */
+    int64_t ldob;      /* bytes */
+    int64_t outb_batch_stride;
+    int32_t out_split; /* 1 or 2: format of out_bf16 */
+    int32_t reserved;
+} efts_gemm_args;
+
+int efts_gemm(const efts_gemm_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Parameter preparation.
+ * efts_pack_weight: w[cout][cin][taps] fp32 (torch Conv1d / Linear layout) -> B operand plane
+ * [taps][cout][Kp].  With g != NULL the weight-norm fold w = g * v / ||v|| (norm over cin*taps)
+ * is applied first (torch.nn.utils.weight_norm, nntts/layers/efts_modules.py:92-99;
+ * remove_weight_norm efficient_tts.py:400-409); w_f32_out (optional) receives the folded fp32
+ * weight in the input layout.  plane row stride = ldb bytes, tap stride = cout*ldb.
+ * ---------------------------------------------------------------------------------- */
+int efts_pack_weight(const float* w, const float* g, float* w_f32_out, void* plane, int64_t ldb,
+                     int32_t cout, int32_t cin, int32_t taps, int32_t split, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Row-space producers.  `rows` = B*Tp.  f32_out (optional) is [rows][c] fp32, plane (optional)
+ * an A operand plane with row stride ld_plane bytes.  Gap rows are written as zero.
+ * efts_row_masks : gapmask[row] = t < T ; lenmask[row] = t < len[b]
+ *                  (make_non_pad_mask, nntts/utils/nets_utils.py:170-254, built on device).
+ * efts_embed     : text_embedding_table(text) (efficient_tts.py:144); ids int64 [B,T].
+ * efts_pack_rows : x fp32 [B,T,c] contiguous (e.g. speech [B,T2,80], efficient_tts.py:161 input).
+ * ---------------------------------------------------------------------------------- */
+int efts_row_masks(const int32_t* lengths, float* gapmask, float* lenmask, int32_t B, int32_t T,
+                   int32_t Tp, void* stream);
+int efts_embed(const int64_t* ids, const float* table, float* f32_out, void* plane, int64_t ld_plane,
+               int32_t B, int32_t T, int32_t Tp, int32_t c, int32_t num_symbols, int32_t split,
+               void* stream);
+int efts_pack_rows(const float* x, float* f32_out, void* plane, int64_t ld_plane, int32_t B, int32_t T,
+                   int32_t Tp, int32_t c, int32_t kp, int32_t split, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Alignment block (fp32 VALU, HBM-bound).
+ * efts_attn_soft_index: scores[B][T2][ld] (= q.k/sqrt(D), from efts_gemm) -> softmax over the
+ *   text_len[b] valid keys and soft_idx[b][j] = sum_i alpha_ij * i, 0 for j >= mel_len[b]
+ *   (scaled_dot_product_attention :377-398 + mask :168 + the bmm of imv_generator :312).
+ *   alpha_out (optional) [B][T1][T2] fp32 receives alpha itself.
+ * efts_imv_scan: d_j = relu(s_j - s_{j-1}), d_0 = 0; pi = cumsum(d) * melmask;
+ *   pi = pi / max(max_j pi, 1e-8) * (text_len - 1)            (imv_generator :314-323).
+ * efts_aligned_positions: e[b][i] = sum_j softmax_j(-sigma_e (pi_j - p_i)^2) * q_j, masked
+ *   (get_aligned_positions :326-345), and the duration target log(e_i - e_{i-1} + offset),
+ *   0 at padded text (efficient_tts.py:203-216, delta_e_method_1).
+ * efts_reconst_alpha: alpha'[b][i][j] = softmax_i(-sigma (q_j - e_i)^2), zero outside the
+ *   text x mel mask (reconstruct_align_from_aligned_position :347-375 + :186).  Lengths NULL
+ *   = inference (no masks, :270-274).  Writes the fp32 API tensor [B][T1][T2] (optional) and
+ *   the split-2 A operand plane of alpha'^T: row (b*T2p + j), K = i  (for the expand bmm :190).
+ * efts_pack_vt: V fp32 [B*T1p][c] -> per-item split-2 B operand plane V^T [B][c][K = i].
+ * efts_cumsum_rows: e = cumsum(delta) over T1 (inference :260); x [B][T] contiguous.
+ * ---------------------------------------------------------------------------------- */
+int efts_attn_soft_index(const float* scores, int64_t ld, const int32_t* text_len, const int32_t* mel_len,
+                         float* soft_idx, float* alpha_out, int32_t B, int32_t T1, int32_t T2, void* stream);
+int efts_imv_scan(const float* soft_idx, const int32_t* text_len, const int32_t* mel_len, float* imv,
+                  int32_t B, int32_t T2, void* stream);
+int efts_aligned_positions(const float* imv, const int32_t* text_len, const int32_t* mel_len, float sigma_e,
+                           float offset, float* e, float* log_delta_e, int32_t B, int32_t T1, int32_t T2,
+                           void* stream);
+int efts_reconst_alpha(const float* e, const int32_t* text_len, const int32_t* mel_len, float sigma,
+                       float* alpha_out, void* plane, int64_t ld_plane, int32_t B, int32_t T1, int32_t T2,
+                       int32_t T2p, void* stream);
+int efts_pack_vt(const float* v, int64_t ldv, void* plane, int64_t ld_plane, int32_t B, int32_t T1,
+                 int32_t T1p, int32_t c, void* stream);
+int efts_cumsum_rows(const float* x, float* y, int32_t B, int32_t T, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Duration predictor tail (nntts/layers/duration_predictor.py:57-88, layer_norm.py:6-30).
+ * efts_layernorm_rows: y = LN_c(x) * gamma + beta (biased variance, eps), times rowmask[row];
+ *   writes fp32 (optional) and/or an A operand plane.
+ * efts_layernorm_dot: out[row] = dot(LN_c(x[row]), w) + b  (LayerNorm + Linear(c,1) + squeeze);
+ *   mode 0: log domain, * rowmask (masked_fill(x_masks, 0), :85-86)
+ *   mode 1: inference, max(exp(.) - offset, 0)  (:78-83, to_round=False), * rowmask if given.
+ * ---------------------------------------------------------------------------------- */
+int efts_layernorm_rows(const float* x, const float* gamma, const float* beta, float eps,
+                        const float* rowmask, float* f32_out, void* plane, int64_t ld_plane,
+                        int32_t rows, int32_t c, int32_t split, void* stream);
+int efts_layernorm_dot(const float* x, const float* gamma, const float* beta, float eps, const float* w,
+                       const float* b, const float* rowmask, int32_t mode, float offset, float* out,
+                       int32_t rows, int32_t c, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * FastSpeechLoss with use_masking=True (nntts/losses/fastspeech_loss.py:54-67):
+ * out[0] = loss, out[1] = mel MSE over valid frames, out[2] = duration L1 over valid tokens.
+ * mel_pred: row space [B*T2p][ldm]; speech [B][T2][odim]; dur_pred/log_delta_e row space /
+ * [B][T1] resp.  workspace: >= efts_losses_workspace_bytes() bytes.
+ * ---------------------------------------------------------------------------------- */
+size_t efts_losses_workspace_bytes(void);
+int efts_masked_losses(const float* mel_pred, int64_t ldm, const float* speech, const int32_t* mel_len,
+                       const float* dur_pred, const float* log_delta_e, const int32_t* text_len,
+                       float* out3, void* workspace, int32_t B, int32_t T1, int32_t T1p, int32_t T2,
+                       int32_t T2p, int32_t odim, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EFTS_ABI_H */

@@ -1,0 +1,74 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol of include/efts_abi.h.
+No compute is launched (there is no GPU in the build container)."""
+import os
+import re
+
+import pytest
+
+from efficient_tts_amd import build as B
+from efficient_tts_amd import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    B.build(verbose=False)
+    return L.load()
+
+
+def test_header_symbols_are_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "efts_abi.h")).read()
+    declared = set(re.findall(r"\b(efts_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in efts_abi.h but not exported by libefts_hip.so"
+    assert declared == set(L.exported_symbols()), (declared ^ set(L.exported_symbols()))
+
+
+def test_version_and_argument_errors(lib):
+    assert lib.efts_version() >= 100
+    g = L.GemmArgs()
+    g.split, g.taps = 7, 5
+    assert lib.efts_gemm(g, None) == -1            # EFTS_EINVAL before any launch
+    assert b"split" in lib.efts_last_error()
+    with pytest.raises(ValueError):
+        L.check(lib.efts_gemm(g, None), "efts_gemm")
+
+
+def test_gemm_args_layout_matches_header():
+    """sizeof(struct efts_gemm_args) as compiled by gcc == the ctypes mirror."""
+    import subprocess, tempfile, ctypes
+    src = '#include <stdio.h>\n#include "efts_abi.h"\nint main(){printf("%zu",sizeof(efts_gemm_args));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        size = int(subprocess.check_output([os.path.join(d, "s")]))
+    assert size == ctypes.sizeof(L.GemmArgs)
+
+
+def test_model_state_dict_keys_match_reference_layout():
+    """state_dict names/shapes are the drop-in contract; checked against the oracle's table."""
+    import torch
+    from efficient_tts_amd import EfficientTTSCNN
+    from oracle import efts_oracle as O
+    m = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, use_weighted_masking=False, sigma=0.01)
+    sd = m.state_dict()
+    shapes = O.param_shapes()
+    assert list(sd.keys()) == list(shapes.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == shapes[k], k
+    m.load_state_dict(O.fill_params())
+    m.remove_weight_norm()
+    assert "decoder.layers.0.conv.0.weight" in m.state_dict()
+    assert sum(p.numel() for p in EfficientTTSCNN(76, use_masking=True).parameters()) == 20587601
+
+
+def test_model_fails_loudly_without_gpu():
+    import torch
+    from efficient_tts_amd import EfficientTTSCNN
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = EfficientTTSCNN(num_symbols=76, use_masking=True)
+    with pytest.raises(Exception):
+        m.inference(torch.zeros(1, 8, dtype=torch.long))

@@ -1,0 +1,181 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C ABI, against the oracle and the
+reference-generated golden fixtures.  Tolerances: north_star states mel max-abs <= 1e-3."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import efts_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MEL_TOL = 1e-3          # north_star: "Output mels match the reference within 1e-3 max-abs"
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def model():
+    from efficient_tts_amd import EfficientTTSCNN
+    from efficient_tts_amd import lib as L
+    L.load()
+    L.require_device()
+    m = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, use_weighted_masking=False,
+                        sigma=0.01, precision="bf16x3")
+    m.load_state_dict(O.fill_params())
+    return m.to(_dev()).eval()
+
+
+def _golden(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+# ------------------------------------------------------------------ the MFMA contraction alone
+@pytest.mark.parametrize("split", [2, 1])
+@pytest.mark.parametrize("taps,cin,cout,B,T", [(5, 512, 512, 3, 70), (3, 512, 512, 2, 131), (1, 80, 512, 2, 50),
+                                              (1, 512, 80, 1, 300), (5, 512, 512, 1, 1)])
+def test_gemm_conv_vs_fp64(split, taps, cin, cout, B, T):
+    from efficient_tts_amd import lib as L, ops as P
+    dev = _dev()
+    g = torch.Generator().manual_seed(taps * 1000 + cin + T)
+    x = torch.randn(B, T, cin, generator=g)
+    w = torch.randn(cout, cin, taps, generator=g) * 0.05
+    bias = torch.randn(cout, generator=g)
+    res = torch.randn(B, T, cout, generator=g)
+    rs = P.Rows(B, T)
+    a = P.Plane.for_rows(rs, cin, split, dev)
+    P.pack_rows(x.to(dev), None, a, rs)
+    pw = P.PackedWeight(cout, cin, taps, split, dev)
+    pw.pack(w.to(dev).contiguous())
+    resid = P.F32Rows(rs, cout, dev)
+    resid.view().copy_(res.to(dev))
+    gap = torch.zeros(rs.rows, device=dev)
+    P.row_masks(torch.full((B,), T, dtype=torch.int32, device=dev), rs, gap, None)
+    out = P.F32Rows(rs, cout, dev)
+    outp = P.Plane.for_rows(rs, cout, 2, dev)
+    P.gemm(a=a, b_ptr=pw.ptr, ldb=pw.ld, b_tap_stride=pw.tap_stride, taps=taps, m=rs.rows, n=cout, act=L.ACT_LEAKY,
+           slope=0.1, bias=bias.to(dev), resid_ptr=resid.ptr, ldr=cout, rowmask_ptr=gap.data_ptr(),
+           out_f32_ptr=out.ptr, ldo=cout, out_plane=outp)
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.conv1d(x.double().transpose(1, 2), w.double(), bias.double(), padding=(taps - 1) // 2)
+    ref = (res.double() + torch.nn.functional.leaky_relu(ref, 0.1).transpose(1, 2)).float()
+    got = out.view().cpu()
+    scale = float(ref.abs().max())
+    tol = (2e-5 if split == 2 else 2e-2) * scale
+    assert float((got - ref).abs().max()) <= tol
+    # gap rows and guard rows stay exactly zero
+    full = out.buf.cpu()
+    assert float(full[:L.GUARD_LO].abs().max()) == 0.0
+    gaprows = full[L.GUARD_LO:L.GUARD_LO + rs.rows].view(B, rs.Tp, cout)[:, T:]
+    assert float(gaprows.abs().max()) == 0.0
+    # the hi/lo operand plane written by the epilogue reconstructs the fp32 output to 2^-16
+    pl = outp.buf[L.GUARD_LO:L.GUARD_LO + rs.rows].view(torch.bfloat16).view(rs.rows, outp.nchunk, 2, 32).float().cpu()
+    recon = (pl[:, :, 0] + pl[:, :, 1]).reshape(B, rs.Tp, outp.nchunk * 32)[:, :T, :cout]
+    assert float((recon - got).abs().max()) <= 2e-5 * scale
+
+
+# ------------------------------------------------------------------ whole forward vs golden + oracle
+@pytest.mark.parametrize("case", ["fwd_tiny", "fwd_small", "fwd_full", "fwd_long"])
+def test_forward_matches_reference_golden(golden_dir, model, case):
+    g = _golden(golden_dir, case)
+    dev = _dev()
+    args = [torch.from_numpy(g[k]) for k in ("text", "text_lengths", "speech", "speech_lengths")]
+    with torch.no_grad():
+        (loss, stats, imv, ralpha, mel_pred, _), extra = model._forward_impl(*[a.to(dev) for a in args], keep=True)
+    torch.cuda.synchronize()
+    st, sa = int(g["mel_pred_stride"]), int(g["alpha_stride"])
+    T1 = args[0].shape[1]
+    err = {
+        "mel_pred": float((mel_pred.cpu()[:, ::st] - torch.from_numpy(g["mel_pred"])).abs().max()),
+        "reconst_alpha": float((ralpha.cpu()[:, ::sa, ::sa] - torch.from_numpy(g["reconst_alpha"])).abs().max()),
+        "imv": float((imv.cpu() - torch.from_numpy(g["imv"])).abs().max()),
+        "e": float((extra["e"].cpu() - torch.from_numpy(g["e"])).abs().max()),
+        "dur_pred": float((extra["dur_pred"].cpu() - torch.from_numpy(g["dur_pred"])).abs().max()),
+        "log_delta_e": float((extra["log_delta_e"].cpu() - torch.from_numpy(g["log_delta_e"])).abs().max()),
+        "loss": abs(float(loss) - float(g["loss"])),
+    }
+    print(case, err)
+    assert err["mel_pred"] <= MEL_TOL, err
+    assert err["reconst_alpha"] <= 1e-3, err
+    assert err["imv"] <= 2e-3 and err["e"] <= 1e-2, err          # index units (0..T1 / 0..T2)
+    assert err["dur_pred"] <= 1e-3 and err["log_delta_e"] <= 1e-3, err
+    assert err["loss"] <= 1e-4 * float(g["loss"]), err
+    assert abs(stats["mel_loss"] - float(g["mel_loss"])) <= 1e-4 * float(g["mel_loss"])
+    assert abs(stats["duration_loss"] - float(g["dur_loss"])) <= 2e-4 * max(1.0, float(g["dur_loss"]))
+    # and against the oracle on the same inputs (full tensors, not strided samples)
+    o = O.forward(O.fill_params(), *args)
+    assert float((mel_pred.cpu() - o["mel_pred"]).abs().max()) <= MEL_TOL
+    assert float((ralpha.cpu() - o["reconst_alpha"]).abs().max()) <= 1e-3
+
+
+def test_inference_matches_reference_golden(golden_dir, model):
+    g = _golden(golden_dir, "inference_lj")
+    dev = _dev()
+    for n in range(4):
+        ids = torch.from_numpy(g[f"text{n}"]).to(dev)
+        mel, ralpha = model.inference(ids)
+        assert mel.shape[1] == int(g[f"t2_{n}"]) and ralpha.shape == (1, ids.shape[1], mel.shape[1])
+        assert float((mel.cpu()[:, ::2] - torch.from_numpy(g[f"mel_pred{n}"])).abs().max()) <= MEL_TOL
+        assert float((ralpha.cpu()[:, ::4, ::4] - torch.from_numpy(g[f"reconst_alpha{n}"])).abs().max()) <= 1e-4
+
+
+def test_remove_weight_norm_keeps_outputs(model, golden_dir):
+    from efficient_tts_amd import EfficientTTSCNN
+    g = _golden(golden_dir, "inference_lj")
+    ids = torch.from_numpy(g["text0"]).to(_dev())
+    a, _ = model.inference(ids)
+    m2 = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, sigma=0.01)
+    m2.load_state_dict(O.fill_params())
+    m2 = m2.to(_dev()).eval()
+    m2.remove_weight_norm()
+    assert "decoder.layers.0.conv.0.weight" in m2.state_dict()
+    b, _ = m2.inference(ids)
+    # torch's fold (remove_weight_norm) and the fused fold kernel round g*v/||v|| differently by 1 ulp
+    assert float((a - b).abs().max()) <= 2e-4
+
+
+def test_bf16_mode_reports_its_own_error(golden_dir):
+    """precision="bf16" (single bf16 MFMA per product) is the fast mode; it cannot meet 1e-3
+    (the reference itself moves by 0.49 under bf16 autocast) -- bound its error."""
+    from efficient_tts_amd import EfficientTTSCNN
+    g = _golden(golden_dir, "fwd_full")
+    dev = _dev()
+    m = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, sigma=0.01, precision="bf16")
+    m.load_state_dict(O.fill_params())
+    m = m.to(dev).eval()
+    args = [torch.from_numpy(g[k]).to(dev) for k in ("text", "text_lengths", "speech", "speech_lengths")]
+    with torch.no_grad():
+        loss, stats, imv, ralpha, mel_pred, _ = m(*args)
+    err = float((mel_pred.cpu()[:, ::int(g["mel_pred_stride"])] - torch.from_numpy(g["mel_pred"])).abs().max())
+    print("bf16 mel max-abs", err)
+    assert err <= 0.5 and abs(float(loss) - float(g["loss"])) <= 2e-2 * float(g["loss"])
+
+
+def test_full_size_properties(model):
+    """BASELINE config 2 shape (B=64, 128, 800): size-independent properties --
+    batch-permutation equivariance, item independence, alpha' columns sum to 1, imv monotone."""
+    dev = _dev()
+    gen = torch.Generator().manual_seed(1234)
+    B, T1, T2 = 64, 128, 800
+    text = torch.randint(0, 76, (B, T1), generator=gen).to(dev)
+    mel = torch.randn(B, T2, 80, generator=gen).to(dev)
+    tl = torch.full((B,), T1, dtype=torch.int64, device=dev)
+    sl = torch.full((B,), T2, dtype=torch.int64, device=dev)
+    with torch.no_grad():
+        loss, stats, imv, ralpha, mel_pred, _ = model(text, tl, mel, sl)
+        perm = torch.randperm(B, generator=gen).to(dev)
+        loss2, _, imv2, ralpha2, mel2, _ = model(text[perm], tl, mel[perm], sl)
+        sub = slice(5, 9)
+        _, _, imv3, _, mel3, _ = model(text[sub], tl[sub], mel[sub], sl[sub])
+    assert torch.isfinite(mel_pred).all()
+    assert float((mel_pred[perm] - mel2).abs().max()) == 0.0            # bitwise: tiles never mix items
+    assert float((imv[perm] - imv2).abs().max()) == 0.0
+    assert abs(float(loss) - float(loss2)) <= 1e-5 * float(loss)
+    assert float((mel_pred[sub] - mel3).abs().max()) <= 1e-4             # item independence (tile phase differs)
+    assert float((ralpha.sum(1) - 1).abs().max()) <= 1e-4
+    assert float((imv[:, 1:] - imv[:, :-1]).min()) >= 0.0
+    assert float((imv[:, -1] - (T1 - 1)).abs().max()) <= 1e-3

@@ -1,0 +1,28 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from efficient_tts_amd import lib as L, ops as P
+dev = torch.device("cuda:0"); L.load(); L.require_device()
+def time_layer(split, B=64, T=800, C=512, iters=20):
+    rs = P.Rows(B, T)
+    a = P.Plane.for_rows(rs, C, split, dev)
+    x = torch.randn(B, T, C, device=dev)
+    xf = P.F32Rows(rs, C, dev); xf.view().copy_(x)
+    P.pack_rows(x, None, a, rs)
+    pw = P.PackedWeight(C, C, 5, split, dev); pw.pack((torch.randn(C, C, 5, device=dev) * 0.02).contiguous())
+    bias = torch.randn(C, device=dev)
+    gap = torch.zeros(rs.rows, device=dev); P.row_masks(torch.full((B,), T, dtype=torch.int32, device=dev), rs, gap, None)
+    out = P.F32Rows(rs, C, dev); outp = P.Plane.for_rows(rs, C, split, dev)
+    def run():
+        P.gemm(a=a, b_ptr=pw.ptr, ldb=pw.ld, b_tap_stride=pw.tap_stride, taps=5, m=rs.rows, n=C, act=L.ACT_LEAKY, slope=0.1,
+               bias=bias, resid_ptr=xf.ptr, ldr=C, rowmask_ptr=gap.data_ptr(), out_f32_ptr=out.ptr, ldo=C, out_plane=outp)
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): run()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    fl = 2.0 * B * T * C * C * 5
+    print(f"dbg={os.environ.get('EFTS_GEMM_DBG','0')} split={split}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TF", flush=True)
+for s in (1, 2): time_layer(s)
