@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- the driver's measurement contract for the EFTS-CNN hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one synthetic batch.  Default workload =
+BASELINE.json configs[1]: EFTS-CNN teacher-forced forward (the reference's
+EfficientTTSCNN.forward under no_grad, nntts/models/efficient_tts.py:120-228) at
+batch 64 / phoneme-len 128 / mel-len 800 / 80 bins on ONE MI355X, bf16 MFMA operands with
+fp32 accumulate and an fp32 residual stream.  Inputs are resident in HBM before the timed
+region.  N > 1 runs one replica per GPU (the inference path has no exchange step): weak
+scaling, value = frames of all ranks / max-over-ranks time.  `--workload train` times the
+data-parallel training step (config 3/4) once the backward path is built.
+
+Prints ONE JSON line on rank 0 (see README of the task for the field contract), with
+`roofline` for the dominant kernel (the k=5 Conv1d contraction at mel length, measured with
+HIP events on the launch stream inside the timed region) and `cpu_baseline` (the oracle's CPU
+restatement timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_MFMA_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0
+FWD_FLOP_PER_ITEM = 21.43e9           # SURVEY.md 8d, (T1, T2) = (128, 800)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
+    ap.add_argument("--workload", default="fwd64", choices=["fwd64", "fwd16_long", "train32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay the step from a captured hipGraph (roofline events then come from extra eager steps)")
+    return ap.parse_args()
+
+
+WORKLOADS = {
+    "fwd64": dict(B=64, T1=128, T2=800, desc="EFTS-CNN forward (teacher-forced, no_grad) B=64 phon=128 mel=800 80-bin"),
+    "fwd16_long": dict(B=16, T1=128, T2=1200, desc="EFTS-CNN forward B=16 phon=128 mel=1200 (long-sequence stress)"),
+    "train32": dict(B=32, T1=128, T2=800, desc="EFTS-CNN training step fwd+bwd+clip+Adam B=32/GPU"),
+}
+
+
+def synth(B, T1, T2, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    text = torch.randint(0, 76, (B, T1), generator=g).to(dev)
+    mel = torch.randn(B, T2, 80, generator=g).to(dev)
+    tl = torch.full((B,), T1, dtype=torch.int64, device=dev)
+    sl = torch.full((B,), T2, dtype=torch.int64, device=dev)
+    return text, tl, mel, sl
+
+
+def cpu_baseline(T1, T2):
+    """The oracle (CPU port of the reference path) timed on this box's host cores: forward at
+    B=16 (bounded sample of the same workload), fp32, all cores."""
+    from oracle import efts_oracle as O          # the cpu_baseline leg: oracle as the thing timed
+    cores = os.cpu_count() or 1
+    P = O.fill_params()
+    Bc = 16
+    g = torch.Generator().manual_seed(1234)
+    text = torch.randint(0, 76, (Bc, T1), generator=g)
+    mel = torch.randn(Bc, T2, 80, generator=g)
+    tl = torch.full((Bc,), T1, dtype=torch.int64)
+    sl = torch.full((Bc,), T2, dtype=torch.int64)
+    best = None
+    # torch's CPU conv (oneDNN) does not scale to every hardware thread of a 2-socket host:
+    # sweep a few thread counts and report the fastest (cores = threads actually used).
+    for nt in sorted({min(cores, n) for n in (8, 16, 32, 64)}):
+        torch.set_num_threads(nt)
+        times = []
+        with torch.no_grad():
+            O.forward(P, text, tl, mel, sl)
+            for _ in range(3):
+                t0 = time.perf_counter()
+                O.forward(P, text, tl, mel, sl)
+                times.append(time.perf_counter() - t0)
+        med = sorted(times)[1]
+        if best is None or med < best[0]:
+            best = (med, nt)
+        if med > 4 * best[0]:
+            break
+    med, nt = best
+    return dict(value=Bc * T2 / med, unit="mel-frames/s", cores=nt, host_cpus=cores, kind="port",
+                sample=f"oracle forward fp32, B={Bc} x (T1={T1}, T2={T2}), median of 3 after 1 warm-up, "
+                       f"best of 8/16/32/64 threads ({med:.3f} s/iter at {nt} threads)")
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from efficient_tts_amd import EfficientTTSCNN, ops as P
+    wl = WORKLOADS[a.workload]
+    B, T1, T2 = wl["B"], wl["T1"], wl["T2"]
+    if a.workload == "train32":
+        from efficient_tts_amd.bench_train import run_train      # DP training step (config 3/4)
+        return run_train(a, world, rank, dev, wl)
+
+    torch.manual_seed(0)
+    model = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, use_weighted_masking=False,
+                            sigma=0.01, precision=a.precision).to(dev).eval()
+    text, tl, mel, sl = synth(B, T1, T2, 1234 + rank, dev)
+
+    def step():
+        with torch.no_grad():
+            return model(text, tl, mel, sl)
+
+    graph = None
+    for _ in range(max(a.warmup, 2) if a.graph else a.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if a.graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = step()
+        graph.replay()
+        torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides.  In eager mode every
+    # efts_gemm launch of the timed steps is bracketed by HIP events on its stream (roofline below).
+    if graph is None:
+        P.PROFILE = []
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        if graph is not None:
+            graph.replay()
+        else:
+            step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(out[0])
+    assert loss == loss, "NaN loss"
+
+    # ---- dominant kernel: per-launch duration from the HIP events of the timed region (eager), or
+    # from 3 extra eager steps right after it when the timed region replayed a hipGraph.
+    rows_conv = P.Rows(B, T2).rows
+    if graph is not None:
+        P.PROFILE = []
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+    durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in P.PROFILE if tag == (5, rows_conv, 512)]
+    P.PROFILE = None
+    n_launch = len(durs)
+    avg = sum(durs) / max(n_launch, 1)
+    conv_flop = 2.0 * B * T2 * 512 * 512 * 5
+    conv_bytes_alg = B * T2 * 512 * (2 + 4 + 4 + 2) + 512 * 512 * 5 * 2      # A bf16 + resid + out f32 + out bf16 + W
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get(f"{a.precision}:{a.workload}")
+        except Exception:
+            traffic = None
+    roof = dict(bound="mfma", kernel=f"gemm_kernel<taps=5,split={model.split}> (k5 Conv1d 512->512, {B}x{T2} frames)",
+                achieved=conv_flop / avg / 1e12, peak=PEAK_MFMA_BF16_TFLOPS, unit="TFLOP/s",
+                frac=conv_flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS, traffic=traffic,
+                avg_launch_us=avg * 1e6, launches_measured=n_launch, algorithmic_flop_per_launch=conv_flop,
+                hbm_frac_algorithmic=conv_bytes_alg / avg / 1e9 / PEAK_HBM_GBS,
+                mfma_issue_frac=(3 if model.split == 2 else 1) * conv_flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS)
+
+    if rank == 0:
+        frames = world * B * T2 * a.steps
+        res = dict(metric="mel-frames/sec (EFTS-CNN forward, batch 64/GPU, 80-mel LJSpeech shape)", value=frames / dt,
+                   unit="mel-frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
+                   higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="bf16" if a.precision == "bf16" else "bf16x3 (split-bf16 MFMA, fp32-class)",
+                   data="synthetic", config=dict(workload=wl["desc"], batch_per_gpu=B, phoneme_len=T1, mel_len=T2,
+                                                 precision=a.precision, parallelism=f"replicas x{world}", hipgraph=bool(graph)),
+                   per_gpu=frames / dt / world, rtf=(dt / a.steps) / (B * T2 * 256 / 22050.0),
+                   tflops=FWD_FLOP_PER_ITEM * B * T2 / 800 * world * a.steps / dt / 1e12 if (T1, T2) == (128, 800) else None,
+                   loss=loss, roofline=roof)
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(T1, T2)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

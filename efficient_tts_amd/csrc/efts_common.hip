@@ -34,3 +34,14 @@ extern "C" int efts_device_check(void) {
     efts_gemm_init();
     return EFTS_OK;
 }
+
+int efts_num_cus(void) {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}

@@ -23,6 +23,7 @@
 //     positions), fp32 store and bf16 operand planes for the next contraction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "efts_internal.h"
@@ -32,12 +33,8 @@ namespace efts {
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int BM = 128;
 constexpr int BN = 128;
-constexpr int A_ROWS = 136;               // 128 + 4 halo rows, rounded up to 8 (one DMA piece = 8 rows)
-constexpr int A_BYTES = A_ROWS * 128;     // 17408
 constexpr int W_BYTES = BN * 128;         // 16384
-constexpr int LDS_BYTES = 2 * A_BYTES + 2 * W_BYTES;  // 67584
 
 // Swizzled LDS byte offset of (row, 16-byte slot) inside a [rows][128 B] tile.  A ds_read_b128
 // lane group holds 16 different rows at one logical slot; rows r and r+2 share banks, so the
@@ -56,11 +53,13 @@ struct GemmKernelArgs {
     char* out_bf16;
     long lda, ldb, b_tap_stride, ldr, ldo, ldob;
     long a_bs, b_bs, r_bs, m_bs, o_bs, ob_bs;
-    int m, n, nchunk, pad;
+    int m_base, m_end;   // this launch covers rows [m_base, m_end) (tail launches use a smaller tile)
+    int n, nchunk, pad;
     int mtiles, ntiles;
     float alpha, slope;
     int act, out_split;
     int vec_ok;   // all fp32 row strides / pointers allow float4 access
+    int stagger;  // persistent mode: cycles the second half of the grid idles before its first tile
     int dbg;   // ablation switches (EFTS_GEMM_DBG): 1 = skip epilogue stores, 2 = no DMA in loop, 4 = no MFMA
 };
 
@@ -79,30 +78,88 @@ __device__ __forceinline__ void dma_piece(const char* rowbase0, long ld, int fir
                                      16, 0, 0);
 }
 
-template <int TAPS, int SPLIT>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
+// Tile configuration.  WM = number of 64-row wave rows.
+//   WM = 2: 128x128 tile, 4 waves, 2-stage operand ring, 2 workgroups per CU (66 KiB LDS each)
+//   WM = 4: 256x128 tile, 8 waves, 3-stage weight ring with COUNTED vmcnt (LDS-DMA stays in flight
+//           across the step barrier), 1 workgroup per CU (114 KiB LDS): half the weight traffic per
+//           FLOP and two steps of latency budget per DMA.
+template <int TAPS, int WM>
+struct Cfg {
+    static constexpr int NW = WM * 2;
+    static constexpr int THREADS = NW * 64;
+    static constexpr int BM = WM * 64;
+    static constexpr int A_PIECES = BM / 8 + (TAPS == 1 ? 0 : 1);
+    static constexpr int A_BYTES = A_PIECES * 1024;
+    static constexpr int NST = (WM == 4) ? 3 : 2;
+    static constexpr int WPW = 16 / NW;                       // weight DMA pieces per wave per step
+    static constexpr int LDS = 2 * A_BYTES + NST * W_BYTES;
+};
+
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    }
+}
+
+template <int TAPS, int SPLIT, int WM>
+__global__ __launch_bounds__(WM * 128, (WM == 4) ? 2 : 2) void gemm_kernel(GemmKernelArgs p) {
+    using C = Cfg<TAPS, WM>;
+    constexpr int BM = C::BM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // all LDS in one array, buffers addressed arithmetically (no runtime-indexed pointer arrays)
-#define EFTS_ABUF(i) (smem + ((i) & 1) * A_BYTES)
-#define EFTS_WBUF(i) (smem + 2 * A_BYTES + ((i) & 1) * W_BYTES)
+#define EFTS_ABUF(i) (smem + ((i) & 1) * C::A_BYTES)
+#define EFTS_WBUF(i) (smem + 2 * C::A_BYTES + ((i) % C::NST) * W_BYTES)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
+    const int z = blockIdx.y;
+    const int lrow = lane & 31;
+    const int lhalf = lane >> 5;
+    const int nsteps = p.nchunk * TAPS;
+    const int nA = (C::A_PIECES - wave + C::NW - 1) / C::NW;     // A window pieces this wave issues
+    const int c4 = (tid & 31) << 2;
+    constexpr int RPP = C::THREADS / 32;                          // tile rows per epilogue sweep
+    constexpr int NPS = 128 / RPP;                                // sweeps per 128-row half
+    const float* resid = p.resid ? p.resid + (long)z * p.r_bs : nullptr;
+    const float* rowmask = p.rowmask ? p.rowmask + (long)z * p.m_bs : nullptr;
+    float* of = p.out_f32 ? p.out_f32 + (long)z * p.o_bs : nullptr;
+    char* ob = p.out_bf16 ? p.out_bf16 + (long)z * p.ob_bs : nullptr;
+
+    // Persistent workgroups: each walks the tile list with stride gridDim.x, so the epilogue's
+    // stores of tile t drain from the memory queues while tile t+1's main loop already runs, and
+    // the residual rows of a tile are prefetched under its last MFMA step.
     // XCD-aware tile order: block b runs on XCD b % 8; give each XCD a contiguous range of
     // tiles (n fastest) so the workgroups sharing an A window hit the same L2.
     const int ntot = p.mtiles * p.ntiles;
-    int bid = blockIdx.x;
+    if (p.stagger > 0 && blockIdx.x >= (gridDim.x >> 1) && gridDim.x < (unsigned)ntot) {
+        // de-phase the two workgroups that share a CU so one's HBM-bound epilogue overlaps the
+        // other's MFMA-bound main loop instead of all epilogues bursting together
+        const long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < p.stagger) __builtin_amdgcn_s_sleep(32);
+    }
+  for (int vt = blockIdx.x; vt < ntot; vt += gridDim.x) {
+    int bid = vt;
     {
         const int q = ntot >> 3, r = ntot & 7;
         const int xcd = bid & 7, loc = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
     const int mt = bid / p.ntiles, nt = bid - mt * p.ntiles;
-    const int z = blockIdx.y;
-    const int m0 = mt * BM, n0 = nt * BN;
+    const int m0 = p.m_base + mt * BM, n0 = nt * BN;
+    const int col = n0 + c4;
+    const bool vec = p.vec_ok && (col + 3 < p.n);
 
     const char* A = p.a + (long)z * p.a_bs;
     const char* Bw = p.b + (long)z * p.b_bs;
@@ -118,38 +175,38 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    constexpr int A_PIECES = (TAPS == 1) ? 16 : 17;
-
-    // prologue: chunk 0 window + tap-0 weights
-    for (int pc = wave; pc < A_PIECES; pc += 4) dma_piece(A, p.lda, a_first, a_max, pc, lane, EFTS_ABUF(0));
-    {
-        const char* wb = Bw + (long)n0 * p.ldb;
+    auto issue_w = [&](int sn) {     // weights of step sn -> ring slot sn % NST
+        const int cn = sn / TAPS, kn = sn - cn * TAPS;
+        const char* wb = Bw + (long)kn * p.b_tap_stride + (long)n0 * p.ldb + (long)cn * 128;
 #pragma unroll
-        for (int pc = 0; pc < 4; ++pc) dma_piece(wb, p.ldb, 0, b_max, wave * 4 + pc, lane, EFTS_WBUF(0));
-    }
-    __syncthreads();
+        for (int pc = 0; pc < C::WPW; ++pc) dma_piece(wb, p.ldb, 0, b_max, wave * C::WPW + pc, lane, EFTS_WBUF(sn));
+    };
+    auto issue_a = [&](int cn) {     // A window of chunk cn -> window buffer cn & 1
+        const char* ab = A + (long)cn * 128;
+        for (int pc = wave; pc < C::A_PIECES; pc += C::NW) dma_piece(ab, p.lda, a_first, a_max, pc, lane, EFTS_ABUF(cn));
+    };
 
-    const int lrow = lane & 31;
-    const int lhalf = lane >> 5;
-    const int nsteps = p.nchunk * TAPS;
+    // prologue: window 0 + the first NST-1 weight tiles
+    issue_a(0);
+    issue_w(0);
+    if constexpr (C::NST == 3) {
+        if (nsteps > 1) issue_w(1);
+        wait_vmcnt(nsteps > 1 ? C::WPW : 0);
+        __builtin_amdgcn_s_barrier();
+    } else {
+        __syncthreads();
+    }
+
     int s = 0;
     for (int c = 0; c < p.nchunk; ++c) {
 #pragma unroll
         for (int k = 0; k < TAPS; ++k, ++s) {
-            // ---- stage the next step's operands (lands while this step computes)
-            if (s + 1 < nsteps && !(p.dbg & 2)) {
-                const int kn = (k + 1 == TAPS) ? 0 : k + 1;
-                const int cn = (k + 1 == TAPS) ? c + 1 : c;
-                const char* wb = Bw + (long)kn * p.b_tap_stride + (long)n0 * p.ldb + (long)cn * 128;
-#pragma unroll
-                for (int pc = 0; pc < 4; ++pc)
-                    dma_piece(wb, p.ldb, 0, b_max, wave * 4 + pc, lane, EFTS_WBUF(s + 1));
-            }
-            if (k == 0 && c + 1 < p.nchunk && !(p.dbg & 2)) {
-                const char* ab = A + (long)(c + 1) * 128;
-                for (int pc = wave; pc < A_PIECES; pc += 4)
-                    dma_piece(ab, p.lda, a_first, a_max, pc, lane, EFTS_ABUF(c + 1));
-            }
+            // ---- stage operands NST-1 steps ahead (they land while this and the next step compute)
+            const bool do_w = (s + C::NST - 1 < nsteps) && !(p.dbg & 2);
+            const bool do_a = (k == 0) && (c + 1 < p.nchunk) && !(p.dbg & 2);
+            if (TAPS == 1 && do_a) issue_a(c + 1);          // taps 1: the window changes every step
+            if (do_w) issue_w(s + C::NST - 1);
+            if (TAPS != 1 && do_a) issue_a(c + 1);
             // ---- MFMAs of this (chunk, tap)
             const char* at = EFTS_ABUF(c);
             const char* wt = EFTS_WBUF(s);
@@ -196,84 +253,111 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
                         }
                 }
             }
-            __syncthreads();   // next operands landed (vmcnt(0)) and this step's reads are done
-        }
-    }
-
-    // ---- fused epilogue, staged through LDS so that every global access is a full-row vector.
-    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); each
-    // wave drops its 64x64 block (bias + activation applied) into a [128][128] fp32 LDS tile,
-    // then 32 consecutive threads sweep one 512-byte tile row: float4 residual load, float4
-    // store, and 8-byte bf16 (hi / lo) operand-plane stores.
-    float* cs = (float*)smem;   // 64 KiB; the main loop's last barrier has retired all LDS reads
-    {
-        const float* bias = p.bias;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int cl = wn * 64 + j * 32 + lrow;
-            const float bv = (bias && n0 + cl < p.n) ? bias[n0 + cl] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                    float v = acc[i][j][r] * p.alpha + bv;
-                    if (p.act == EFTS_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
-                    else if (p.act == EFTS_ACT_RELU) v = v > 0.f ? v : 0.f;
-                    cs[rl * 128 + cl] = v;
+            if constexpr (C::NST == 3) {
+                // Counted wait: everything this wave issued up to and including the weights of step
+                // s+1 must have landed; younger DMAs (weights of s+2, a window issued this or the
+                // previous step) stay in flight across the barrier.  taps 1: the window of the next
+                // step is older than the weights issued this step, so it is covered too.
+                int n = do_w ? C::WPW : 0;
+                if (TAPS != 1) {
+                    if (do_a) n += nA;
+                    if (k == 1 && c + 1 < p.nchunk && !(p.dbg & 2)) n += nA;   // window issued one step ago
                 }
+                wait_vmcnt(n);
+                __builtin_amdgcn_s_barrier();
+            } else {
+                __syncthreads();   // next operands landed (vmcnt(0)) and this step's reads are done
             }
         }
     }
-    __syncthreads();
-    if (p.dbg & 1) return;
-    const float* resid = p.resid ? p.resid + (long)z * p.r_bs : nullptr;
-    const float* rowmask = p.rowmask ? p.rowmask + (long)z * p.m_bs : nullptr;
-    float* of = p.out_f32 ? p.out_f32 + (long)z * p.o_bs : nullptr;
-    char* ob = p.out_bf16 ? p.out_bf16 + (long)z * p.ob_bs : nullptr;
-    const int c4 = (tid & 31) << 2;
-    const int col = n0 + c4;
-    const bool vec = p.vec_ok && (col + 3 < p.n);
-    if (col < p.n) {
-#pragma unroll 4
-        for (int ps = 0; ps < 16; ++ps) {
-            const int rl = ps * 8 + (tid >> 5);
-            const int row = m0 + rl;
-            if (row >= p.m) break;
-            float4 v = *(const float4*)(cs + rl * 128 + c4);
-            const float rm = rowmask ? rowmask[row] : 1.f;
-            if (vec) {
-                if (resid) {
-                    const float4 x = *(const float4*)(resid + (long)row * p.ldr + col);
-                    v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
-                }
-                v.x *= rm; v.y *= rm; v.z *= rm; v.w *= rm;
-                if (of) *(float4*)(of + (long)row * p.ldo + col) = v;
-                if (ob) plane_store4(ob + (long)row * p.ldob, col, v.x, v.y, v.z, v.w, p.out_split);
-            } else {
-                float vv[4] = {v.x, v.y, v.z, v.w};
+    if constexpr (C::NST == 3) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- fused epilogue, staged through LDS so that every global access is a full-row vector.
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); per
+    // 128-row half, each wave drops its 64x64 block (bias + activation applied) into a [128][128]
+    // fp32 LDS tile, then 32 consecutive threads sweep one 512-byte tile row: float4 residual
+    // load, float4 store, and 8-byte bf16 (hi / lo) operand-plane stores.
+    float* cs = (float*)smem;   // 64 KiB; the main loop's last barrier has retired all LDS reads
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (col + u >= p.n) break;
-                    float t = vv[u];
-                    if (resid) t += resid[(long)row * p.ldr + col + u];
-                    t *= rm;
-                    if (of) of[(long)row * p.ldo + col + u] = t;
-                    if (ob) {
-                        const unsigned short hi = f32_to_bf16(t);
-                        char* d = ob + (long)row * p.ldob + plane_off_hi(col + u, p.out_split);
-                        *(unsigned short*)d = hi;
-                        if (p.out_split == 2) *(unsigned short*)(d + 64) = f32_to_bf16(t - bf16_to_f32(hi));
+    for (int half = 0; half < WM / 2; ++half) {
+        if ((wm >> 1) == half) {
+            const float* bias = p.bias;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cl = wn * 64 + j * 32 + lrow;
+                const float bv = (bias && n0 + cl < p.n) ? bias[n0 + cl] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = (wm & 1) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                        float v = acc[i][j][r] * p.alpha + bv;
+                        if (p.act == EFTS_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                        else if (p.act == EFTS_ACT_RELU) v = v > 0.f ? v : 0.f;
+                        cs[rl * 128 + cl] = v;
                     }
                 }
             }
         }
+        __syncthreads();
+        if (col < p.n && !(p.dbg & 1)) {
+#pragma unroll 4
+            for (int ps = 0; ps < NPS; ++ps) {
+                const int rl = ps * RPP + (tid >> 5);
+                const int row = m0 + half * 128 + rl;
+                if (row >= p.m_end) break;
+                float4 v = *(const float4*)(cs + rl * 128 + c4);
+                const float rm = rowmask ? rowmask[row] : 1.f;
+                if (vec) {
+                    if (resid) {
+                        const float4 x = *(const float4*)(resid + (long)row * p.ldr + col);
+                        v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                    }
+                    v.x *= rm; v.y *= rm; v.z *= rm; v.w *= rm;
+                    if (of) *(float4*)(of + (long)row * p.ldo + col) = v;
+                    if (ob) plane_store4(ob + (long)row * p.ldob, col, v.x, v.y, v.z, v.w, p.out_split);
+                } else {
+                    float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (col + u >= p.n) break;
+                        float t = vv[u];
+                        if (resid) t += resid[(long)row * p.ldr + col + u];
+                        t *= rm;
+                        if (of) of[(long)row * p.ldo + col + u] = t;
+                        if (ob) {
+                            const unsigned short hi = f32_to_bf16(t);
+                            char* d = ob + (long)row * p.ldob + plane_off_hi(col + u, p.out_split);
+                            *(unsigned short*)d = hi;
+                            if (p.out_split == 2) *(unsigned short*)(d + 64) = f32_to_bf16(t - bf16_to_f32(hi));
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();   // the LDS tile is re-used by the next half / the next tile's operand ring
     }
+  }   // persistent tile loop
 }
 
 }  // namespace efts
 
 using namespace efts;
+
+template <int T, int S, int W>
+static void launch_gemm(dim3 grid, hipStream_t st, const GemmKernelArgs& k) {
+    int lds = Cfg<T, W>::LDS;
+    if (W == 2) { const char* e = getenv("EFTS_GEMM_LDS_PAD"); if (e) lds += atoi(e); }
+    hipLaunchKernelGGL((gemm_kernel<T, S, W>), grid, dim3(W * 128), lds, st, k);
+}
+template <int T, int S>
+static void set_lds_attr() {
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<T, S, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<T, S, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<T, 4>::LDS);
+}
 
 extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     if (!a) return efts_fail(EFTS_EINVAL, "efts_gemm: null args");
@@ -296,23 +380,65 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     k.lda = a->lda; k.ldb = a->ldb; k.b_tap_stride = a->b_tap_stride; k.ldr = a->ldr; k.ldo = a->ldo; k.ldob = a->ldob;
     k.a_bs = a->a_batch_stride; k.b_bs = a->b_batch_stride; k.r_bs = a->resid_batch_stride;
     k.m_bs = a->rowmask_batch_stride; k.o_bs = a->out_batch_stride; k.ob_bs = a->outb_batch_stride;
-    k.m = a->m; k.n = a->n; k.nchunk = a->nchunk; k.pad = (a->taps - 1) / 2;
-    k.mtiles = (a->m + BM - 1) / BM; k.ntiles = (a->n + BN - 1) / BN;
+    k.n = a->n; k.nchunk = a->nchunk; k.pad = (a->taps - 1) / 2;
+    k.ntiles = (a->n + BN - 1) / BN;
     k.alpha = a->alpha; k.slope = a->slope; k.act = a->act; k.out_split = a->out_split;
     k.vec_ok = (!a->out_f32 || ((a->ldo & 3) == 0 && ((uintptr_t)a->out_f32 & 15) == 0 && (a->out_batch_stride & 3) == 0)) &&
                (!a->resid || ((a->ldr & 3) == 0 && ((uintptr_t)a->resid & 15) == 0 && (a->resid_batch_stride & 3) == 0)) &&
                (!a->out_bf16 || ((a->ldob & 7) == 0 && ((uintptr_t)a->out_bf16 & 7) == 0 && (a->outb_batch_stride & 7) == 0));
     { const char* e = getenv("EFTS_GEMM_DBG"); k.dbg = e ? atoi(e) : 0; }
-
-    dim3 grid(k.mtiles * k.ntiles, a->batch), block(256);
+    { const char* e = getenv("EFTS_GEMM_STAGGER"); k.stagger = e ? atoi(e) : 0; }
     hipStream_t st = (hipStream_t)stream;
-#define EFTS_LAUNCH(T, S) hipLaunchKernelGGL((gemm_kernel<T, S>), grid, block, LDS_BYTES, st, k)
-    if (a->split == 1) {
-        if (a->taps == 5) EFTS_LAUNCH(5, 1); else if (a->taps == 3) EFTS_LAUNCH(3, 1); else EFTS_LAUNCH(1, 1);
-    } else {
-        if (a->taps == 5) EFTS_LAUNCH(5, 2); else if (a->taps == 3) EFTS_LAUNCH(3, 2); else EFTS_LAUNCH(1, 2);
+
+    // Tile plan.  The 256x128 / 8-wave kernel (1 workgroup per CU) is the fast one; it is used for
+    // as many FULL rounds of the chip as the row range holds (256 CUs / ntiles m-tiles per round),
+    // the remaining rows go to the 128x128 / 4-wave kernel (2 workgroups per CU) whose finer tiles
+    // waste less of the last, partially filled round.  EFTS_GEMM_TILE=128|256 forces one kernel.
+    int big_rows = 0;
+    {
+        const char* e = getenv("EFTS_GEMM_TILE");
+        const int force = e ? atoi(e) : 0;
+        const int ncu = efts_num_cus();
+        const long tiles_per_round = (long)ncu;                // one 256x128 workgroup per CU
+        const long mt256 = a->m / 256;                         // full 256-row tiles available
+        long rounds = (mt256 * k.ntiles * a->batch) / tiles_per_round;
+        if (force == 256) big_rows = (int)(mt256 * 256);
+        else if (force != 1 || a->batch > 1) big_rows = 0;   // 128x128 is the default: the 8-wave kernel measured slower
+        else if (rounds >= 1 && tiles_per_round % k.ntiles == 0) big_rows = (int)(rounds * (tiles_per_round / k.ntiles) * 256);
+        // a remainder that is itself almost a full round of big tiles is cheaper on the big kernel
+        if (!force && a->batch == 1 && big_rows > 0) {
+            const long rem_tiles256 = ((a->m - big_rows + 255) / 256) * k.ntiles;
+            if (rem_tiles256 * 10 >= tiles_per_round * 7) big_rows = (int)(mt256 * 256);
+        }
     }
-#undef EFTS_LAUNCH
+#define EFTS_LAUNCH_TS(W)                                                                                   \
+    do {                                                                                                    \
+        if (a->split == 1) {                                                                                \
+            if (a->taps == 5) launch_gemm<5, 1, W>(grid, st, k); else if (a->taps == 3) launch_gemm<3, 1, W>(grid, st, k); else launch_gemm<1, 1, W>(grid, st, k); \
+        } else {                                                                                            \
+            if (a->taps == 5) launch_gemm<5, 2, W>(grid, st, k); else if (a->taps == 3) launch_gemm<3, 2, W>(grid, st, k); else launch_gemm<1, 2, W>(grid, st, k); \
+        }                                                                                                   \
+    } while (0)
+    if (big_rows > 0) {
+        k.m_base = 0; k.m_end = big_rows < a->m ? big_rows : a->m;
+        k.mtiles = (k.m_end - k.m_base + 255) / 256;
+        const int nt_all = k.mtiles * k.ntiles, cap = efts_num_cus();
+        dim3 grid(nt_all < cap ? nt_all : cap, a->batch);
+        EFTS_LAUNCH_TS(4);
+    }
+    if (big_rows < a->m) {
+        k.m_base = big_rows; k.m_end = a->m;
+        k.mtiles = (k.m_end - k.m_base + 127) / 128;
+        const int nt_all = k.mtiles * k.ntiles;
+        // one workgroup per tile by default; EFTS_GEMM_PERSIST=1 runs 2 persistent workgroups per CU
+        // instead (measured neutral on MI355X)
+        int cap = nt_all;
+        { const char* e = getenv("EFTS_GEMM_PERSIST"); if (e && atoi(e) == 1) cap = 2 * efts_num_cus(); }
+        if (a->batch > 1) cap = nt_all;
+        dim3 grid(nt_all < cap ? nt_all : cap, a->batch);
+        EFTS_LAUNCH_TS(2);
+    }
+#undef EFTS_LAUNCH_TS
     return efts_check_launch("efts_gemm");
 }
 
@@ -320,10 +446,18 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
 namespace {
 struct GemmInit {
     GemmInit() {
-#define EFTS_ATTR(T, S) (void)hipFuncSetAttribute((const void*)gemm_kernel<T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)
-        EFTS_ATTR(5, 1); EFTS_ATTR(3, 1); EFTS_ATTR(1, 1); EFTS_ATTR(5, 2); EFTS_ATTR(3, 2); EFTS_ATTR(1, 2);
-#undef EFTS_ATTR
+        set_lds_attr<5, 1>(); set_lds_attr<3, 1>(); set_lds_attr<1, 1>(); set_lds_attr<5, 2>(); set_lds_attr<3, 2>(); set_lds_attr<1, 2>();
     }
 };
 }  // namespace
-extern "C" void efts_gemm_init(void) { static GemmInit once; }
+extern "C" void efts_gemm_init(void) {
+    static GemmInit once;
+    if (getenv("EFTS_DEBUG")) {
+        int nb = -1;
+        constexpr int l2 = Cfg<5, 2>::LDS, l4 = Cfg<5, 4>::LDS;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)gemm_kernel<5, 1, 2>, 256, l2);
+        fprintf(stderr, "[efts] gemm_kernel<5,1,2>: %d workgroups/CU at %d B LDS\n", nb, l2);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)gemm_kernel<5, 1, 4>, 512, l4);
+        fprintf(stderr, "[efts] gemm_kernel<5,1,4>: %d workgroups/CU at %d B LDS\n", nb, l4);
+    }
+}

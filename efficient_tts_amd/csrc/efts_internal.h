@@ -10,6 +10,8 @@ int efts_fail(int code, const char* fmt, ...);
 // hipGetLastError() after a launch -> EFTS_ELAUNCH with the HIP error string.
 int efts_check_launch(const char* what);
 extern "C" void efts_gemm_init(void);
+// number of compute units of the current device (cached)
+int efts_num_cus(void);
 
 namespace efts {
 

@@ -13,6 +13,11 @@ import torch
 from . import lib as L
 
 
+# When set to a list, every efts_gemm launch is bracketed by HIP events recorded on the launch
+# stream (torch's current stream) and (tag, start, end) is appended; tag = (taps, m, n).
+PROFILE = None
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -90,6 +95,13 @@ def gemm(*, a: Plane, a_ptr: Optional[int] = None, b_ptr: int, ldb: int, b_tap_s
         g.out_bf16 = out_plane_ptr if out_plane_ptr is not None else out_plane.ptr
         g.ldob, g.out_split = out_plane.ld, out_plane.split
     g.outb_batch_stride = outb_batch_stride
+    if PROFILE is not None:
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        L.check(L.load().efts_gemm(C.byref(g), _stream()), "efts_gemm")
+        s1.record()
+        PROFILE.append(((taps, m, n), s0, s1))
+        return
     L.check(L.load().efts_gemm(C.byref(g), _stream()), "efts_gemm")
 
 

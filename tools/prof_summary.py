@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 rocpd databases (kernel-trace stats + PMC passes) into text."""
+import glob
+import os
+import sqlite3
+import sys
+
+out, tag = sys.argv[1], sys.argv[2]
+
+
+def db(sub):
+    f = glob.glob(os.path.join(out, sub, "**", "*.db"), recursive=True)
+    return sqlite3.connect(f[0]) if f else None
+
+
+def short(name):
+    return name.replace("void ", "").replace("efts::", "")[:72]
+
+
+print(f"# rocprofv3 summary {tag}: python bench.py --steps 5 --warmup 2 --precision {os.environ.get('PREC', 'bf16')}")
+con = db("trace")
+if con:
+    print("\n## kernel-trace --stats: top kernels (name, calls, total, average [as reported by rocprofv3, us], %)")
+    for r in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 16"):
+        print(f"{short(r[0]):72s} {r[1]:6d} {r[2]:14.1f} {r[3]:10.2f} {r[4]:6.2f}")
+    print("\n## kernel-trace: efts kernels by grid size (name, grid, calls, avg duration us)")
+    try:
+        for r in con.execute("select name, grid_size, count(*), avg(end - start) / 1000.0 from kernels "
+                             "where name like '%efts::%' group by name, grid_size order by 4 * count(*) desc limit 24"):
+            print(f"{short(r[0]):72s} grid={r[1]:9d} n={r[2]:4d} avg={r[3]:9.2f} us")
+    except Exception as e:
+        print("(kernels view unavailable:", e, ")")
+for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_l2"):
+    con = db(sub)
+    if not con:
+        print(f"\n## {sub}: no database (pass failed, see {sub}.log)")
+        continue
+    print(f"\n## {sub}: average counter value per dispatch (efts kernels only)")
+    q = ("select kernel_name, counter_name, avg(value), count(*), grid_size from counters_collection "
+         "where kernel_name like '%efts::%' group by kernel_name, grid_size, counter_name order by kernel_name, grid_size")
+    for r in con.execute(q):
+        print(f"{short(r[0]):72s} {r[1]:28s} {r[2]:18.1f}  n={r[3]} grid={r[4]:.0f}")
