@@ -52,4 +52,15 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// inclusive prefix sum across the 64 lanes of a wave
+__device__ __forceinline__ float wave_scan_incl(float v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
 }  // namespace efts

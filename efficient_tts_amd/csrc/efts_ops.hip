@@ -30,16 +30,6 @@ __device__ __forceinline__ float block_max256(float v, float* sh) {
     __syncthreads();
     return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
 }
-// inclusive prefix sum across the 64 lanes of a wave
-__device__ __forceinline__ float wave_scan_incl(float v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const float t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
-}
 // exclusive prefix of one value per thread over a 256-thread block; *total = block sum
 __device__ __forceinline__ float block_scan_excl256(float v, float* sh /* >= 4 */, float* total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;

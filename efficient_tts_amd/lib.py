@@ -55,6 +55,20 @@ _SIGS = {
     "efts_layernorm_dot": (i32, [vp, vp, vp, f32, vp, vp, vp, i32, f32, vp, i32, i32, vp]),
     "efts_losses_workspace_bytes": (C.c_size_t, []),
     "efts_masked_losses": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    # training step
+    "efts_pack_weight_t": (i32, [vp, vp, i64, i32, i32, i32, i32, vp]),
+    "efts_loss_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "efts_act_bwd": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, i64, i32, vp, i32, i32, vp]),
+    "efts_pack_t": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "efts_wgrad_reduce": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "efts_layernorm_bwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "efts_alpha_bwd": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, vp]),
+    "efts_e_bwd": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, vp]),
+    "efts_imv_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "efts_attn_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
+    "efts_embed_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "efts_sumsq": (i32, [vp, i64, vp, vp]),
+    "efts_adam_amsgrad": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -112,6 +112,12 @@ class _Workspace:
             self.bufs[key] = Plane(nrows, k, split, self.device)
         return self.bufs[key]
 
+    def get(self, key, make):
+        """generic cached object (e.g. transposed planes of the training step)"""
+        if key not in self.bufs:
+            self.bufs[key] = make()
+        return self.bufs[key]
+
     def tensor(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
         key = ("t", name, tuple(shape), dtype)
         if key not in self.bufs:

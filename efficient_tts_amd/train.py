@@ -1,0 +1,379 @@
+"""Training step of EfficientTTSCNN on MI355X: forward with saved activations + hand-written
+backward, all through the C ABI (reference: nntts/trainers/efficient_tts_trainer.py:139-160 calling
+torch autograd on nntts/models/efficient_tts.py:120-228).
+
+`TrainEngine.forward_backward()` returns the three losses and fills ONE flat fp32 gradient buffer
+(views per parameter, laid out in backward-completion order so data-parallel buckets are contiguous
+ranges that become final early: mel head + decoder first, text encoder + embedding last).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import lib as L
+from . import ops as O
+from .ops import F32Rows, PackedWeight, Plane, Rows
+
+_lib = L.load
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class _TPlane(Plane):
+    """transposed operand plane [channels][K = time] for wgrad"""
+
+    def __init__(self, c: int, kpad: int, split: int, device):
+        super().__init__(O.roundup(c, 128) + 136, kpad, split, device)
+        self.c, self.kpad = c, kpad
+
+
+def grad_layout(model) -> List[Tuple[str, torch.nn.Parameter]]:
+    """Parameters in backward-completion order (see module docstring)."""
+    named = dict(model.named_parameters())
+    order: List[str] = []
+
+    def conv(prefix):
+        return [n for n in named if n.startswith(prefix)]
+
+    order += conv("mel_output_layer.")
+    for i in reversed(range(len(model.decoder.layers))):
+        order += conv(f"decoder.layers.{i}.")
+    order += conv("duration_predictor.")
+    for i in reversed(range(len(model.mel_encoder.layers))):
+        order += conv(f"mel_encoder.layers.{i}.")
+    order += conv("mel_prenet.")
+    order += conv("text_encoder_value.") + conv("text_encoder_key.")
+    for i in reversed(range(len(model.text_encoder.layers))):
+        order += conv(f"text_encoder.layers.{i}.")
+    order += conv("text_embedding_table.")
+    assert sorted(order) == sorted(named), "grad layout must cover every parameter exactly once"
+    return [(n, named[n]) for n in order]
+
+
+class TrainEngine:
+    def __init__(self, model):
+        self.m = model
+        self.layout = grad_layout(model)
+        self.dev = next(model.parameters()).device
+        self.numel = sum(p.numel() for _, p in self.layout)
+        pad = (-self.numel) % 4
+        self.flat = torch.zeros(self.numel + pad, dtype=torch.float32, device=self.dev)
+        self.g: Dict[str, torch.Tensor] = {}
+        self.offsets: Dict[str, Tuple[int, int]] = {}
+        off = 0
+        for n, p in self.layout:
+            self.g[n] = self.flat[off:off + p.numel()].view_as(p)
+            self.offsets[n] = (off, off + p.numel())
+            off += p.numel()
+        # bucket boundaries (element offsets into `flat`): head+decoder | dur+mel side | text side
+        self.bucket_ends = [self.offsets[[n for n, _ in self.layout if n.startswith("decoder.layers.0.")][-1]][1],
+                            self.offsets[[n for n, _ in self.layout if n.startswith("mel_prenet.")][-1]][1],
+                            self.numel]
+        self.folded: Dict[str, torch.Tensor] = {}
+        self.wt: Dict[str, PackedWeight] = {}
+        self._sig = None
+        self.bucket_hook: Optional[Callable[[int], None]] = None
+
+    # ------------------------------------------------------------------ weights for the backward
+    def _prepare_weights(self):
+        """forward planes (model._weights), folded fp32 weights and transposed/flipped dgrad planes"""
+        m = self.m
+        pk = m._weights()
+        sig = m._packed_sig
+        if sig == self._sig:
+            return pk
+        dev = self.dev
+        for name, conv in m._conv_modules():
+            taps = conv.kernel_size[0]
+            if name not in self.folded:
+                self.folded[name] = torch.empty(conv.out_channels, conv.in_channels, taps, device=dev)
+                self.wt[name] = PackedWeight(conv.in_channels, conv.out_channels, taps, m.split, dev)
+            if hasattr(conv, "weight_g"):
+                pk[name].pack(conv.weight_v.detach().contiguous(), conv.weight_g.detach().contiguous(), self.folded[name])
+                wsrc = self.folded[name]
+            else:
+                wsrc = conv.weight.detach().contiguous()
+            L.check(_lib().efts_pack_weight_t(wsrc.data_ptr(), self.wt[name].ptr, self.wt[name].ld, conv.out_channels,
+                                              conv.in_channels, taps, m.split, O._stream()), "efts_pack_weight_t")
+        for name, lin in (("key", m.text_encoder_key), ("value", m.text_encoder_value), ("head", m.mel_output_layer)):
+            if name not in self.wt:
+                self.wt[name] = PackedWeight(lin.in_features, lin.out_features, 1, m.split, dev)
+            L.check(_lib().efts_pack_weight_t(lin.weight.detach().contiguous().data_ptr(), self.wt[name].ptr, self.wt[name].ld,
+                                              lin.out_features, lin.in_features, 1, m.split, O._stream()), "efts_pack_weight_t")
+        self._sig = sig
+        return pk
+
+    # ------------------------------------------------------------------ small wrappers
+    def _act_bwd(self, g_ptr, y_ptr, x_ptr, mask_ptr, mode, dz: Optional[F32Rows], plane: Optional[Plane], dbias, rows, c):
+        L.check(_lib().efts_act_bwd(g_ptr, y_ptr, x_ptr, mask_ptr, self.m.slope, mode, None if dz is None else dz.ptr,
+                                    None if plane is None else plane.ptr, 0 if plane is None else plane.ld,
+                                    1 if plane is None else plane.split, _ptr(dbias), rows, c, O._stream()), "efts_act_bwd")
+
+    def _wgrad(self, ws, dz_ptr, cout, x_ptr, ldx, cin, taps, rows, v, g, out_dw, out_dg):
+        """dW[co][ci][k] = sum_t dZ[t][co] X[t+k-pad][ci] as `taps` split-K GEMMs on transposed planes"""
+        split = self.m.split
+        ck = O.chunk_k(split)
+        tiles = ((cout + 127) // 128) * ((cin + 127) // 128)
+        nch_total = (rows + ck - 1) // ck
+        S = max(1, min(64, 512 // tiles, nch_total))
+        nch = (nch_total + S - 1) // S
+        kpad = O.roundup(S * nch * ck, 64)
+        zt = ws.get(("zt", cout, kpad, split), lambda: _TPlane(cout, kpad, split, self.dev))
+        L.check(_lib().efts_pack_t(dz_ptr, cout, zt.ptr, zt.ld, split, rows, cout, 0, kpad, O._stream()), "efts_pack_t")
+        part = ws.get(("part", taps, S, cout, cin), lambda: torch.empty(taps, S, cout, cin, device=self.dev))
+        pad = (taps - 1) // 2
+        for k in range(taps):
+            xt = ws.get(("xt", cin, kpad, split, k), lambda: _TPlane(cin, kpad, split, self.dev))
+            L.check(_lib().efts_pack_t(x_ptr, ldx, xt.ptr, xt.ld, split, rows, cin, k - pad, kpad, O._stream()), "efts_pack_t")
+            O.gemm(a=zt, b_ptr=xt.ptr, ldb=xt.ld, m=cout, n=cin, batch=S, nchunk=nch, a_batch_stride=nch * 128,
+                   b_batch_stride=nch * 128, out_f32_ptr=part[k].data_ptr(), ldo=cin, out_batch_stride=cout * cin)
+        L.check(_lib().efts_wgrad_reduce(part.data_ptr(), S, _ptr(v), _ptr(g), out_dw.data_ptr(), _ptr(out_dg), cout, cin, taps,
+                                         O._stream()), "efts_wgrad_reduce")
+
+    # ------------------------------------------------------------------ forward with saved activations
+    def _stack_fwd(self, ws, tag, blk, pk, rs, x_f, x_p, gap_ptr, last_split):
+        m, C = self.m, self.m.n_channels
+        saved = []
+        layers = getattr(m, blk).layers
+        for i, layer in enumerate(layers):
+            last = i == len(layers) - 1
+            w = pk[f"{blk}.{i}"]
+            o_f = ws.f32(f"T{tag}_f{i}", rs, C)
+            o_p = ws.plane(f"T{tag}_p{i}", rs, C, last_split if last else m.split)
+            O.gemm(a=x_p, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=5, m=rs.rows, n=C, act=L.ACT_LEAKY, slope=m.slope,
+                   bias=layer.conv[0].bias, resid_ptr=x_f.ptr, ldr=C, rowmask_ptr=gap_ptr, out_f32_ptr=o_f.ptr, ldo=C, out_plane=o_p)
+            saved.append((x_f, o_f))
+            x_f, x_p = o_f, o_p
+        return x_f, x_p, saved
+
+    def _stack_bwd(self, ws, tag, blk, rs, G: F32Rows, saved, gap_ptr, final_mask_ptr, final_plane: Optional[Plane]):
+        """backward through n x (x + leaky(conv(x))); returns the gradient w.r.t. the stack input"""
+        m, C = self.m, self.m.n_channels
+        layers = getattr(m, blk).layers
+        for i in reversed(range(len(layers))):
+            x_f, y_f = saved[i]
+            conv = layers[i].conv[0]
+            pre = f"{blk}.layers.{i}.conv.0."
+            dz_f = ws.f32(f"B{tag}_dz", rs, C)
+            dz_p = ws.plane(f"B{tag}_dzp", rs, C, m.split)
+            self._act_bwd(G.ptr, y_f.ptr, x_f.ptr, gap_ptr, 1, dz_f, dz_p, self.g[pre + "bias"], rs.rows, C)
+            if hasattr(conv, "weight_g"):
+                self._wgrad(ws, dz_f.ptr, C, x_f.ptr, C, C, 5, rs.rows, conv.weight_v.detach(), conv.weight_g.detach(),
+                            self.g[pre + "weight_v"], self.g[pre + "weight_g"])
+            else:
+                self._wgrad(ws, dz_f.ptr, C, x_f.ptr, C, C, 5, rs.rows, None, None, self.g[pre + "weight"], None)
+            wt = self.wt[f"{blk}.{i}"]
+            Gn = ws.f32(f"B{tag}_G{i & 1}", rs, C)
+            last = i == 0
+            O.gemm(a=dz_p, b_ptr=wt.ptr, ldb=wt.ld, b_tap_stride=wt.tap_stride, taps=5, m=rs.rows, n=C, resid_ptr=G.ptr, ldr=C,
+                   rowmask_ptr=final_mask_ptr if last else gap_ptr, out_f32_ptr=Gn.ptr, ldo=C,
+                   out_plane=final_plane if last else None)
+            G = Gn
+        return G
+
+    def forward_backward(self, text, text_lengths, speech, speech_lengths, gscale: Optional[torch.Tensor] = None,
+                         keep: bool = False):
+        """One fwd+bwd.  Returns (out3 = [loss, mel_loss, dur_loss] device tensor, aux dict)."""
+        m = self.m
+        dev = self.dev
+        L.require_device()
+        B, T1 = text.shape
+        T2 = speech.shape[1]
+        C, odim, split = m.n_channels, m.odim, m.split
+        text = text.contiguous()
+        speech = speech.contiguous().float()
+        tl = text_lengths.to(device=dev, dtype=torch.int32)
+        ml = speech_lengths.to(device=dev, dtype=torch.int32)
+        pk = self._prepare_weights()
+        ws = m._workspace(("train", B, T1, T2), dev)
+        rs1, rs2 = Rows(B, T1), Rows(B, T2)
+        gap1, len1 = ws.tensor("gap1", (rs1.rows,)), ws.tensor("len1", (rs1.rows,))
+        gap2, len2 = ws.tensor("gap2", (rs2.rows,)), ws.tensor("len2", (rs2.rows,))
+        O.row_masks(tl, rs1, gap1, len1)
+        O.row_masks(ml, rs2, gap2, len2)
+        self.flat.zero_()
+
+        # ============================ forward (efficient_tts.py:144-227), activations kept
+        emb_f, emb_p = ws.f32("Temb_f", rs1, C), ws.plane("Temb_p", rs1, C, split)
+        O.embed(text, m.text_embedding_table.weight.detach(), emb_f, emb_p, rs1)
+        te_f, te_p, te_saved = self._stack_fwd(ws, "te", "text_encoder", pk, rs1, emb_f, emb_p, gap1.data_ptr(), split)
+        key_f, key_p = ws.f32("Tkey_f", rs1, C), ws.plane("Tkey_p", rs1, C, 2)
+        val_f, val_p = ws.f32("Tval_f", rs1, C), ws.plane("Tval_p", rs1, C, split)
+        wk, wv = pk["key"], pk["value"]
+        O.gemm(a=te_p, b_ptr=wk.ptr, ldb=wk.ld, m=rs1.rows, n=C, bias=m.text_encoder_key.bias, rowmask_ptr=len1.data_ptr(),
+               out_f32_ptr=key_f.ptr, ldo=C, out_plane=key_p)
+        O.gemm(a=te_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=m.text_encoder_value.bias, rowmask_ptr=len1.data_ptr(),
+               out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p)
+
+        mel_in_f, mel_in = ws.f32("Tmel_in_f", rs2, odim), ws.plane("Tmel_in", rs2, odim, split)
+        O.pack_rows(speech, mel_in_f, mel_in, rs2)
+        pre_f, pre_p = ws.f32("Tpre_f", rs2, C), ws.plane("Tpre_p", rs2, C, split)
+        wp = pk["prenet"]
+        O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, act=L.ACT_LEAKY, slope=m.slope, bias=m.mel_prenet[0].bias,
+               rowmask_ptr=gap2.data_ptr(), out_f32_ptr=pre_f.ptr, ldo=C, out_plane=pre_p)
+        q_f, q_p, me_saved = self._stack_fwd(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2)
+
+        scale = O.INV_SQRT(C)
+        scores = ws.tensor("Tscores", (B, T2, T1))
+        O.gemm(a=q_p, b_ptr=key_p.ptr, ldb=key_p.ld, m=T2, n=T1, batch=B, a_batch_stride=rs2.Tp * q_p.ld,
+               b_batch_stride=rs1.Tp * key_p.ld, alpha=scale, out_f32_ptr=scores.data_ptr(), ldo=T1, out_batch_stride=T2 * T1)
+        sidx, imv = ws.tensor("Tsidx", (B, T2)), ws.tensor("Timv", (B, T2))
+        O.attn_soft_index(scores, T1, tl, ml, sidx, None, B, T1, T2)
+        O.imv_scan(sidx, tl, ml, imv, B, T2)
+        e, lde = ws.tensor("Te", (B, T1)), ws.tensor("Tlde", (B, T1))
+        O.aligned_positions(imv, tl, ml, float(m.sigma_e), float(m.duration_offset), e, lde, B, T1, T2)
+        ralpha = ws.tensor("Tralpha", (B, T1, T2))
+        ra_p = ws.plane("Tra_p", rs2, T1, 2)
+        O.reconst_alpha(e, tl, ml, float(m.sigma), ralpha, ra_p, B, T1, T2, rs2.Tp)
+
+        vt = ws.raw_plane("Tvt", B * C + 136, T1, 2)
+        O.pack_vt(val_f, vt, B, T1, rs1.Tp, C)
+        h_f, h_p = ws.f32("Texp_f", rs2, C), ws.plane("Texp_p", rs2, C, split)
+        O.gemm(a=ra_p, b_ptr=vt.ptr, ldb=vt.ld, m=T2, n=C, batch=B, a_batch_stride=rs2.Tp * ra_p.ld, b_batch_stride=C * vt.ld,
+               rowmask_ptr=len2.data_ptr(), rowmask_batch_stride=rs2.Tp, out_f32_ptr=h_f.ptr, ldo=C, out_batch_stride=rs2.Tp * C,
+               out_plane=h_p, outb_batch_stride=rs2.Tp * h_p.ld)
+        d_f, d_p, dec_saved = self._stack_fwd(ws, "dec", "decoder", pk, rs2, h_f, h_p, gap2.data_ptr(), split)
+        mel = ws.f32("Tmel_pred", rs2, odim)
+        wh = pk["head"]
+        O.gemm(a=d_p, b_ptr=wh.ptr, ldb=wh.ld, m=rs2.rows, n=odim, bias=m.mel_output_layer.bias, rowmask_ptr=len2.data_ptr(),
+               out_f32_ptr=mel.ptr, ldo=odim)
+
+        dp = m.duration_predictor
+        h1_f, l1_f, l1_p = ws.f32("Tdur_h1", rs1, C), ws.f32("Tdur_l1", rs1, C), ws.plane("Tdur_l1p", rs1, C, split)
+        h2_f = ws.f32("Tdur_h2", rs1, C)
+        dur = ws.tensor("Tdur_out", (rs1.rows,))
+        w0, w1 = pk["dur.0"], pk["dur.1"]
+        ln0, ln1 = dp.conv[0][2], dp.conv[1][2]
+        O.gemm(a=val_p, b_ptr=w0.ptr, ldb=w0.ld, b_tap_stride=w0.tap_stride, taps=3, m=rs1.rows, n=C, act=L.ACT_RELU,
+               bias=dp.conv[0][0].bias, out_f32_ptr=h1_f.ptr, ldo=C)
+        O.layernorm_rows(h1_f.ptr, ln0.weight.detach(), ln0.bias.detach(), ln0.eps, gap1.data_ptr(), l1_f.ptr, l1_p, rs1.rows, C)
+        O.gemm(a=l1_p, b_ptr=w1.ptr, ldb=w1.ld, b_tap_stride=w1.tap_stride, taps=3, m=rs1.rows, n=C, act=L.ACT_RELU,
+               bias=dp.conv[1][0].bias, out_f32_ptr=h2_f.ptr, ldo=C)
+        O.layernorm_dot(h2_f.ptr, ln1.weight.detach(), ln1.bias.detach(), ln1.eps, dp.linear.weight.detach(),
+                        dp.linear.bias.detach(), len1.data_ptr(), 0, float(dp.offset), dur, rs1.rows, C)
+
+        out3 = torch.empty(3, dtype=torch.float32, device=dev)
+        O.masked_losses(mel.ptr, odim, speech, ml, dur, lde, tl, out3, ws.tensor("loss_ws", (1024,)), B, T1, rs1.Tp, T2, rs2.Tp, odim)
+
+        # ============================ backward
+        g = self.g
+        dmel_f = ws.f32("Bdmel_f", rs2, odim)
+        dmel_p = ws.plane("Bdmel_p", rs2, odim, split)
+        ddur = ws.tensor("Bddur", (rs1.rows,))
+        L.check(_lib().efts_loss_bwd(mel.ptr, odim, speech.data_ptr(), ml.data_ptr(), dur.data_ptr(), lde.data_ptr(), tl.data_ptr(),
+                                     _ptr(gscale), dmel_f.ptr, None, 0, split, ddur.data_ptr(), B, T1, rs1.Tp, T2, rs2.Tp, odim,
+                                     O._stream()), "efts_loss_bwd")
+        # mel head (Linear 512->80, masked): bias grad + operand plane, wgrad, dgrad
+        self._act_bwd(dmel_f.ptr, None, None, None, 0, None, dmel_p, g["mel_output_layer.bias"], rs2.rows, odim)
+        self._wgrad(ws, dmel_f.ptr, odim, d_f.ptr, C, C, 1, rs2.rows, None, None, g["mel_output_layer.weight"], None)
+        G = ws.f32("Bdec_Gh", rs2, C)
+        wt = self.wt["head"]
+        O.gemm(a=dmel_p, b_ptr=wt.ptr, ldb=wt.ld, m=rs2.rows, n=C, rowmask_ptr=gap2.data_ptr(), out_f32_ptr=G.ptr, ldo=C)
+        # decoder; its input gradient dH is masked like H (efficient_tts.py:193-194) and also emitted as a split-2 plane
+        dH_p = ws.plane("BdH_p", rs2, C, 2)
+        dH = self._stack_bwd(ws, "dec", "decoder", rs2, G, dec_saved, gap2.data_ptr(), len2.data_ptr(), dH_p)
+        if self.bucket_hook:
+            self.bucket_hook(0)
+
+        # ---- duration predictor (input text_value is NOT detached: efficient_tts.py:219)
+        def gname(i, k):
+            return f"duration_predictor.conv.{i}.{k}"
+        dz2_f, dz2_p = ws.f32("Bdur_dz2", rs1, C), ws.plane("Bdur_dz2p", rs1, C, split)
+        L.check(_lib().efts_layernorm_bwd(h2_f.ptr, ln1.weight.data_ptr(), ln1.bias.data_ptr(), ln1.eps, None, ddur.data_ptr(),
+                                          dp.linear.weight.data_ptr(), None, dz2_f.ptr, dz2_p.ptr, dz2_p.ld, split,
+                                          g[gname(1, "2.weight")].data_ptr(), g[gname(1, "2.bias")].data_ptr(),
+                                          g[gname(1, "0.bias")].data_ptr(), g["duration_predictor.linear.weight"].data_ptr(),
+                                          g["duration_predictor.linear.bias"].data_ptr(), rs1.rows, C, O._stream()), "efts_layernorm_bwd")
+        self._wgrad(ws, dz2_f.ptr, C, l1_f.ptr, C, C, 3, rs1.rows, None, None, g[gname(1, "0.weight")], None)
+        G1 = ws.f32("Bdur_G1", rs1, C)
+        wt = self.wt["dur.1"]
+        O.gemm(a=dz2_p, b_ptr=wt.ptr, ldb=wt.ld, b_tap_stride=wt.tap_stride, taps=3, m=rs1.rows, n=C, out_f32_ptr=G1.ptr, ldo=C)
+        dz1_f, dz1_p = ws.f32("Bdur_dz1", rs1, C), ws.plane("Bdur_dz1p", rs1, C, split)
+        L.check(_lib().efts_layernorm_bwd(h1_f.ptr, ln0.weight.data_ptr(), ln0.bias.data_ptr(), ln0.eps, G1.ptr, None, None,
+                                          gap1.data_ptr(), dz1_f.ptr, dz1_p.ptr, dz1_p.ld, split,
+                                          g[gname(0, "2.weight")].data_ptr(), g[gname(0, "2.bias")].data_ptr(),
+                                          g[gname(0, "0.bias")].data_ptr(), None, None, rs1.rows, C, O._stream()), "efts_layernorm_bwd")
+        self._wgrad(ws, dz1_f.ptr, C, val_f.ptr, C, C, 3, rs1.rows, None, None, g[gname(0, "0.weight")], None)
+        dV_dur = ws.f32("BdV_dur", rs1, C)
+        wt = self.wt["dur.0"]
+        O.gemm(a=dz1_p, b_ptr=wt.ptr, ldb=wt.ld, b_tap_stride=wt.tap_stride, taps=3, m=rs1.rows, n=C, out_f32_ptr=dV_dur.ptr, ldo=C)
+
+        # ---- expand bmm backward: d alpha' [B,T1,T2] and dV
+        val_p2 = ws.plane("Bval_p2", rs1, C, 2)
+        L.check(_lib().efts_pack_rows(val_f.ptr, None, val_p2.ptr, val_p2.ld, B, rs1.Tp, rs1.Tp, C, C, 2, O._stream()), "efts_pack_rows")
+        dAp = ws.tensor("BdAp", (B, T1, T2))
+        O.gemm(a=val_p2, b_ptr=dH_p.ptr, ldb=dH_p.ld, m=T1, n=T2, batch=B, a_batch_stride=rs1.Tp * val_p2.ld,
+               b_batch_stride=rs2.Tp * dH_p.ld, out_f32_ptr=dAp.data_ptr(), ldo=T2, out_batch_stride=T1 * T2)
+        ra1_p = ws.plane("Bra1_p", rs1, T2, 2)                       # alpha' as an A operand: rows (b,i), K = j
+        O.pack_rows(ralpha, None, ra1_p, rs1)
+        dHt = ws.raw_plane("BdHt", B * C + 136, T2, 2)              # dH^T per item: [B][C][K = j]
+        O.pack_vt(dH, dHt, B, T2, rs2.Tp, C)
+        GV = ws.f32("BGV", rs1, C)
+        GV_p = ws.plane("BGV_p", rs1, C, split)
+        O.gemm(a=ra1_p, b_ptr=dHt.ptr, ldb=dHt.ld, m=T1, n=C, batch=B, a_batch_stride=rs1.Tp * ra1_p.ld, b_batch_stride=C * dHt.ld,
+               resid_ptr=dV_dur.ptr, ldr=C, resid_batch_stride=rs1.Tp * C, rowmask_ptr=len1.data_ptr(), rowmask_batch_stride=rs1.Tp,
+               out_f32_ptr=GV.ptr, ldo=C, out_batch_stride=rs1.Tp * C, out_plane=GV_p, outb_batch_stride=rs1.Tp * GV_p.ld)
+
+        # ---- alpha' -> e -> pi -> soft index -> scores
+        de, dpi, dsx = ws.tensor("Bde", (B, T1)), ws.tensor("Bdpi", (B, T2)), ws.tensor("Bdsx", (B, T2))
+        L.check(_lib().efts_alpha_bwd(ralpha.data_ptr(), dAp.data_ptr(), e.data_ptr(), tl.data_ptr(), ml.data_ptr(), float(m.sigma),
+                                      ws.tensor("Br", (B, T2)).data_ptr(), de.data_ptr(), B, T1, T2, O._stream()), "efts_alpha_bwd")
+        L.check(_lib().efts_e_bwd(imv.data_ptr(), e.data_ptr(), de.data_ptr(), tl.data_ptr(), ml.data_ptr(), float(m.sigma_e),
+                                  ws.tensor("Bstats", (2, B, T1)).data_ptr(), dpi.data_ptr(), B, T1, T2, O._stream()), "efts_e_bwd")
+        L.check(_lib().efts_imv_bwd(sidx.data_ptr(), imv.data_ptr(), dpi.data_ptr(), tl.data_ptr(), ml.data_ptr(), dsx.data_ptr(), B, T2,
+                                    O._stream()), "efts_imv_bwd")
+        dS = ws.tensor("BdS", (B, T2, T1))
+        dS_p = ws.plane("BdS_p", rs2, T1, 2)
+        L.check(_lib().efts_attn_bwd(scores.data_ptr(), T1, sidx.data_ptr(), dsx.data_ptr(), tl.data_ptr(), ml.data_ptr(), dS.data_ptr(),
+                                     T1, dS_p.ptr, dS_p.ld, B, T1, T2, rs2.Tp, O._stream()), "efts_attn_bwd")
+        # dQ = scale * dS K ; dK = scale * dS^T Q
+        kt = ws.raw_plane("Bkt", B * C + 136, T1, 2)
+        O.pack_vt(key_f, kt, B, T1, rs1.Tp, C)
+        GQ = ws.f32("BGQ", rs2, C)
+        O.gemm(a=dS_p, b_ptr=kt.ptr, ldb=kt.ld, m=T2, n=C, batch=B, a_batch_stride=rs2.Tp * dS_p.ld, b_batch_stride=C * kt.ld, alpha=scale,
+               out_f32_ptr=GQ.ptr, ldo=C, out_batch_stride=rs2.Tp * C)
+        dSt = ws.raw_plane("BdSt", B * T1 + 264, T2, 2)             # dS^T: rows (b,i), K = j
+        L.check(_lib().efts_pack_vt(dS.data_ptr(), T1, dSt.ptr, dSt.ld, B, T2, T2, T1, O._stream()), "efts_pack_vt")
+        qt = ws.raw_plane("Bqt", B * C + 136, T2, 2)
+        O.pack_vt(q_f, qt, B, T2, rs2.Tp, C)
+        GK = ws.f32("BGK", rs1, C)
+        GK_p = ws.plane("BGK_p", rs1, C, split)
+        O.gemm(a=dSt, b_ptr=qt.ptr, ldb=qt.ld, m=T1, n=C, batch=B, a_batch_stride=T1 * dSt.ld, b_batch_stride=C * qt.ld, alpha=scale,
+               rowmask_ptr=len1.data_ptr(), rowmask_batch_stride=rs1.Tp, out_f32_ptr=GK.ptr, ldo=C, out_batch_stride=rs1.Tp * C,
+               out_plane=GK_p, outb_batch_stride=rs1.Tp * GK_p.ld)
+
+        # ---- mel encoder + prenet
+        Gm = self._stack_bwd(ws, "me", "mel_encoder", rs2, GQ, me_saved, gap2.data_ptr(), gap2.data_ptr(), None)
+        dzp_f = ws.f32("Bpre_dz", rs2, C)
+        self._act_bwd(Gm.ptr, pre_f.ptr, None, gap2.data_ptr(), 3, dzp_f, None, g["mel_prenet.0.bias"], rs2.rows, C)
+        self._wgrad(ws, dzp_f.ptr, C, mel_in_f.ptr, odim, odim, 1, rs2.rows, None, None, g["mel_prenet.0.weight"], None)
+        if self.bucket_hook:
+            self.bucket_hook(1)
+
+        # ---- value / key Linears -> text encoder -> embedding
+        L.check(_lib().efts_act_bwd(GV.ptr, None, None, None, 0.0, 0, ws.f32("Bscratch1", rs1, C).ptr, None, 0, 1,
+                                    g["text_encoder_value.bias"].data_ptr(), rs1.rows, C, O._stream()), "efts_act_bwd")
+        L.check(_lib().efts_act_bwd(GK.ptr, None, None, None, 0.0, 0, ws.f32("Bscratch1", rs1, C).ptr, None, 0, 1,
+                                    g["text_encoder_key.bias"].data_ptr(), rs1.rows, C, O._stream()), "efts_act_bwd")
+        self._wgrad(ws, GV.ptr, C, te_f.ptr, C, C, 1, rs1.rows, None, None, g["text_encoder_value.weight"], None)
+        self._wgrad(ws, GK.ptr, C, te_f.ptr, C, C, 1, rs1.rows, None, None, g["text_encoder_key.weight"], None)
+        Gt0, Gt = ws.f32("Bte_G0", rs1, C), ws.f32("Bte_G1x", rs1, C)
+        wtv, wtk = self.wt["value"], self.wt["key"]
+        O.gemm(a=GV_p, b_ptr=wtv.ptr, ldb=wtv.ld, m=rs1.rows, n=C, rowmask_ptr=gap1.data_ptr(), out_f32_ptr=Gt0.ptr, ldo=C)
+        O.gemm(a=GK_p, b_ptr=wtk.ptr, ldb=wtk.ld, m=rs1.rows, n=C, resid_ptr=Gt0.ptr, ldr=C, rowmask_ptr=gap1.data_ptr(),
+               out_f32_ptr=Gt.ptr, ldo=C)
+        Ge = self._stack_bwd(ws, "te", "text_encoder", rs1, Gt, te_saved, gap1.data_ptr(), gap1.data_ptr(), None)
+        L.check(_lib().efts_embed_bwd(text.data_ptr(), Ge.ptr, g["text_embedding_table.weight"].data_ptr(), B, T1, rs1.Tp, C,
+                                      m.num_symbols, O._stream()), "efts_embed_bwd")
+        if self.bucket_hook:
+            self.bucket_hook(2)
+
+        aux = None
+        if keep:
+            aux = dict(imv=imv, ralpha=ralpha, mel=mel, e=e, dH=dH, dAp=dAp, de=de, dpi=dpi, dsx=dsx, dS=dS, GQ=GQ, GK=GK, GV=GV,
+                       Gm=Gm, Ge=Ge, rs1=rs1, rs2=rs2, ddur=ddur)
+        return out3, aux

@@ -190,6 +190,62 @@ int efts_masked_losses(const float* mel_pred, int64_t ldm, const float* speech, 
                        float* out3, void* workspace, int32_t B, int32_t T1, int32_t T1p, int32_t T2,
                        int32_t T2p, int32_t odim, void* stream);
 
+/* ====================================================================================
+ * Training step (backward + optimizer).  The reference backward is torch autograd of the
+ * forward ops (loss.backward(), nntts/trainers/efficient_tts_trainer.py:153); these entry
+ * points are its hand-written equivalents.  MFMA-shaped gradients (conv/linear dgrad and
+ * wgrad, the four products of the alignment block) run through efts_gemm on operand planes
+ * produced here.
+ * ==================================================================================== */
+/* folded weight w[cout][cin][taps] -> dgrad B plane [taps][cin rows][K = cout], taps flipped */
+int efts_pack_weight_t(const float* w, void* plane, int64_t ldb, int32_t cout, int32_t cin, int32_t taps,
+                       int32_t split, void* stream);
+/* d loss / d mel_pred (fp32 [B*T2p][odim] and/or operand plane) and d loss / d dur_pred [B*T1p]
+ * of FastSpeechLoss(use_masking) (fastspeech_loss.py:54-67); gscale: device scalar or NULL (1). */
+int efts_loss_bwd(const float* mel_pred, int64_t ldm, const float* speech, const int32_t* mel_len,
+                  const float* dur_pred, const float* log_delta_e, const int32_t* text_len, const float* gscale,
+                  float* dmel, void* dmel_plane, int64_t ld_plane, int32_t split, float* ddur, int32_t B, int32_t T1,
+                  int32_t T1p, int32_t T2, int32_t T2p, int32_t odim, void* stream);
+/* dZ = G * act'(.) * rowmask, bias grad += column sums.  mode 1: residual LeakyReLU layer
+ * (sign from y - x); 2: ReLU (sign of y); 3: LeakyReLU without residual (sign of y); 0: identity. */
+int efts_act_bwd(const float* g, const float* y, const float* x, const float* rowmask, float slope, int32_t mode,
+                 float* dz, void* plane, int64_t ld_plane, int32_t split, float* dbias, int32_t rows, int32_t c,
+                 void* stream);
+/* transposed operand plane out[ch][t] = x[t + shift][ch], K = t padded with zeros to kpad (wgrad) */
+int efts_pack_t(const float* x, int64_t ldx, void* plane, int64_t ld_plane, int32_t split, int32_t rows, int32_t c,
+                int32_t shift, int32_t kpad, void* stream);
+/* dW[co][ci][k] = sum_s part[k][s][co][ci]; with g != NULL also the weight-norm backward
+ * (dv -> dw_or_dv, dg) of w = g v / ||v|| */
+int efts_wgrad_reduce(const float* part, int32_t nsplit, const float* v, const float* g, float* dw_or_dv, float* dg,
+                      int32_t cout, int32_t cin, int32_t taps, void* stream);
+/* backward of [ReLU ->] LayerNorm [-> Linear(c,1)] (duration_predictor.py:57-77); accumulates
+ * dgamma, dbeta, conv-bias grad (dbias), and with ddur != NULL the Linear's dw, db. */
+int efts_layernorm_bwd(const float* x, const float* gamma, const float* beta, float eps, const float* dy,
+                       const float* ddur, const float* w, const float* rowmask, float* dz, void* plane,
+                       int64_t ld_plane, int32_t split, float* dgamma, float* dbeta, float* dbias, float* dw, float* db,
+                       int32_t rows, int32_t c, void* stream);
+/* alignment block backward (efficient_tts.py:287-398 under autograd): */
+int efts_alpha_bwd(const float* ralpha, const float* dalpha, const float* e, const int32_t* text_len,
+                   const int32_t* mel_len, float sigma, float* r_ws /* [B*T2] */, float* de, int32_t B, int32_t T1,
+                   int32_t T2, void* stream);
+int efts_e_bwd(const float* imv, const float* e, const float* de, const int32_t* text_len, const int32_t* mel_len,
+               float sigma_e, float* stats_ws /* [2*B*T1] */, float* dpi, int32_t B, int32_t T1, int32_t T2,
+               void* stream);
+int efts_imv_bwd(const float* soft_idx, const float* imv, const float* dpi, const int32_t* text_len,
+                 const int32_t* mel_len, float* dsoft_idx, int32_t B, int32_t T2, void* stream);
+int efts_attn_bwd(const float* scores, int64_t ld, const float* soft_idx, const float* dsoft_idx,
+                  const int32_t* text_len, const int32_t* mel_len, float* dscores, int64_t ldd, void* plane,
+                  int64_t ld_plane, int32_t B, int32_t T1, int32_t T2, int32_t T2p, void* stream);
+int efts_embed_bwd(const int64_t* ids, const float* g, float* dtable, int32_t B, int32_t T, int32_t Tp, int32_t c,
+                   int32_t num_symbols, void* stream);
+/* clip_grad_norm_ + torch.optim.Adam(amsgrad=True, coupled weight decay) on flat fp32 buffers
+ * (trainer.py:154-158; YAML :34-40).  efts_sumsq ACCUMULATES sum(g^2) into *out1 (zero it first);
+ * efts_adam_amsgrad scales g by gscale * min(1, max_norm / (gscale*sqrt(sumsq) + 1e-6)). */
+int efts_sumsq(const float* g, int64_t n, float* out1, void* stream);
+int efts_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, const float* sumsq,
+                      float max_norm, float gscale, float lr, float beta1, float beta2, float eps, float weight_decay,
+                      int32_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

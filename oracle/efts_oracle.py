@@ -247,7 +247,7 @@ def decode(P: Params, expanded: torch.Tensor, hp: dict) -> torch.Tensor:
 
 
 def forward(P: Params, text: torch.Tensor, text_lengths: torch.Tensor, speech: torch.Tensor,
-            speech_lengths: torch.Tensor, hp: dict = DEFAULT_HP) -> dict:
+            speech_lengths: torch.Tensor, hp: dict = DEFAULT_HP, retain: bool = False) -> dict:
     """Teacher-forced forward (efficient_tts.py:120-228).  Returns every intermediate the
     parity tests compare: loss, mel_loss, dur_loss, imv, e, reconst_alpha, mel_pred,
     dur_pred, log_delta_e, alpha (plus text_value / mel_h for kernel-level checks)."""
@@ -271,6 +271,10 @@ def forward(P: Params, text: torch.Tensor, text_lengths: torch.Tensor, speech: t
     ralpha = reconstruct_alignment(e, hp["sigma"], mel_mask, text_mask).masked_fill(~both, 0.0)  # :184-186
 
     expanded = torch.bmm(val.transpose(1, 2), ralpha) * mel_mask[:, None, :]    # :190-194
+    if retain:                                   # gradient checks of the hand-written backward
+        for t in (expanded, ralpha, e, imv, mel_h, key, val):
+            if t.requires_grad:
+                t.retain_grad()
     mel_pred = decode(P, expanded, hp) * mel_mask[:, :, None]                   # :197-200
 
     delta_e = torch.cat([e[:, :1], e[:, 1:] - e[:, :-1]], dim=1).detach()       # :204 (method 1)
@@ -284,7 +288,8 @@ def forward(P: Params, text: torch.Tensor, text_lengths: torch.Tensor, speech: t
     dur_loss = ((dur_pred - log_delta_e).abs() * text_mask).sum() / text_mask.sum()
     return dict(loss=mel_loss + dur_loss, mel_loss=mel_loss, dur_loss=dur_loss, imv=imv, e=e,
                 reconst_alpha=ralpha, mel_pred=mel_pred, dur_pred=dur_pred,
-                log_delta_e=log_delta_e, alpha=alpha, text_value=val, text_key=key, mel_h=mel_h)
+                log_delta_e=log_delta_e, alpha=alpha, text_value=val, text_key=key, mel_h=mel_h,
+                expanded=expanded)
 
 
 def inference(P: Params, text: torch.Tensor, hp: dict = DEFAULT_HP,

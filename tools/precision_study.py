@@ -5,32 +5,11 @@
 Prints max-abs error of each output vs the fp32 oracle on the golden inputs."""
 import os, sys
 import numpy as np, torch
-import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import efts_oracle as O
 
-def split(x):
-    hi = x.to(torch.bfloat16).float()
-    lo = (x - hi).to(torch.bfloat16).float()
-    return hi, lo
+from oracle.precision_emulation import Mode  # noqa: E402
 
-class Mode:
-    def __init__(self, conv_mode, attn_mode):
-        self.conv_mode, self.attn_mode = conv_mode, attn_mode
-    def op(self, f, a, b, mode):
-        if mode == "fp32":
-            return f(a, b)
-        ah, al = split(a); bh, bl = split(b)
-        if mode == "bf16":
-            return f(ah, bh)
-        return f(ah, bh) + f(ah, bl) + f(al, bh)
-    def __enter__(self):
-        self.c, self.l, self.b = F.conv1d, F.linear, torch.bmm
-        F.conv1d = lambda x, w, bias=None, padding=0: self.op(lambda a, b: self.c(a, b, None, padding=padding), x, w, self.conv_mode) + (0 if bias is None else bias[None, :, None])
-        F.linear = lambda x, w, bias=None: self.op(lambda a, b: self.l(a, b), x, w, self.conv_mode) + (0 if bias is None else bias)
-        torch.bmm = lambda a, b: self.op(self.b, a, b, self.attn_mode)
-    def __exit__(self, *a):
-        F.conv1d, F.linear, torch.bmm = self.c, self.l, self.b
 
 def main():
     P = O.fill_params()
