@@ -6,5 +6,6 @@ the ``EfficientTTSTrainer`` step around it): hand-written HIP/CDNA4 kernels behi
 """
 from .model import EfficientTTSCNN  # noqa: F401
 from . import models  # noqa: F401
+from . import trainers  # noqa: F401
 
-__all__ = ["EfficientTTSCNN", "models"]
+__all__ = ["EfficientTTSCNN", "models", "trainers"]

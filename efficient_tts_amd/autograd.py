@@ -1,0 +1,47 @@
+"""torch.autograd bridge: `loss.backward()` on the value returned by EfficientTTSCNN.forward()
+(the reference contract, nntts/trainers/efficient_tts_trainer.py:152-153) runs the hand-written HIP
+backward.  The fused engine computes forward and backward in one pass; the autograd Function hands
+the per-parameter gradients (views of the engine's flat buffer) to torch when backward is called."""
+from __future__ import annotations
+
+import torch
+
+from .model import LazyStats
+from .train import TrainEngine
+
+
+def engine_of(model) -> TrainEngine:
+    eng = getattr(model, "_engine", None)
+    if eng is None or eng.dev != next(model.parameters()).device or eng.stale(model):
+        eng = TrainEngine(model)
+        object.__setattr__(model, "_engine", eng)
+    return eng
+
+
+class _FusedStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, text, text_lengths, speech, speech_lengths, *params):
+        eng = engine_of(model)
+        out3, _ = eng.forward_backward(text, text_lengths, speech, speech_lengths)
+        ctx.eng = eng
+        ctx.names = [n for n, _ in model.named_parameters()]
+        ctx.mark_non_differentiable(out3)
+        return out3[0].clone(), out3
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_out3):
+        eng = ctx.eng
+        eng.flat.mul_(g_loss)                               # d(loss) scaling (1.0 in the reference loop)
+        grads = tuple(eng.g[n] for n in ctx.names)
+        return (None, None, None, None, None) + grads
+
+
+def training_forward(model, text, text_lengths, speech, speech_lengths):
+    params = tuple(model.parameters())
+    loss, out3 = _FusedStep.apply(model, text, text_lengths, speech, speech_lengths, *params)
+    eng = engine_of(model)
+    ws = model._workspace(("train", text.shape[0], text.shape[1], speech.shape[1]), text.device)
+    rs2 = ws.bufs[("f", "Tmel_pred", text.shape[0], speech.shape[1], model.odim)]
+    imv = ws.bufs[("t", "Timv", (text.shape[0], speech.shape[1]), torch.float32)]
+    ralpha = ws.bufs[("t", "Tralpha", (text.shape[0], text.shape[1], speech.shape[1]), torch.float32)]
+    return loss, LazyStats(out3), imv.clone(), ralpha.clone(), rs2.view().clone(), speech

@@ -1,0 +1,76 @@
+"""Data-parallel training over RCCL/xGMI: one process per GPU, gradients averaged with a bucketed
+all-reduce that overlaps the backward pass (replaces torch DistributedDataParallel of the reference,
+nntts/bin/train.py:210-216; payload 20 587 601 fp32 = 82.35 MB per step).
+
+The engine lays its flat gradient buffer out in backward-completion order (efficient_tts_amd/train.py),
+so a bucket is a contiguous slice that is FINAL as soon as its stage of the backward has been
+enqueued: [mel head + decoder] -> [duration predictor + mel encoder + prenet] -> [K/V + text encoder +
+embedding].  Each bucket's all-reduce is issued on a side stream right after that stage while the
+compute stream continues with the next stage; the optimizer waits on the last bucket only.
+xGMI is point-to-point (7 links/GPU): three 25-35 MB buckets keep each ring/tree transfer long
+enough to be link-bound rather than latency-bound.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class BucketReducer:
+    """Sum-all-reduce contiguous slices of one flat tensor, asynchronously, in call order."""
+
+    def __init__(self, flat: torch.Tensor, bucket_ends: List[int], group=None):
+        self.flat, self.ends, self.group = flat, list(bucket_ends), group
+        self.starts = [0] + self.ends[:-1]
+        self.works = []
+        self.comm_stream = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
+
+    def reduce(self, i: int) -> None:
+        view = self.flat[self.starts[i]:self.ends[i]]
+        if self.comm_stream is not None:
+            # the bucket is final once everything already enqueued on the compute stream has run
+            self.comm_stream.wait_stream(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self.comm_stream):
+                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self) -> None:
+        """make the compute stream (or the host, on CPU) wait for every outstanding bucket"""
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.comm_stream is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.comm_stream)
+
+
+class DistributedEFTS(torch.nn.Module):
+    """DDP stand-in with the attributes the reference trainer uses (`.module`, call-through)."""
+
+    def __init__(self, module, group=None):
+        super().__init__()
+        self.module = module
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        from .autograd import engine_of
+        self.engine = engine_of(module)
+        self.reducer: Optional[BucketReducer] = None
+        if self.world > 1:
+            self.reducer = BucketReducer(self.engine.flat, self.engine.bucket_ends, group)
+            self.engine.bucket_hook = self.reducer.reduce
+            # identical initial parameters on every rank (DDP broadcasts rank 0's)
+            for p in module.parameters():
+                dist.broadcast(p.data, src=0, group=group)
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+    def finish_reduce(self) -> None:
+        if self.reducer is not None:
+            self.reducer.finish()

@@ -1,0 +1,91 @@
+"""Optimizer and schedule of the reference recipe, fused for MI355X.
+
+* `EftsAdam` -- torch.optim.Adam(lr, betas, eps, weight_decay (coupled L2), amsgrad=True)
+  (egs/lj/conf/efficient_tts_cnn_phnseq_noDropout.v1.yaml:34-40) as ONE HBM-bound kernel over flat
+  fp32 buffers, with `clip_grad_norm_` (trainer.py:154-157) folded in: the global-norm reduction
+  stays on the device, no host sync per step.  Parameters are re-homed as views of one flat buffer
+  in the engine's gradient layout (so data-parallel buckets are contiguous).
+* `WarmupLR` -- nntts/schedulers/warmup_lr.py:9-51: lr * w^0.5 * min(s^-0.5, s * w^-1.5).
+"""
+from __future__ import annotations
+
+import torch
+from torch.optim.lr_scheduler import _LRScheduler
+
+from . import lib as L
+from . import ops as O
+from .autograd import engine_of
+
+
+class EftsAdam(torch.optim.Optimizer):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.99), eps=1e-9, weight_decay=1e-5, amsgrad=True, grad_norm=1.0):
+        if not amsgrad:
+            raise NotImplementedError("the fused kernel implements amsgrad=True (the reference YAML)")
+        self.model = model
+        self.eng = engine_of(model)
+        eng = self.eng
+        self.grad_norm = float(grad_norm)
+        dev = eng.dev
+        # re-home parameters into one flat buffer (engine layout)
+        self.flat_p = torch.empty_like(eng.flat)
+        with torch.no_grad():
+            for n, p in eng.layout:
+                a, b = eng.offsets[n]
+                self.flat_p[a:b].copy_(p.detach().reshape(-1))
+                p.data = self.flat_p[a:b].view_as(p)
+        self.m = torch.zeros_like(eng.flat)
+        self.v = torch.zeros_like(eng.flat)
+        self.vmax = torch.zeros_like(eng.flat)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.t = 0
+        super().__init__([p for _, p in eng.layout], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        """clip (global norm of grad_scale * flat grads) + Adam-amsgrad, all on the device."""
+        eng = self.eng
+        grp = self.param_groups[0]
+        self.t += 1
+        n = eng.numel
+        st = O._stream()
+        lib = L.load()
+        if self.grad_norm > 0:
+            self.sumsq.zero_()
+            L.check(lib.efts_sumsq(eng.flat.data_ptr(), n, self.sumsq.data_ptr(), st), "efts_sumsq")
+        L.check(lib.efts_adam_amsgrad(self.flat_p.data_ptr(), eng.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                      self.vmax.data_ptr(), n, self.sumsq.data_ptr() if self.grad_norm > 0 else None,
+                                      self.grad_norm, float(grad_scale), float(grp["lr"]), float(grp["betas"][0]),
+                                      float(grp["betas"][1]), float(grp["eps"]), float(grp["weight_decay"]), self.t, st),
+                "efts_adam_amsgrad")
+        # parameters changed in place through the flat view: invalidate packed-weight caches
+        self.model._packed_sig = None
+
+    def zero_grad(self, set_to_none: bool = True):
+        for _, p in self.eng.layout:
+            p.grad = None
+
+    def state_dict(self):
+        return dict(t=self.t, m=self.m, v=self.v, vmax=self.vmax, param_groups=[{k: v for k, v in g.items() if k != "params"}
+                                                                              for g in self.param_groups])
+
+    def load_state_dict(self, sd):
+        self.t = int(sd["t"])
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.vmax.copy_(sd["vmax"])
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)
+
+
+class WarmupLR(_LRScheduler):
+    """lr = base_lr * warmup^0.5 * min(step^-0.5, step * warmup^-1.5), step = last_epoch + 1
+    (nntts/schedulers/warmup_lr.py:44-51)."""
+
+    def __init__(self, optimizer, warmup_steps=25000, last_epoch=-1):
+        self.warmup_steps = warmup_steps
+        super().__init__(optimizer, last_epoch)
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}(warmup_steps={self.warmup_steps})"
+
+    def get_lr(self):
+        s = self.last_epoch + 1
+        return [lr * self.warmup_steps ** 0.5 * min(s ** -0.5, s * self.warmup_steps ** -1.5) for lr in self.base_lrs]

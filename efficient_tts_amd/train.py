@@ -78,6 +78,12 @@ class TrainEngine:
         self._sig = None
         self.bucket_hook: Optional[Callable[[int], None]] = None
 
+    def stale(self, model) -> bool:
+        """True when the model's parameter set no longer matches the layout captured at construction
+        (remove_weight_norm / apply_weight_norm / .to(device))."""
+        cur = {n: p for n, p in model.named_parameters()}
+        return set(cur) != set(self.g) or any(cur[n].shape != self.g[n].shape or cur[n].device != self.dev for n in cur)
+
     # ------------------------------------------------------------------ weights for the backward
     def _prepare_weights(self):
         """forward planes (model._weights), folded fp32 weights and transposed/flipped dgrad planes"""

@@ -1,0 +1,97 @@
+"""CPU, world_size 2 over gloo: the bucketed gradient all-reduce plumbing (efficient_tts_amd/dist.py)
+and the gradient layout it relies on.  The kernels need an MI355X; here the gradient source is the
+oracle's autograd, which is enough to check that N ranks averaging bucket-by-bucket reproduce the
+mean of the per-rank gradients (the reference's DDP semantics, nntts/bin/train.py:210-216)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, golden, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from efficient_tts_amd import EfficientTTSCNN
+    from efficient_tts_amd.dist import BucketReducer
+    from efficient_tts_amd.train import grad_layout
+    from oracle import efts_oracle as O
+    g = np.load(os.path.join(golden, "fwd_tiny.npz"))
+    # each rank takes one item of the tiny batch (DistributedSampler-style shard)
+    sl = slice(rank, rank + 1)
+    T1, T2 = int(g["text_lengths"][rank]), int(g["speech_lengths"][rank])
+    args = [torch.from_numpy(g["text"][sl, :T1]), torch.from_numpy(g["text_lengths"][sl]),
+            torch.from_numpy(g["speech"][sl, :T2]), torch.from_numpy(g["speech_lengths"][sl])]
+    P = {k: v.clone().requires_grad_(True) for k, v in O.fill_params().items()}
+    O.forward(P, *args)["loss"].backward()
+    m = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, sigma=0.01)
+    layout = grad_layout(m)
+    flat = torch.cat([P[n].grad.reshape(-1) for n, _ in layout])
+    local = flat.clone()
+    numel = flat.numel()
+    ends, acc = [], 0
+    for n, p in layout:                      # same three stages as TrainEngine.bucket_ends
+        acc += p.numel()
+        if n.startswith("decoder.layers.0.") or n.startswith("mel_prenet."):
+            last = acc
+        if n == [k for k, _ in layout if k.startswith("decoder.layers.0.")][-1] or n == [k for k, _ in layout if k.startswith("mel_prenet.")][-1]:
+            ends.append(acc)
+    ends.append(numel)
+    red = BucketReducer(flat, ends)
+    for i in range(len(ends)):
+        red.reduce(i)
+    red.finish()
+    flat /= world
+    gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    ref = sum(gathered) / world
+    ok = bool(torch.allclose(flat, ref, rtol=0, atol=1e-7)) and ends[-1] == 20587601 and len(ends) == 3
+    if rank == 0:
+        open(out, "w").write("ok" if ok else f"mismatch {float((flat - ref).abs().max())} {ends}")
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_two_ranks_gloo(golden_dir, tmp_path):
+    out = str(tmp_path / "res.txt")
+    mp.spawn(_worker, args=(2, _free_port(), golden_dir, out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_grad_layout_is_backward_completion_order():
+    from efficient_tts_amd import EfficientTTSCNN
+    from efficient_tts_amd.train import grad_layout
+    m = EfficientTTSCNN(num_symbols=76, use_masking=True)
+    names = [n for n, _ in grad_layout(m)]
+    assert names[0].startswith("mel_output_layer") and names[-1] == "text_embedding_table.weight"
+    assert names.index("decoder.layers.5.conv.0.bias") < names.index("decoder.layers.0.conv.0.bias")
+    assert names.index("decoder.layers.0.conv.0.bias") < names.index("duration_predictor.linear.weight")
+    assert names.index("mel_prenet.0.weight") < names.index("text_encoder_value.weight")
+    assert sorted(names) == sorted(n for n, _ in m.named_parameters())
+
+
+def test_warmup_lr_matches_closed_form():
+    from efficient_tts_amd.optim import WarmupLR
+    from oracle import efts_oracle as O
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=1e-3)
+    sch = WarmupLR(opt, warmup_steps=4000)
+    for step in range(1, 6):
+        assert abs(opt.param_groups[0]["lr"] - O.warmup_lr(1e-3, step, 4000)) < 1e-15
+        opt.step()
+        sch.step()
