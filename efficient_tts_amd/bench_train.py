@@ -1,0 +1,85 @@
+"""bench.py --workload train32: the data-parallel training step (BASELINE configs 3 and 4):
+fwd + bwd + clip(1.0) + Adam-amsgrad + WarmupLR at batch 32 per GPU, (T1, T2) = (128, 800), with the
+gradient all-reduce over RCCL overlapped with backward when world > 1
+(reference: nntts/trainers/efficient_tts_trainer.py:139-160 under nntts/bin/train.py:210-216)."""
+import json
+import os
+import time
+
+import torch
+
+TRAIN_FLOP_PER_ITEM = 3 * 21.43e9
+
+
+def run_train(a, world, rank, dev, wl):
+    import torch.distributed as dist
+    from . import EfficientTTSCNN, ops as P
+    from .dist import DistributedEFTS
+    from .optim import EftsAdam, WarmupLR
+    B, T1, T2 = wl["B"], wl["T1"], wl["T2"]
+    torch.manual_seed(0)
+    model = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, use_weighted_masking=False, sigma=0.01,
+                            precision=a.precision).to(dev).train()
+    opt = EftsAdam(model, lr=1e-3, betas=(0.9, 0.99), eps=1e-9, weight_decay=1e-5, amsgrad=True, grad_norm=1.0)
+    sch = WarmupLR(opt, warmup_steps=4000)
+    ddp = DistributedEFTS(model) if world > 1 else None
+    net = ddp if ddp is not None else model
+    g = torch.Generator().manual_seed(1234 + rank)
+    text = torch.randint(0, 76, (B, T1), generator=g).to(dev)
+    mel = torch.randn(B, T2, 80, generator=g).to(dev)
+    tl = torch.full((B,), T1, dtype=torch.int64, device=dev)
+    sl = torch.full((B,), T2, dtype=torch.int64, device=dev)
+
+    def step():
+        loss, stats, *_ = net(text=text, text_lengths=tl, speech=mel, speech_lengths=sl)
+        opt.zero_grad()
+        loss.backward()
+        if ddp is not None:
+            ddp.finish_reduce()
+        opt.step(grad_scale=1.0 / world)
+        sch.step()
+        return loss
+
+    for _ in range(a.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    P.PROFILE = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    lv = float(loss)
+    assert lv == lv, "NaN loss"
+    rows = P.Rows(B, T2).rows
+    durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in P.PROFILE if tag == (5, rows, 512)]
+    P.PROFILE = None
+    avg = sum(durs) / max(len(durs), 1)
+    conv_flop = 2.0 * B * T2 * 512 * 512 * 5
+    split = model.split
+    if rank == 0:
+        frames = world * B * T2 * a.steps
+        res = dict(metric="mel-frames/sec (EFTS-CNN training step, batch 32/GPU, 80-mel LJSpeech shape)", value=frames / dt,
+                   unit="mel-frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
+                   higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="bf16" if a.precision == "bf16" else "bf16x3 (split-bf16 MFMA, fp32-class)", data="synthetic",
+                   config=dict(workload=wl["desc"], batch_per_gpu=B, phoneme_len=T1, mel_len=T2, precision=a.precision,
+                               parallelism=f"dp{world}", optimizer="Adam-amsgrad fused, clip 1.0, WarmupLR 4000",
+                               allreduce="RCCL, 3 buckets overlapped with backward" if world > 1 else "none"),
+                   per_gpu=frames / dt / world, tflops=TRAIN_FLOP_PER_ITEM * B * world * a.steps / dt / 1e12, loss=lv,
+                   roofline=dict(bound="mfma", kernel=f"gemm_kernel<taps=5,split={split}> fwd + dgrad launches at mel length",
+                                 achieved=conv_flop / avg / 1e12 if avg else None, peak=2500.0, unit="TFLOP/s",
+                                 frac=conv_flop / avg / 1e12 / 2500.0 if avg else None, traffic=None,
+                                 avg_launch_us=avg * 1e6, launches_measured=len(durs)))
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()

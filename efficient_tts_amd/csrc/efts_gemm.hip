@@ -53,6 +53,7 @@ struct GemmKernelArgs {
     char* out_bf16;
     long lda, ldb, b_tap_stride, ldr, ldo, ldob;
     long a_bs, b_bs, r_bs, m_bs, o_bs, ob_bs;
+    long a_bs2, b_bs2, o_bs2;   // outer batch (blockIdx.z)
     int m_base, m_end;   // this launch covers rows [m_base, m_end) (tail launches use a smaller tile)
     int n, nchunk, pad;
     int mtiles, ntiles;
@@ -132,9 +133,10 @@ __global__ __launch_bounds__(WM * 128, (WM == 4) ? 2 : 2) void gemm_kernel(GemmK
     const int c4 = (tid & 31) << 2;
     constexpr int RPP = C::THREADS / 32;                          // tile rows per epilogue sweep
     constexpr int NPS = 128 / RPP;                                // sweeps per 128-row half
+    const int z2 = blockIdx.z;
     const float* resid = p.resid ? p.resid + (long)z * p.r_bs : nullptr;
     const float* rowmask = p.rowmask ? p.rowmask + (long)z * p.m_bs : nullptr;
-    float* of = p.out_f32 ? p.out_f32 + (long)z * p.o_bs : nullptr;
+    float* of = p.out_f32 ? p.out_f32 + (long)z * p.o_bs + (long)z2 * p.o_bs2 : nullptr;
     char* ob = p.out_bf16 ? p.out_bf16 + (long)z * p.ob_bs : nullptr;
 
     // Persistent workgroups: each walks the tile list with stride gridDim.x, so the epilogue's
@@ -161,8 +163,8 @@ __global__ __launch_bounds__(WM * 128, (WM == 4) ? 2 : 2) void gemm_kernel(GemmK
     const int col = n0 + c4;
     const bool vec = p.vec_ok && (col + 3 < p.n);
 
-    const char* A = p.a + (long)z * p.a_bs;
-    const char* Bw = p.b + (long)z * p.b_bs;
+    const char* A = p.a + (long)z * p.a_bs + (long)z2 * p.a_bs2;
+    const char* Bw = p.b + (long)z * p.b_bs + (long)z2 * p.b_bs2;
     const int a_first = m0 - p.pad;            // may be negative: guard rows exist
     const int a_max = 0x7fffffff;              // A rows are never clamped (guards)
     const int b_max = p.n - 1 - n0;            // clamp B rows to the last real row
@@ -380,6 +382,9 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     k.lda = a->lda; k.ldb = a->ldb; k.b_tap_stride = a->b_tap_stride; k.ldr = a->ldr; k.ldo = a->ldo; k.ldob = a->ldob;
     k.a_bs = a->a_batch_stride; k.b_bs = a->b_batch_stride; k.r_bs = a->resid_batch_stride;
     k.m_bs = a->rowmask_batch_stride; k.o_bs = a->out_batch_stride; k.ob_bs = a->outb_batch_stride;
+    k.a_bs2 = a->a_batch2_stride; k.b_bs2 = a->b_batch2_stride; k.o_bs2 = a->out_batch2_stride;
+    const int nb2 = a->batch2 > 1 ? a->batch2 : 1;
+    if (nb2 > 1 && (a->out_bf16 || a->resid || a->rowmask)) return efts_fail(EFTS_EINVAL, "efts_gemm: batch2 supports fp32 output only");
     k.n = a->n; k.nchunk = a->nchunk; k.pad = (a->taps - 1) / 2;
     k.ntiles = (a->n + BN - 1) / BN;
     k.alpha = a->alpha; k.slope = a->slope; k.act = a->act; k.out_split = a->out_split;
@@ -423,7 +428,7 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
         k.m_base = 0; k.m_end = big_rows < a->m ? big_rows : a->m;
         k.mtiles = (k.m_end - k.m_base + 255) / 256;
         const int nt_all = k.mtiles * k.ntiles, cap = efts_num_cus();
-        dim3 grid(nt_all < cap ? nt_all : cap, a->batch);
+        dim3 grid(nt_all < cap ? nt_all : cap, a->batch, nb2);
         EFTS_LAUNCH_TS(4);
     }
     if (big_rows < a->m) {
@@ -435,7 +440,7 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
         int cap = nt_all;
         { const char* e = getenv("EFTS_GEMM_PERSIST"); if (e && atoi(e) == 1) cap = 2 * efts_num_cus(); }
         if (a->batch > 1) cap = nt_all;
-        dim3 grid(nt_all < cap ? nt_all : cap, a->batch);
+        dim3 grid(nt_all < cap ? nt_all : cap, a->batch, nb2);
         EFTS_LAUNCH_TS(2);
     }
 #undef EFTS_LAUNCH_TS

@@ -113,26 +113,31 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 // 128 contiguous bytes per 32 lanes).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_t_kernel(const float* __restrict__ x, long ldx, char* __restrict__ plane,
-                                                     long ldp, int split, int rows, int c, int shift, int kpad) {
-    __shared__ float tile[64][33];
+                                                     long ldp, long plane_stride, int split, int rows, int c, int shift0,
+                                                     int nshift, int kpad) {
+    // nshift planes (shift0, shift0+1, ...) from ONE staged (64 + nshift - 1)-row tile
+    __shared__ float tile[64 + 8][33];
     const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int r = ty; r < 64; r += 8) {
-        const int t = t0 + r + shift;
+    for (int r = ty; r < 64 + nshift - 1; r += 8) {
+        const int t = t0 + r + shift0;
         tile[r][tx] = (t >= 0 && t < rows && c0 + tx < c) ? x[(long)t * ldx + c0 + tx] : 0.f;
     }
     __syncthreads();
     const int tt = t0 + 2 * tx;                        // this thread's first t
     if (tt >= kpad) return;
-    for (int r = ty; r < 32; r += 8) {
-        if (c0 + r >= c) continue;
-        const float a = tile[2 * tx][r], b = tile[2 * tx + 1][r];
-        const unsigned short ha = f32_to_bf16(a), hb = f32_to_bf16(b);
-        char* d = plane + (long)(c0 + r) * ldp + plane_off_hi(tt, split);
-        *(unsigned*)d = (unsigned)ha | ((unsigned)hb << 16);
-        if (split == 2) {
-            const unsigned short la = f32_to_bf16(a - bf16_to_f32(ha)), lb = f32_to_bf16(b - bf16_to_f32(hb));
-            *(unsigned*)(d + 64) = (unsigned)la | ((unsigned)lb << 16);
+    for (int sft = 0; sft < nshift; ++sft) {
+        char* pl = plane + (long)sft * plane_stride;
+        for (int r = ty; r < 32; r += 8) {
+            if (c0 + r >= c) continue;
+            const float a = tile[2 * tx + sft][r], b = tile[2 * tx + 1 + sft][r];
+            const unsigned short ha = f32_to_bf16(a), hb = f32_to_bf16(b);
+            char* d = pl + (long)(c0 + r) * ldp + plane_off_hi(tt, split);
+            *(unsigned*)d = (unsigned)ha | ((unsigned)hb << 16);
+            if (split == 2) {
+                const unsigned short la = f32_to_bf16(a - bf16_to_f32(ha)), lb = f32_to_bf16(b - bf16_to_f32(hb));
+                *(unsigned*)(d + 64) = (unsigned)la | ((unsigned)lb << 16);
+            }
         }
     }
 }
@@ -150,17 +155,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int co = blockIdx.x;
     const int n = cin * taps;
     float dot = 0.f, nn = 0.f;
-    for (int idx = threadIdx.x; idx < n; idx += 256) {
-        const int ci = idx / taps, k = idx - ci * taps;
-        float s = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) s += part[(((long)k * nsplit + sp) * cout + co) * cin + ci];
-        dw_s[idx] = s;
-        if (g) {
+    for (int k = 0; k < taps; ++k)
+        for (int ci = threadIdx.x; ci < cin; ci += 256) {      // threads along ci: coalesced partial reads
+            float s = 0.f;
+            for (int sp = 0; sp < nsplit; ++sp) s += part[(((long)k * nsplit + sp) * cout + co) * cin + ci];
+            dw_s[ci * taps + k] = s;
+        }
+    __syncthreads();
+    if (g)
+        for (int idx = threadIdx.x; idx < n; idx += 256) {
             const float vv = v[(long)co * n + idx];
-            dot += s * vv;
+            dot += dw_s[idx] * vv;
             nn += vv * vv;
         }
-    }
     if (!g) {
         for (int idx = threadIdx.x; idx < n; idx += 256) dw_or_dv[(long)co * n + idx] = dw_s[idx];
         return;
@@ -533,11 +540,13 @@ extern "C" int efts_act_bwd(const float* g, const float* y, const float* x, cons
     return efts_check_launch("efts_act_bwd");
 }
 
-extern "C" int efts_pack_t(const float* x, int64_t ldx, void* plane, int64_t ld_plane, int32_t split, int32_t rows, int32_t c, int32_t shift,
-                           int32_t kpad, void* stream) {
+extern "C" int efts_pack_t(const float* x, int64_t ldx, void* plane, int64_t ld_plane, int64_t plane_stride, int32_t split, int32_t rows,
+                           int32_t c, int32_t shift0, int32_t nshift, int32_t kpad, void* stream) {
     if (!x || !plane) return efts_fail(EFTS_EINVAL, "efts_pack_t: null pointer");
     if (kpad % 64 || ld_plane < (split == 1 ? kpad * 2 : kpad * 4)) return efts_fail(EFTS_ESHAPE, "efts_pack_t: kpad must be a multiple of 64 and fit ld_plane");
-    hipLaunchKernelGGL(pack_t_kernel, dim3(kpad / 64, (c + 31) / 32), dim3(256), 0, ST, x, (long)ldx, (char*)plane, (long)ld_plane, split, rows, c, shift, kpad);
+    if (nshift < 1 || nshift > 9) return efts_fail(EFTS_ESHAPE, "efts_pack_t: nshift must be in 1..9");
+    hipLaunchKernelGGL(pack_t_kernel, dim3(kpad / 64, (c + 31) / 32), dim3(256), 0, ST, x, (long)ldx, (char*)plane, (long)ld_plane, (long)plane_stride,
+                       split, rows, c, shift0, nshift, kpad);
     return efts_check_launch("efts_pack_t");
 }
 

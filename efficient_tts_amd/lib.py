@@ -32,7 +32,8 @@ class GemmArgs(C.Structure):
         ("rowmask", vp), ("rowmask_batch_stride", i64),
         ("out_f32", vp), ("ldo", i64), ("out_batch_stride", i64),
         ("out_bf16", vp), ("ldob", i64), ("outb_batch_stride", i64),
-        ("out_split", i32), ("reserved", i32),
+        ("out_split", i32), ("batch2", i32),
+        ("a_batch2_stride", i64), ("b_batch2_stride", i64), ("out_batch2_stride", i64),
     ]
 
 
@@ -59,7 +60,7 @@ _SIGS = {
     "efts_pack_weight_t": (i32, [vp, vp, i64, i32, i32, i32, i32, vp]),
     "efts_loss_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "efts_act_bwd": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, i64, i32, vp, i32, i32, vp]),
-    "efts_pack_t": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "efts_pack_t": (i32, [vp, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, vp]),
     "efts_wgrad_reduce": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
     "efts_layernorm_bwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, i32, i32, vp]),
     "efts_alpha_bwd": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, vp]),

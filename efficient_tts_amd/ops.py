@@ -80,7 +80,8 @@ def gemm(*, a: Plane, a_ptr: Optional[int] = None, b_ptr: int, ldb: int, b_tap_s
          rowmask_ptr: Optional[int] = None, rowmask_batch_stride: int = 0,
          out_f32_ptr: Optional[int] = None, ldo: int = 0, out_batch_stride: int = 0,
          out_plane: Optional[Plane] = None, out_plane_ptr: Optional[int] = None, outb_batch_stride: int = 0,
-         nchunk: Optional[int] = None) -> None:
+         nchunk: Optional[int] = None, batch2: int = 0, a_batch2_stride: int = 0, b_batch2_stride: int = 0,
+         out_batch2_stride: int = 0) -> None:
     g = L.GemmArgs()
     g.a, g.lda, g.a_batch_stride = (a_ptr if a_ptr is not None else a.ptr), a.ld, a_batch_stride
     g.b, g.ldb, g.b_tap_stride, g.b_batch_stride = b_ptr, ldb, b_tap_stride, b_batch_stride
@@ -95,6 +96,7 @@ def gemm(*, a: Plane, a_ptr: Optional[int] = None, b_ptr: int, ldb: int, b_tap_s
         g.out_bf16 = out_plane_ptr if out_plane_ptr is not None else out_plane.ptr
         g.ldob, g.out_split = out_plane.ld, out_plane.split
     g.outb_batch_stride = outb_batch_stride
+    g.batch2, g.a_batch2_stride, g.b_batch2_stride, g.out_batch2_stride = batch2, a_batch2_stride, b_batch2_stride, out_batch2_stride
     if PROFILE is not None:
         s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s0.record()

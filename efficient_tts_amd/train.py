@@ -31,6 +31,19 @@ class _TPlane(Plane):
         self.c, self.kpad = c, kpad
 
 
+class _TPlaneStack:
+    """`n` transposed planes back to back (one per conv tap)"""
+
+    def __init__(self, c: int, kpad: int, split: int, n: int, device):
+        nrows = O.roundup(c, 128) + 136
+        self.split = split
+        self.nchunk = (kpad + O.chunk_k(split) - 1) // O.chunk_k(split)
+        self.ld = self.nchunk * 128
+        self.plane_bytes = nrows * self.ld
+        self.buf = torch.zeros(n, nrows, self.ld, dtype=torch.uint8, device=device)
+        self.ptr = self.buf.data_ptr()
+
+
 def grad_layout(model) -> List[Tuple[str, torch.nn.Parameter]]:
     """Parameters in backward-completion order (see module docstring)."""
     named = dict(model.named_parameters())
@@ -125,18 +138,19 @@ class TrainEngine:
         ck = O.chunk_k(split)
         tiles = ((cout + 127) // 128) * ((cin + 127) // 128)
         nch_total = (rows + ck - 1) // ck
-        S = max(1, min(64, 512 // tiles, nch_total))
+        S = max(1, min(32, (640 + tiles * taps - 1) // (tiles * taps), nch_total))    # ~640 workgroups per launch
         nch = (nch_total + S - 1) // S
         kpad = O.roundup(S * nch * ck, 64)
         zt = ws.get(("zt", cout, kpad, split), lambda: _TPlane(cout, kpad, split, self.dev))
-        L.check(_lib().efts_pack_t(dz_ptr, cout, zt.ptr, zt.ld, split, rows, cout, 0, kpad, O._stream()), "efts_pack_t")
+        L.check(_lib().efts_pack_t(dz_ptr, cout, zt.ptr, zt.ld, 0, split, rows, cout, 0, 1, kpad, O._stream()), "efts_pack_t")
         part = ws.get(("part", taps, S, cout, cin), lambda: torch.empty(taps, S, cout, cin, device=self.dev))
         pad = (taps - 1) // 2
-        for k in range(taps):
-            xt = ws.get(("xt", cin, kpad, split, k), lambda: _TPlane(cin, kpad, split, self.dev))
-            L.check(_lib().efts_pack_t(x_ptr, ldx, xt.ptr, xt.ld, split, rows, cin, k - pad, kpad, O._stream()), "efts_pack_t")
-            O.gemm(a=zt, b_ptr=xt.ptr, ldb=xt.ld, m=cout, n=cin, batch=S, nchunk=nch, a_batch_stride=nch * 128,
-                   b_batch_stride=nch * 128, out_f32_ptr=part[k].data_ptr(), ldo=cin, out_batch_stride=cout * cin)
+        xts = ws.get(("xt", cin, kpad, split, taps), lambda: _TPlaneStack(cin, kpad, split, taps, self.dev))
+        L.check(_lib().efts_pack_t(x_ptr, ldx, xts.ptr, xts.ld, xts.plane_bytes, split, rows, cin, -pad, taps, kpad, O._stream()),
+                "efts_pack_t")
+        O.gemm(a=zt, b_ptr=xts.ptr, ldb=xts.ld, m=cout, n=cin, batch=S, nchunk=nch, a_batch_stride=nch * 128, b_batch_stride=nch * 128,
+               out_f32_ptr=part.data_ptr(), ldo=cin, out_batch_stride=cout * cin, batch2=taps, b_batch2_stride=xts.plane_bytes,
+               out_batch2_stride=S * cout * cin)
         L.check(_lib().efts_wgrad_reduce(part.data_ptr(), S, _ptr(v), _ptr(g), out_dw.data_ptr(), _ptr(out_dg), cout, cin, taps,
                                          O._stream()), "efts_wgrad_reduce")
 

@@ -99,7 +99,8 @@ typedef struct efts_gemm_args {
     int64_t ldob;      /* bytes */
     int64_t outb_batch_stride;
     int32_t out_split; /* 1 or 2: format of out_bf16 */
-    int32_t reserved;
+    int32_t batch2;    /* optional outer batch (grid.z), 0/1 = none; e.g. the taps of a wgrad */
+    int64_t a_batch2_stride, b_batch2_stride, out_batch2_stride; /* bytes, bytes, elements */
 } efts_gemm_args;
 
 int efts_gemm(const efts_gemm_args* a, void* stream);
@@ -211,9 +212,11 @@ int efts_loss_bwd(const float* mel_pred, int64_t ldm, const float* speech, const
 int efts_act_bwd(const float* g, const float* y, const float* x, const float* rowmask, float slope, int32_t mode,
                  float* dz, void* plane, int64_t ld_plane, int32_t split, float* dbias, int32_t rows, int32_t c,
                  void* stream);
-/* transposed operand plane out[ch][t] = x[t + shift][ch], K = t padded with zeros to kpad (wgrad) */
-int efts_pack_t(const float* x, int64_t ldx, void* plane, int64_t ld_plane, int32_t split, int32_t rows, int32_t c,
-                int32_t shift, int32_t kpad, void* stream);
+/* transposed operand planes out_s[ch][t] = x[t + shift0 + s][ch], s = 0..nshift-1 (plane s at
+ * plane + s*plane_stride bytes), K = t padded with zeros to kpad: the wgrad operands of all taps
+ * from one pass over x */
+int efts_pack_t(const float* x, int64_t ldx, void* plane, int64_t ld_plane, int64_t plane_stride, int32_t split,
+                int32_t rows, int32_t c, int32_t shift0, int32_t nshift, int32_t kpad, void* stream);
 /* dW[co][ci][k] = sum_s part[k][s][co][ci]; with g != NULL also the weight-norm backward
  * (dv -> dw_or_dv, dg) of w = g v / ||v|| */
 int efts_wgrad_reduce(const float* part, int32_t nsplit, const float* v, const float* g, float* dw_or_dv, float* dg,
