@@ -52,6 +52,16 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// counter-based dropout mask: keep (and scale by 1/(1-p)) iff hash(seed, element index) >= p * 2^32.
+// Stateless, so forward and backward regenerate the same mask from (seed, index).
+__device__ __forceinline__ unsigned hash_u32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float drop_scale(unsigned seed_h, unsigned idx, unsigned thresh, float inv_keep) {
+    return hash_u32(idx ^ seed_h) >= thresh ? inv_keep : 0.f;
+}
+
 // inclusive prefix sum across the 64 lanes of a wave
 __device__ __forceinline__ float wave_scan_incl(float v) {
     const int lane = threadIdx.x & 63;

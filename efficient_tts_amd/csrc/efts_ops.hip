@@ -326,7 +326,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ rowmask, float* __restrict__ f32o,
                                                         char* __restrict__ plane, long ldp, int rows, int c, int split,
                                                         const float* __restrict__ w, const float* __restrict__ bptr,
-                                                        int mode, float offset, float* __restrict__ out) {
+                                                        int mode, float offset, float* __restrict__ out, float drop_p,
+                                                        unsigned drop_seed) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -350,6 +351,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         }
     const float rstd = 1.f / sqrtf(wave_sum(q) / (float)c + eps);
     const float rm = rowmask ? rowmask[row] : 1.f;
+    const bool drop = drop_p > 0.f;
+    const unsigned thresh = drop ? (unsigned)(drop_p * 4294967296.0) : 0u, seed_h = hash_u32(drop_seed);
+    const float inv_keep = drop ? 1.f / (1.f - drop_p) : 1.f;
     float dot = 0.f;
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -359,6 +363,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             float4 y;
             y.x = v[u].x * rstd * g.x + bb.x; y.y = v[u].y * rstd * g.y + bb.y;
             y.z = v[u].z * rstd * g.z + bb.z; y.w = v[u].w * rstd * g.w + bb.w;
+            if (drop) {   // Dropout after LayerNorm (duration_predictor.py:61), train mode only
+                const unsigned e0 = (unsigned)row * (unsigned)c + c4;
+                y.x *= drop_scale(seed_h, e0, thresh, inv_keep); y.y *= drop_scale(seed_h, e0 + 1, thresh, inv_keep);
+                y.z *= drop_scale(seed_h, e0 + 2, thresh, inv_keep); y.w *= drop_scale(seed_h, e0 + 3, thresh, inv_keep);
+            }
             if constexpr (DOT) {
                 const float4 ww = *(const float4*)(w + c4);
                 dot += y.x * ww.x + y.y * ww.y + y.z * ww.z + y.w * ww.w;
@@ -522,20 +531,22 @@ extern "C" int efts_cumsum_rows(const float* x, float* y, int32_t B, int32_t T, 
 }
 
 extern "C" int efts_layernorm_rows(const float* x, const float* gamma, const float* beta, float eps, const float* rowmask,
-                                   float* f32_out, void* plane, int64_t ld_plane, int32_t rows, int32_t c, int32_t split, void* stream) {
+                                   float* f32_out, void* plane, int64_t ld_plane, int32_t rows, int32_t c, int32_t split, float drop_p,
+                                   uint32_t drop_seed, void* stream) {
     if (!x || !gamma || !beta || (!f32_out && !plane)) return efts_fail(EFTS_EINVAL, "efts_layernorm_rows: null pointer");
     if (c % 256 || c > 2048 || rows <= 0) return efts_fail(EFTS_ESHAPE, "efts_layernorm_rows: c must be a multiple of 256, <= 2048");
     hipLaunchKernelGGL((layernorm_kernel<false>), dim3((rows + 3) / 4), dim3(256), 0, ST, x, gamma, beta, eps, rowmask, f32_out, (char*)plane,
-                       (long)ld_plane, rows, c, split, (const float*)nullptr, (const float*)nullptr, 0, 0.f, (float*)nullptr);
+                       (long)ld_plane, rows, c, split, (const float*)nullptr, (const float*)nullptr, 0, 0.f, (float*)nullptr, drop_p, drop_seed);
     return efts_check_launch("efts_layernorm_rows");
 }
 
 extern "C" int efts_layernorm_dot(const float* x, const float* gamma, const float* beta, float eps, const float* w, const float* b,
-                                  const float* rowmask, int32_t mode, float offset, float* out, int32_t rows, int32_t c, void* stream) {
+                                  const float* rowmask, int32_t mode, float offset, float* out, int32_t rows, int32_t c, float drop_p,
+                                  uint32_t drop_seed, void* stream) {
     if (!x || !gamma || !beta || !w || !b || !out) return efts_fail(EFTS_EINVAL, "efts_layernorm_dot: null pointer");
     if (c % 256 || c > 2048 || rows <= 0) return efts_fail(EFTS_ESHAPE, "efts_layernorm_dot: c must be a multiple of 256, <= 2048");
     hipLaunchKernelGGL((layernorm_kernel<true>), dim3((rows + 3) / 4), dim3(256), 0, ST, x, gamma, beta, eps, rowmask, (float*)nullptr, (char*)nullptr,
-                       0L, rows, c, 1, w, b, mode, offset, out);
+                       0L, rows, c, 1, w, b, mode, offset, out, drop_p, drop_seed);
     return efts_check_launch("efts_layernorm_dot");
 }
 

@@ -76,11 +76,15 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ x, const float* __restrict__ rowmask,
                                                       float slope, int mode, float* __restrict__ dz, char* __restrict__ plane,
                                                       long ldp, int split, float* __restrict__ dbias, int rows, int c) {
-    // block: 32 rows x c columns; thread t owns column quads t, t+256, ...
+    // block: 32 rows x c columns; the 256 threads cover (c/4) column quads x rpar rows at a time
+    const int nq = c >> 2;
+    const int rpar = nq >= 256 ? 1 : 256 / nq;
+    const int q = nq >= 256 ? threadIdx.x : threadIdx.x % nq, rsub = nq >= 256 ? 0 : threadIdx.x / nq;
     const int r0 = blockIdx.x * 32, r1 = min(r0 + 32, rows);
-    for (int c4 = threadIdx.x << 2; c4 < c; c4 += 1024) {
+    if (rsub >= rpar) return;
+    for (int c4 = q << 2; c4 < c; c4 += 1024) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int r = r0; r < r1; ++r) {
+        for (int r = r0 + rsub; r < r1; r += rpar) {
             const long o = (long)r * c + c4;
             float4 gv = *(const float4*)(g + o);
             const float rm = rowmask ? rowmask[r] : 1.f;
@@ -195,12 +199,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             float* __restrict__ dz, char* __restrict__ plane, long ldp, int split,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             float* __restrict__ dbias, float* __restrict__ dw, float* __restrict__ db,
-                                                            int rows, int c) {
+                                                            int rows, int c, float drop_p, unsigned drop_seed) {
     extern __shared__ float acc_s[];                   // [4][c]: dgamma, dbeta, dbias, dw  (block partials)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 4 * c; i += 256) acc_s[i] = 0.f;
     __syncthreads();
     const int nv = c >> 8;
+    const bool drop = drop_p > 0.f;
+    const unsigned thresh = drop ? (unsigned)(drop_p * 4294967296.0) : 0u, seed_h = hash_u32(drop_seed);
+    const float inv_keep = drop ? 1.f / (1.f - drop_p) : 1.f;
     float db_loc = 0.f;
     // each wave walks rows blockIdx.x*ROWS + wv, +4, ...
     constexpr int ROWS = 32;
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const float dd = ddur ? ddur[row] : 0.f;
         const float rm = rowmask ? rowmask[row] : 1.f;
         float s1 = 0.f, s2 = 0.f;
-        float4 dyv[8];
+        float4 dyv[8], dmv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (u < nv) {
@@ -234,6 +241,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                 float4 dy;
                 if (ddur) { const float4 ww = *(const float4*)(w + c4); dy = make_float4(dd * ww.x, dd * ww.y, dd * ww.z, dd * ww.w); }
                 else { dy = *(const float4*)(dy_in + (long)row * c + c4); dy.x *= rm; dy.y *= rm; dy.z *= rm; dy.w *= rm; }
+                float4 dm = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (drop) {
+                    const unsigned e0 = (unsigned)row * (unsigned)c + c4;
+                    dm = make_float4(drop_scale(seed_h, e0, thresh, inv_keep), drop_scale(seed_h, e0 + 1, thresh, inv_keep),
+                                     drop_scale(seed_h, e0 + 2, thresh, inv_keep), drop_scale(seed_h, e0 + 3, thresh, inv_keep));
+                    dy.x *= dm.x; dy.y *= dm.y; dy.z *= dm.z; dy.w *= dm.w;
+                }
+                dmv[u] = dm;
                 dyv[u] = dy;
                 const float h0 = (xv[u].x - mean) * rstd, h1 = (xv[u].y - mean) * rstd, h2 = (xv[u].z - mean) * rstd, h3 = (xv[u].w - mean) * rstd;
                 s1 += dy.x * gm.x + dy.y * gm.y + dy.z * gm.z + dy.w * gm.w;
@@ -249,6 +264,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                 const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
                 const float dys[4] = {dyv[u].x, dyv[u].y, dyv[u].z, dyv[u].w};
                 const float gms[4] = {gm.x, gm.y, gm.z, gm.w}, bts[4] = {bt.x, bt.y, bt.z, bt.w};
+                const float dms[4] = {dmv[u].x, dmv[u].y, dmv[u].z, dmv[u].w};
                 float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -258,7 +274,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                     atomicAdd(&acc_s[0 * c + c4 + e], dys[e] * h);
                     atomicAdd(&acc_s[1 * c + c4 + e], dys[e]);
                     atomicAdd(&acc_s[2 * c + c4 + e], o[e]);
-                    if (ddur) atomicAdd(&acc_s[3 * c + c4 + e], dd * (h * gms[e] + bts[e]));
+                    if (ddur) atomicAdd(&acc_s[3 * c + c4 + e], dd * (h * gms[e] + bts[e]) * dms[e]);
                 }
                 if (dz) *(float4*)(dz + (long)row * c + c4) = make_float4(o[0], o[1], o[2], o[3]);
                 if (plane) plane_store4(plane + (long)row * ldp, c4, o[0], o[1], o[2], o[3], split);
@@ -560,11 +576,12 @@ extern "C" int efts_wgrad_reduce(const float* part, int32_t nsplit, const float*
 
 extern "C" int efts_layernorm_bwd(const float* x, const float* gamma, const float* beta, float eps, const float* dy, const float* ddur,
                                   const float* w, const float* rowmask, float* dz, void* plane, int64_t ld_plane, int32_t split,
-                                  float* dgamma, float* dbeta, float* dbias, float* dw, float* db, int32_t rows, int32_t c, void* stream) {
+                                  float* dgamma, float* dbeta, float* dbias, float* dw, float* db, int32_t rows, int32_t c, float drop_p,
+                                  uint32_t drop_seed, void* stream) {
     if (!x || !gamma || !beta || (!dy && !ddur) || (ddur && !w) || !dgamma || !dbeta) return efts_fail(EFTS_EINVAL, "efts_layernorm_bwd: null pointer");
     if (c % 256 || c > 2048) return efts_fail(EFTS_ESHAPE, "efts_layernorm_bwd: c must be a multiple of 256, <= 2048");
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + 31) / 32), dim3(256), (size_t)4 * c * sizeof(float), ST, x, gamma, beta, eps, dy, ddur, w,
-                       rowmask, dz, (char*)plane, (long)ld_plane, split, dgamma, dbeta, dbias, dw, db, rows, c);
+                       rowmask, dz, (char*)plane, (long)ld_plane, split, dgamma, dbeta, dbias, dw, db, rows, c, drop_p, drop_seed);
     return efts_check_launch("efts_layernorm_bwd");
 }
 

@@ -52,8 +52,8 @@ _SIGS = {
     "efts_reconst_alpha": (i32, [vp, vp, vp, f32, vp, vp, i64, i32, i32, i32, i32, vp]),
     "efts_pack_vt": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "efts_cumsum_rows": (i32, [vp, vp, i32, i32, vp]),
-    "efts_layernorm_rows": (i32, [vp, vp, vp, f32, vp, vp, vp, i64, i32, i32, i32, vp]),
-    "efts_layernorm_dot": (i32, [vp, vp, vp, f32, vp, vp, vp, i32, f32, vp, i32, i32, vp]),
+    "efts_layernorm_rows": (i32, [vp, vp, vp, f32, vp, vp, vp, i64, i32, i32, i32, f32, C.c_uint32, vp]),
+    "efts_layernorm_dot": (i32, [vp, vp, vp, f32, vp, vp, vp, i32, f32, vp, i32, i32, f32, C.c_uint32, vp]),
     "efts_losses_workspace_bytes": (C.c_size_t, []),
     "efts_masked_losses": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     # training step
@@ -62,7 +62,7 @@ _SIGS = {
     "efts_act_bwd": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, i64, i32, vp, i32, i32, vp]),
     "efts_pack_t": (i32, [vp, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, vp]),
     "efts_wgrad_reduce": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
-    "efts_layernorm_bwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "efts_layernorm_bwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, i32, i32, f32, C.c_uint32, vp]),
     "efts_alpha_bwd": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, vp]),
     "efts_e_bwd": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, vp]),
     "efts_imv_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),

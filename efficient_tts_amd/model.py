@@ -180,6 +180,7 @@ class EfficientTTSCNN(torch.nn.Module):
         self.decoder = _ResConvBlock(n_decoder_layer, n_channels, k_size, a, ap, dropout_rate, use_weight_norm)
         self.mel_output_layer = torch.nn.Linear(n_channels, odim)
         self.duration_predictor = _DurationPredictor(n_channels, n_duration_layer, n_channels, offset=duration_offset)
+        self.dropout_seed = 0x5EED          # base seed of the duration predictor's dropout masks (train mode)
         self._packed: Dict[str, PackedWeight] = {}
         self._packed_sig = None
         self._ws: Dict[Tuple, _Workspace] = {}

@@ -176,15 +176,18 @@ def cumsum_rows(x, y, B, T) -> None:
     L.check(L.load().efts_cumsum_rows(x.data_ptr(), y.data_ptr(), B, T, _stream()), "efts_cumsum_rows")
 
 
-def layernorm_rows(x_ptr, gamma, beta, eps, rowmask_ptr, out_f32_ptr, plane: Optional[Plane], rows, c) -> None:
+def layernorm_rows(x_ptr, gamma, beta, eps, rowmask_ptr, out_f32_ptr, plane: Optional[Plane], rows, c, drop_p: float = 0.0,
+                   drop_seed: int = 0) -> None:
     L.check(L.load().efts_layernorm_rows(x_ptr, gamma.data_ptr(), beta.data_ptr(), eps, rowmask_ptr, out_f32_ptr,
                                          None if plane is None else plane.ptr, 0 if plane is None else plane.ld,
-                                         rows, c, 1 if plane is None else plane.split, _stream()), "efts_layernorm_rows")
+                                         rows, c, 1 if plane is None else plane.split, drop_p, drop_seed & 0xFFFFFFFF, _stream()),
+            "efts_layernorm_rows")
 
 
-def layernorm_dot(x_ptr, gamma, beta, eps, w, b, rowmask_ptr, mode, offset, out, rows, c) -> None:
+def layernorm_dot(x_ptr, gamma, beta, eps, w, b, rowmask_ptr, mode, offset, out, rows, c, drop_p: float = 0.0,
+                  drop_seed: int = 0) -> None:
     L.check(L.load().efts_layernorm_dot(x_ptr, gamma.data_ptr(), beta.data_ptr(), eps, w.data_ptr(), b.data_ptr(),
-                                        rowmask_ptr, mode, offset, out.data_ptr(), rows, c, _stream()),
+                                        rowmask_ptr, mode, offset, out.data_ptr(), rows, c, drop_p, drop_seed & 0xFFFFFFFF, _stream()),
             "efts_layernorm_dot")
 
 

@@ -270,11 +270,17 @@ class TrainEngine:
         ln0, ln1 = dp.conv[0][2], dp.conv[1][2]
         O.gemm(a=val_p, b_ptr=w0.ptr, ldb=w0.ld, b_tap_stride=w0.tap_stride, taps=3, m=rs1.rows, n=C, act=L.ACT_RELU,
                bias=dp.conv[0][0].bias, out_f32_ptr=h1_f.ptr, ldo=C)
-        O.layernorm_rows(h1_f.ptr, ln0.weight.detach(), ln0.bias.detach(), ln0.eps, gap1.data_ptr(), l1_f.ptr, l1_p, rs1.rows, C)
+        # Dropout(0.1) of the duration predictor is active in train() mode like the reference's
+        # (duration_predictor.py:61; the model never forwards its own dropout_rate to it)
+        drop_p = float(dp.conv[0][3].p) if m.training else 0.0
+        self.drop_calls = getattr(self, "drop_calls", 0) + 1
+        seed0, seed1 = (m.dropout_seed + 2 * self.drop_calls) & 0xFFFFFFFF, (m.dropout_seed + 2 * self.drop_calls + 1) & 0xFFFFFFFF
+        O.layernorm_rows(h1_f.ptr, ln0.weight.detach(), ln0.bias.detach(), ln0.eps, gap1.data_ptr(), l1_f.ptr, l1_p, rs1.rows, C,
+                         drop_p, seed0)
         O.gemm(a=l1_p, b_ptr=w1.ptr, ldb=w1.ld, b_tap_stride=w1.tap_stride, taps=3, m=rs1.rows, n=C, act=L.ACT_RELU,
                bias=dp.conv[1][0].bias, out_f32_ptr=h2_f.ptr, ldo=C)
         O.layernorm_dot(h2_f.ptr, ln1.weight.detach(), ln1.bias.detach(), ln1.eps, dp.linear.weight.detach(),
-                        dp.linear.bias.detach(), len1.data_ptr(), 0, float(dp.offset), dur, rs1.rows, C)
+                        dp.linear.bias.detach(), len1.data_ptr(), 0, float(dp.offset), dur, rs1.rows, C, drop_p, seed1)
 
         out3 = torch.empty(3, dtype=torch.float32, device=dev)
         O.masked_losses(mel.ptr, odim, speech, ml, dur, lde, tl, out3, ws.tensor("loss_ws", (1024,)), B, T1, rs1.Tp, T2, rs2.Tp, odim)
@@ -307,7 +313,8 @@ class TrainEngine:
                                           dp.linear.weight.data_ptr(), None, dz2_f.ptr, dz2_p.ptr, dz2_p.ld, split,
                                           g[gname(1, "2.weight")].data_ptr(), g[gname(1, "2.bias")].data_ptr(),
                                           g[gname(1, "0.bias")].data_ptr(), g["duration_predictor.linear.weight"].data_ptr(),
-                                          g["duration_predictor.linear.bias"].data_ptr(), rs1.rows, C, O._stream()), "efts_layernorm_bwd")
+                                          g["duration_predictor.linear.bias"].data_ptr(), rs1.rows, C, drop_p, seed1, O._stream()),
+                "efts_layernorm_bwd")
         self._wgrad(ws, dz2_f.ptr, C, l1_f.ptr, C, C, 3, rs1.rows, None, None, g[gname(1, "0.weight")], None)
         G1 = ws.f32("Bdur_G1", rs1, C)
         wt = self.wt["dur.1"]
@@ -316,7 +323,8 @@ class TrainEngine:
         L.check(_lib().efts_layernorm_bwd(h1_f.ptr, ln0.weight.data_ptr(), ln0.bias.data_ptr(), ln0.eps, G1.ptr, None, None,
                                           gap1.data_ptr(), dz1_f.ptr, dz1_p.ptr, dz1_p.ld, split,
                                           g[gname(0, "2.weight")].data_ptr(), g[gname(0, "2.bias")].data_ptr(),
-                                          g[gname(0, "0.bias")].data_ptr(), None, None, rs1.rows, C, O._stream()), "efts_layernorm_bwd")
+                                          g[gname(0, "0.bias")].data_ptr(), None, None, rs1.rows, C, drop_p, seed0, O._stream()),
+                "efts_layernorm_bwd")
         self._wgrad(ws, dz1_f.ptr, C, val_f.ptr, C, C, 3, rs1.rows, None, None, g[gname(0, "0.weight")], None)
         dV_dur = ws.f32("BdV_dur", rs1, C)
         wt = self.wt["dur.0"]

@@ -171,13 +171,15 @@ int efts_cumsum_rows(const float* x, float* y, int32_t B, int32_t T, void* strea
  * efts_layernorm_dot: out[row] = dot(LN_c(x[row]), w) + b  (LayerNorm + Linear(c,1) + squeeze);
  *   mode 0: log domain, * rowmask (masked_fill(x_masks, 0), :85-86)
  *   mode 1: inference, max(exp(.) - offset, 0)  (:78-83, to_round=False), * rowmask if given.
+ * drop_p > 0 applies the module's Dropout(0.1) after the LayerNorm (:61, train mode): a stateless
+ * counter-based mask from (drop_seed, element index), regenerated identically by efts_layernorm_bwd.
  * ---------------------------------------------------------------------------------- */
 int efts_layernorm_rows(const float* x, const float* gamma, const float* beta, float eps,
                         const float* rowmask, float* f32_out, void* plane, int64_t ld_plane,
-                        int32_t rows, int32_t c, int32_t split, void* stream);
+                        int32_t rows, int32_t c, int32_t split, float drop_p, uint32_t drop_seed, void* stream);
 int efts_layernorm_dot(const float* x, const float* gamma, const float* beta, float eps, const float* w,
                        const float* b, const float* rowmask, int32_t mode, float offset, float* out,
-                       int32_t rows, int32_t c, void* stream);
+                       int32_t rows, int32_t c, float drop_p, uint32_t drop_seed, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * FastSpeechLoss with use_masking=True (nntts/losses/fastspeech_loss.py:54-67):
@@ -226,7 +228,7 @@ int efts_wgrad_reduce(const float* part, int32_t nsplit, const float* v, const f
 int efts_layernorm_bwd(const float* x, const float* gamma, const float* beta, float eps, const float* dy,
                        const float* ddur, const float* w, const float* rowmask, float* dz, void* plane,
                        int64_t ld_plane, int32_t split, float* dgamma, float* dbeta, float* dbias, float* dw, float* db,
-                       int32_t rows, int32_t c, void* stream);
+                       int32_t rows, int32_t c, float drop_p, uint32_t drop_seed, void* stream);
 /* alignment block backward (efficient_tts.py:287-398 under autograd): */
 int efts_alpha_bwd(const float* ralpha, const float* dalpha, const float* e, const int32_t* text_len,
                    const int32_t* mel_len, float sigma, float* r_ws /* [B*T2] */, float* de, int32_t B, int32_t T1,
