@@ -76,14 +76,18 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ x, const float* __restrict__ rowmask,
                                                       float slope, int mode, float* __restrict__ dz, char* __restrict__ plane,
                                                       long ldp, int split, float* __restrict__ dbias, int rows, int c) {
-    // block: 32 rows x c columns; the 256 threads cover (c/4) column quads x rpar rows at a time
-    const int nq = c >> 2;
-    const int rpar = nq >= 256 ? 1 : 256 / nq;
-    const int q = nq >= 256 ? threadIdx.x : threadIdx.x % nq, rsub = nq >= 256 ? 0 : threadIdx.x / nq;
-    const int r0 = blockIdx.x * 32, r1 = min(r0 + 32, rows);
-    if (rsub >= rpar) return;
-    for (int c4 = q << 2; c4 < c; c4 += 1024) {
+    // block: 64 rows x 128 columns (blockIdx.y = column group); 256 threads = 32 column quads x 8
+    // rows in flight.  Column sums are combined in LDS first: ONE global atomic per column per
+    // block (same-address atomics serialise at L2 and were the bottleneck of the first version).
+    __shared__ float colsum[8][128];
+    const int q = threadIdx.x & 31, rsub = threadIdx.x >> 5;
+    const int r0 = blockIdx.x * 64, r1 = min(r0 + 64, rows);
+    const int cbase = blockIdx.y * 128;
+    constexpr int rpar = 8;
+    {
+        const int c4 = cbase + (q << 2);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c4 < c)
         for (int r = r0 + rsub; r < r1; r += rpar) {
             const long o = (long)r * c + c4;
             float4 gv = *(const float4*)(g + o);
@@ -105,8 +109,15 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
             acc.x += gv.x; acc.y += gv.y; acc.z += gv.z; acc.w += gv.w;
         }
         if (dbias) {
-            atomicAdd(dbias + c4, acc.x); atomicAdd(dbias + c4 + 1, acc.y);
-            atomicAdd(dbias + c4 + 2, acc.z); atomicAdd(dbias + c4 + 3, acc.w);
+            colsum[rsub][q * 4] = acc.x; colsum[rsub][q * 4 + 1] = acc.y;
+            colsum[rsub][q * 4 + 2] = acc.z; colsum[rsub][q * 4 + 3] = acc.w;
+            __syncthreads();
+            if (threadIdx.x < 128 && cbase + threadIdx.x < c) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t += colsum[k][threadIdx.x];
+                atomicAdd(dbias + cbase + threadIdx.x, t);
+            }
         }
     }
 }
@@ -551,7 +562,7 @@ extern "C" int efts_act_bwd(const float* g, const float* y, const float* x, cons
                             void* plane, int64_t ld_plane, int32_t split, float* dbias, int32_t rows, int32_t c, void* stream) {
     if (!g || (!dz && !plane)) return efts_fail(EFTS_EINVAL, "efts_act_bwd: null pointer");
     if (c % 4 || (mode == 1 && (!x || !y)) || ((mode == 2 || mode == 3) && !y)) return efts_fail(EFTS_EINVAL, "efts_act_bwd: bad mode/shape");
-    hipLaunchKernelGGL(act_bwd_kernel, dim3((rows + 31) / 32), dim3(256), 0, ST, g, y, x, rowmask, slope, mode, dz, (char*)plane, (long)ld_plane,
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((rows + 63) / 64, (c + 127) / 128), dim3(256), 0, ST, g, y, x, rowmask, slope, mode, dz, (char*)plane, (long)ld_plane,
                        split, dbias, rows, c);
     return efts_check_launch("efts_act_bwd");
 }
