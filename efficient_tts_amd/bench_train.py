@@ -43,7 +43,8 @@ def run_train(a, world, rank, dev, wl):
     for _ in range(a.warmup):
         loss = step()
     torch.cuda.synchronize()
-    P.PROFILE = []
+    rows = P.Rows(B, T2).rows
+    P.PROFILE, P.PROFILE_TAG = [], (5, rows, 512)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -60,9 +61,8 @@ def run_train(a, world, rank, dev, wl):
         dt = float(t.item())
     lv = float(loss)
     assert lv == lv, "NaN loss"
-    rows = P.Rows(B, T2).rows
     durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in P.PROFILE if tag == (5, rows, 512)]
-    P.PROFILE = None
+    P.PROFILE, P.PROFILE_TAG = None, None
     avg = sum(durs) / max(len(durs), 1)
     conv_flop = 2.0 * B * T2 * 512 * 512 * 5
     split = model.split

@@ -345,6 +345,233 @@ __global__ __launch_bounds__(WM * 128, (WM == 4) ? 2 : 2) void gemm_kernel(GemmK
   }   // persistent tile loop
 }
 
+
+// =============================================================================================
+// gemm_kernel_v3: 256x128 tile, 4 waves of 128x64 (8 accumulator blocks, 128 VGPR), 64-byte LDS rows
+// (32 bf16 / 16 hi + 16 lo per step), 4-stage weight ring with COUNTED vmcnt so LDS-DMA stays in
+// flight across three steps, still 2 workgroups per CU (66 KiB LDS each).  Per FLOP it moves 0.59x
+// the DMA bytes (the weight tile is amortised over 256 rows) and issues 0.75x the ds_read_b128 of
+// the 128x128 kernel.  A 128-byte global chunk is consumed as two 64-byte half-chunks.
+// =============================================================================================
+constexpr int V3_BM = 256;
+constexpr int V3_NST = 4;
+constexpr int V3_W_BYTES = BN * 64;     // 8192
+
+// 64-byte rows: four 16-byte slots per row; rows r and r+4 share banks -> slot ^= (r >> 2) & 3
+__device__ __forceinline__ int lds_off64(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+
+// one DMA piece = 16 tile rows x 64 B; `sub` selects the half-chunk, SPLIT the byte mapping
+template <int SPLIT>
+__device__ __forceinline__ void dma_piece64(const char* rowbase0, long ld, int first_row, int max_row, int piece, int lane,
+                                            int sub, char* lds_tile) {
+    const int r = piece * 16 + (lane >> 2);
+    const int ps = lane & 3;
+    const int s = ps ^ ((r >> 2) & 3);
+    int gr = first_row + r;
+    gr = gr > max_row ? max_row : gr;
+    const int boff = (SPLIT == 1) ? sub * 64 + s * 16 : ((s & 2) ? 64 : 0) + sub * 32 + (s & 1) * 16;
+    const char* src = rowbase0 + (long)gr * ld + boff;
+    __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(lds_tile + piece * 1024), 16, 0, 0);
+}
+
+template <int TAPS, int SPLIT>
+__global__ __launch_bounds__(256, 2) void gemm_kernel_v3(GemmKernelArgs p) {
+    constexpr int A_PIECES = V3_BM / 16 + (TAPS == 1 ? 0 : 1);     // 16 or 17 pieces of 16 rows
+    constexpr int A_BYTES = A_PIECES * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#define V3_ABUF(i) (smem + ((i) & 1) * A_BYTES)
+#define V3_WBUF(i) (smem + 2 * A_BYTES + ((i) & (V3_NST - 1)) * V3_W_BYTES)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int z = blockIdx.y, z2 = blockIdx.z;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int nhc = p.nchunk * 2;                      // half-chunks
+    const int nsteps = nhc * TAPS;
+    const int nA = (A_PIECES - wave + 3) / 4;
+
+    const int ntot = p.mtiles * p.ntiles;
+    int bid = blockIdx.x;
+    {
+        const int q = ntot >> 3, r = ntot & 7;
+        const int xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = bid / p.ntiles, nt = bid - mt * p.ntiles;
+    const int m0 = p.m_base + mt * V3_BM, n0 = nt * BN;
+    const char* A = p.a + (long)z * p.a_bs + (long)z2 * p.a_bs2;
+    const char* Bw = p.b + (long)z * p.b_bs + (long)z2 * p.b_bs2;
+    const int a_first = m0 - p.pad;
+    const int b_max = p.n - 1 - n0;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto issue_w = [&](int sn) {
+        const int hc = sn / TAPS, kn = sn - hc * TAPS;
+        const char* wb = Bw + (long)kn * p.b_tap_stride + (long)n0 * p.ldb + (long)(hc >> 1) * 128;
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) dma_piece64<SPLIT>(wb, p.ldb, 0, b_max, wave * 2 + pc, lane, hc & 1, V3_WBUF(sn));
+    };
+    auto issue_a = [&](int hc) {
+        const char* ab = A + (long)(hc >> 1) * 128;
+        for (int pc = wave; pc < A_PIECES; pc += 4) dma_piece64<SPLIT>(ab, p.lda, a_first, 0x7fffffff, pc, lane, hc & 1, V3_ABUF(hc));
+    };
+
+    // prologue: window 0, weights of steps 0..2; wait for window 0 + W(0)
+    issue_a(0);
+    issue_w(0);
+    int pro = 0;
+    if (nsteps > 1) { issue_w(1); pro += 2; }
+    if (nsteps > 2) { issue_w(2); pro += 2; }
+    wait_vmcnt(pro);
+    __builtin_amdgcn_s_barrier();
+
+    int s = 0;
+    for (int hc = 0; hc < nhc; ++hc) {
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k, ++s) {
+            const bool do_w = (s + 3 < nsteps);
+            const bool do_a = (k == 0) && (hc + 1 < nhc);
+            if (TAPS == 1 && do_a) issue_a(hc + 1);
+            if (do_w) issue_w(s + 3);
+            if (TAPS != 1 && do_a) issue_a(hc + 1);
+
+            const char* at = V3_ABUF(hc);
+            const char* wt = V3_WBUF(s);
+            const int arow = wm * 128 + lrow + k;
+            const int brow = wn * 64 + lrow;
+            if constexpr (SPLIT == 1) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int slot = kk * 2 + lhalf;
+                    bf16x8 af[4], bfr[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bfr[j] = *(const bf16x8*)(wt + lds_off64(brow + j * 32, slot));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(at + lds_off64(arow + i * 32, slot));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
+            } else {
+                bf16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bh[j] = *(const bf16x8*)(wt + lds_off64(brow + j * 32, lhalf));
+                    bl[j] = *(const bf16x8*)(wt + lds_off64(brow + j * 32, 2 + lhalf));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ah[i] = *(const bf16x8*)(at + lds_off64(arow + i * 32, lhalf));
+                    al[i] = *(const bf16x8*)(at + lds_off64(arow + i * 32, 2 + lhalf));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            // Counted wait.  DMAs retire in issue order; after this step the weights of step s+1 (and
+            // for taps 1 the next window) must have landed, while the weights of s+2 / s+3 and a
+            // window issued this or the previous step stay in flight across the barrier.
+            int n = 0;
+            if (TAPS == 1) {
+                n = do_w ? 2 : 0;
+            } else {
+                if (s + 2 < nsteps) n += 2;
+                if (do_w) n += 2;
+                if (do_a) n += nA;
+                if (k == 1 && hc + 1 < nhc) n += nA;
+            }
+            wait_vmcnt(n);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue: two 128-row halves through the [128][128] fp32 LDS tile (wave row wm owns half wm)
+    float* cs = (float*)smem;
+    const float* resid = p.resid ? p.resid + (long)z * p.r_bs : nullptr;
+    const float* rowmask = p.rowmask ? p.rowmask + (long)z * p.m_bs : nullptr;
+    float* of = p.out_f32 ? p.out_f32 + (long)z * p.o_bs + (long)z2 * p.o_bs2 : nullptr;
+    char* ob = p.out_bf16 ? p.out_bf16 + (long)z * p.ob_bs : nullptr;
+    const int c4 = (tid & 31) << 2;
+    const int col = n0 + c4;
+    const bool vec = p.vec_ok && (col + 3 < p.n);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (wm == half) {
+            const float* bias = p.bias;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cl = wn * 64 + j * 32 + lrow;
+                const float bv = (bias && n0 + cl < p.n) ? bias[n0 + cl] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                        float v = acc[i][j][r] * p.alpha + bv;
+                        if (p.act == EFTS_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                        else if (p.act == EFTS_ACT_RELU) v = v > 0.f ? v : 0.f;
+                        cs[rl * 128 + cl] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (col < p.n && !(p.dbg & 1)) {
+#pragma unroll 4
+            for (int ps = 0; ps < 16; ++ps) {
+                const int rl = ps * 8 + (tid >> 5);
+                const int row = m0 + half * 128 + rl;
+                if (row >= p.m_end) break;
+                float4 v = *(const float4*)(cs + rl * 128 + c4);
+                const float rm = rowmask ? rowmask[row] : 1.f;
+                if (vec) {
+                    if (resid) {
+                        const float4 x = *(const float4*)(resid + (long)row * p.ldr + col);
+                        v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                    }
+                    v.x *= rm; v.y *= rm; v.z *= rm; v.w *= rm;
+                    if (of) *(float4*)(of + (long)row * p.ldo + col) = v;
+                    if (ob) plane_store4(ob + (long)row * p.ldob, col, v.x, v.y, v.z, v.w, p.out_split);
+                } else {
+                    float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (col + u >= p.n) break;
+                        float t = vv[u];
+                        if (resid) t += resid[(long)row * p.ldr + col + u];
+                        t *= rm;
+                        if (of) of[(long)row * p.ldo + col + u] = t;
+                        if (ob) {
+                            const unsigned short hi = f32_to_bf16(t);
+                            char* d = ob + (long)row * p.ldob + plane_off_hi(col + u, p.out_split);
+                            *(unsigned short*)d = hi;
+                            if (p.out_split == 2) *(unsigned short*)(d + 64) = f32_to_bf16(t - bf16_to_f32(hi));
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace efts
 
 using namespace efts;
@@ -354,6 +581,13 @@ static void launch_gemm(dim3 grid, hipStream_t st, const GemmKernelArgs& k) {
     int lds = Cfg<T, W>::LDS;
     if (W == 2) { const char* e = getenv("EFTS_GEMM_LDS_PAD"); if (e) lds += atoi(e); }
     hipLaunchKernelGGL((gemm_kernel<T, S, W>), grid, dim3(W * 128), lds, st, k);
+}
+template <int T, int S>
+static void launch_gemm_v3(dim3 grid, hipStream_t st, const GemmKernelArgs& k) {
+    constexpr int lds = 2 * (V3_BM / 16 + (T == 1 ? 0 : 1)) * 1024 + V3_NST * V3_W_BYTES;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_kernel_v3<T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL((gemm_kernel_v3<T, S>), grid, dim3(256), lds, st, k);
 }
 template <int T, int S>
 static void set_lds_attr() {
@@ -395,26 +629,14 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     { const char* e = getenv("EFTS_GEMM_STAGGER"); k.stagger = e ? atoi(e) : 0; }
     hipStream_t st = (hipStream_t)stream;
 
-    // Tile plan.  The 256x128 / 8-wave kernel (1 workgroup per CU) is the fast one; it is used for
-    // as many FULL rounds of the chip as the row range holds (256 CUs / ntiles m-tiles per round),
-    // the remaining rows go to the 128x128 / 4-wave kernel (2 workgroups per CU) whose finer tiles
-    // waste less of the last, partially filled round.  EFTS_GEMM_TILE=128|256 forces one kernel.
+    // Tile plan.  Default: the 128x128 / 2-stage kernel everywhere.  EFTS_GEMM_TILE=256 routes
+    // non-batched launches to gemm_kernel_v3 (256x128 tile, 64-byte LDS rows, 4-stage ring, counted
+    // vmcnt): correct, and measured 5-8 % SLOWER on MI355X this round, kept for
+    // the next round's work on the staging path.
     int big_rows = 0;
     {
         const char* e = getenv("EFTS_GEMM_TILE");
-        const int force = e ? atoi(e) : 0;
-        const int ncu = efts_num_cus();
-        const long tiles_per_round = (long)ncu;                // one 256x128 workgroup per CU
-        const long mt256 = a->m / 256;                         // full 256-row tiles available
-        long rounds = (mt256 * k.ntiles * a->batch) / tiles_per_round;
-        if (force == 256) big_rows = (int)(mt256 * 256);
-        else if (force != 1 || a->batch > 1) big_rows = 0;   // 128x128 is the default: the 8-wave kernel measured slower
-        else if (rounds >= 1 && tiles_per_round % k.ntiles == 0) big_rows = (int)(rounds * (tiles_per_round / k.ntiles) * 256);
-        // a remainder that is itself almost a full round of big tiles is cheaper on the big kernel
-        if (!force && a->batch == 1 && big_rows > 0) {
-            const long rem_tiles256 = ((a->m - big_rows + 255) / 256) * k.ntiles;
-            if (rem_tiles256 * 10 >= tiles_per_round * 7) big_rows = (int)(mt256 * 256);
-        }
+        if (e && atoi(e) == 256 && a->batch == 1 && nb2 == 1) big_rows = a->m;
     }
 #define EFTS_LAUNCH_TS(W)                                                                                   \
     do {                                                                                                    \
@@ -427,9 +649,12 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     if (big_rows > 0) {
         k.m_base = 0; k.m_end = big_rows < a->m ? big_rows : a->m;
         k.mtiles = (k.m_end - k.m_base + 255) / 256;
-        const int nt_all = k.mtiles * k.ntiles, cap = efts_num_cus();
-        dim3 grid(nt_all < cap ? nt_all : cap, a->batch, nb2);
-        EFTS_LAUNCH_TS(4);
+        dim3 grid(k.mtiles * k.ntiles, a->batch, nb2);
+        if (a->split == 1) {
+            if (a->taps == 5) launch_gemm_v3<5, 1>(grid, st, k); else if (a->taps == 3) launch_gemm_v3<3, 1>(grid, st, k); else launch_gemm_v3<1, 1>(grid, st, k);
+        } else {
+            if (a->taps == 5) launch_gemm_v3<5, 2>(grid, st, k); else if (a->taps == 3) launch_gemm_v3<3, 2>(grid, st, k); else launch_gemm_v3<1, 2>(grid, st, k);
+        }
     }
     if (big_rows < a->m) {
         k.m_base = big_rows; k.m_end = a->m;

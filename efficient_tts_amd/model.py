@@ -337,6 +337,10 @@ class EfficientTTSCNN(torch.nn.Module):
         return self._forward_impl(text, text_lengths, speech, speech_lengths)[0]
 
     def _forward_impl(self, text, text_lengths, speech, speech_lengths, keep: bool = False):
+        with O.stream_scope():
+            return self._forward_body(text, text_lengths, speech, speech_lengths, keep)
+
+    def _forward_body(self, text, text_lengths, speech, speech_lengths, keep: bool = False):
         dev = text.device
         B, T1 = text.shape
         T2 = speech.shape[1]

@@ -16,10 +16,29 @@ from . import lib as L
 # When set to a list, every efts_gemm launch is bracketed by HIP events recorded on the launch
 # stream (torch's current stream) and (tag, start, end) is appended; tag = (taps, m, n).
 PROFILE = None
+# optional filter: only launches whose tag equals PROFILE_TAG are bracketed (keeps the host light)
+PROFILE_TAG = None
+
+_cached_stream = None
+
+
+class stream_scope:
+    """Resolve torch's current HIP stream ONCE for a whole forward / training step (the lookup costs
+    ~8 us per call and there are hundreds of launches per step)."""
+
+    def __enter__(self):
+        global _cached_stream
+        self.prev = _cached_stream
+        _cached_stream = torch.cuda.current_stream().cuda_stream
+        return self
+
+    def __exit__(self, *a):
+        global _cached_stream
+        _cached_stream = self.prev
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return _cached_stream if _cached_stream is not None else torch.cuda.current_stream().cuda_stream
 
 
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -97,7 +116,7 @@ def gemm(*, a: Plane, a_ptr: Optional[int] = None, b_ptr: int, ldb: int, b_tap_s
         g.ldob, g.out_split = out_plane.ld, out_plane.split
     g.outb_batch_stride = outb_batch_stride
     g.batch2, g.a_batch2_stride, g.b_batch2_stride, g.out_batch2_stride = batch2, a_batch2_stride, b_batch2_stride, out_batch2_stride
-    if PROFILE is not None:
+    if PROFILE is not None and (PROFILE_TAG is None or PROFILE_TAG == (taps, m, n)):
         s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s0.record()
         L.check(L.load().efts_gemm(C.byref(g), _stream()), "efts_gemm")

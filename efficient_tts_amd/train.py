@@ -198,6 +198,10 @@ class TrainEngine:
     def forward_backward(self, text, text_lengths, speech, speech_lengths, gscale: Optional[torch.Tensor] = None,
                          keep: bool = False):
         """One fwd+bwd.  Returns (out3 = [loss, mel_loss, dur_loss] device tensor, aux dict)."""
+        with O.stream_scope():
+            return self._forward_backward(text, text_lengths, speech, speech_lengths, gscale, keep)
+
+    def _forward_backward(self, text, text_lengths, speech, speech_lengths, gscale, keep):
         m = self.m
         dev = self.dev
         L.require_device()

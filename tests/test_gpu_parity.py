@@ -172,8 +172,8 @@ def test_full_size_properties(model):
         sub = slice(5, 9)
         _, _, imv3, _, mel3, _ = model(text[sub], tl[sub], mel[sub], sl[sub])
     assert torch.isfinite(mel_pred).all()
-    assert float((mel_pred[perm] - mel2).abs().max()) == 0.0            # bitwise: tiles never mix items
-    assert float((imv[perm] - imv2).abs().max()) == 0.0
+    assert float((mel_pred[perm] - mel2).abs().max()) == 0.0            # bitwise: tiles never mix items and
+    assert float((imv[perm] - imv2).abs().max()) == 0.0                 # every row sees the same summation order
     assert abs(float(loss) - float(loss2)) <= 1e-5 * float(loss)
     assert float((mel_pred[sub] - mel3).abs().max()) <= 1e-4             # item independence (tile phase differs)
     assert float((ralpha.sum(1) - 1).abs().max()) <= 1e-4
