@@ -424,3 +424,55 @@ class EfficientTTSCNN(torch.nn.Module):
         O.reconst_alpha(e, None, None, float(self.sigma), ralpha, ra_p, 1, T1, t2, rs2.Tp)   # :270-274
         mel = self._expand_decode(ws2, pk, 1, T1, rs1, rs2, val_f, ra_p, None, gap2)         # :278-284
         return mel.view().clone(), ralpha
+
+    # ------------------------------------------------------------------ batched ragged inference (extension)
+    @torch.no_grad()
+    def inference_batch(self, text: torch.Tensor, text_lengths: torch.Tensor):
+        """Free-running synthesis of B utterances at once -- an extension the reference cannot do
+        (its inference() is B == 1 only: efficient_tts.py:361).  Every item is computed exactly as if it
+        were alone: positions beyond an item's own length are kept at zero after EVERY layer (true
+        zero padding, the opposite of the teacher-forced forward's leakage semantics), durations are
+        accumulated per item and each item gets its own mel length T2_b = round(sum of durations).
+
+        Returns (mel_pred [B, max T2_b, odim] zero-padded, mel_lengths [B] int64, reconst_alpha
+        [B, T1, max T2_b]).  One host sync (max T2_b), like the reference's single `.item()`."""
+        self._require(text)
+        with O.stream_scope():
+            dev = text.device
+            B, T1 = text.shape
+            C = self.n_channels
+            pk = self._weights()
+            ws = self._workspace(("infb", B, T1), dev)
+            rs1 = Rows(B, T1)
+            tl = text_lengths.to(device=dev, dtype=torch.int32)
+            gap1, len1 = ws.tensor("gap1", (rs1.rows,)), ws.tensor("len1", (rs1.rows,))
+            O.row_masks(tl, rs1, gap1, len1)
+            # embedding with padded positions zeroed, then every layer masked by the item length
+            e_f, e_p = ws.f32("emb_raw", rs1, C), None
+            O.embed(text.contiguous(), self.text_embedding_table.weight.detach(), e_f, None, rs1)
+            x_f, x_p = ws.f32("emb_f", rs1, C), ws.plane("emb_p", rs1, C, self.split)
+            O.mask_rows(e_f.ptr, len1.data_ptr(), x_f, x_p, rs1.rows, C)
+            _, h_p = self._res_stack(ws, "te", "text_encoder", pk, rs1, x_f, x_p, len1.data_ptr(), self.split, False)
+            val_f, val_p = ws.f32("val_f", rs1, C), ws.plane("val_p", rs1, C, self.split)
+            wv = pk["value"]
+            O.gemm(a=h_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=self.text_encoder_value.bias,
+                   rowmask_ptr=len1.data_ptr(), out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p)
+            delta = self._duration(ws, pk, rs1, val_p, len1, len1.data_ptr(), 1)          # zero beyond each length
+            d2 = delta.view(B, rs1.Tp)[:, :T1].contiguous()
+            e = ws.tensor("e", (B, T1))
+            O.cumsum_rows(d2, e, B, T1)
+            last = e.gather(1, (text_lengths.to(dev).long() - 1).clamp(min=0)[:, None]).squeeze(1)
+            ml = torch.round(last).to(torch.int32)
+            t2 = int(ml.max().item())                                                      # the one host sync
+            if t2 <= 0:
+                raise ValueError("predicted total durations round to 0 frames")
+            rs2 = Rows(B, t2)
+            ws2 = self._workspace(("infb2", B, T1, t2), dev)
+            gap2, len2 = ws2.tensor("gap2", (rs2.rows,)), ws2.tensor("len2", (rs2.rows,))
+            O.row_masks(ml, rs2, gap2, len2)
+            ralpha = torch.empty(B, T1, t2, dtype=torch.float32, device=dev)
+            ra_p = ws2.plane("ra_p", rs2, T1, 2)
+            O.reconst_alpha(e, tl, ml, float(self.sigma), ralpha, ra_p, B, T1, t2, rs2.Tp)
+            mel = self._expand_decode(ws2, pk, B, T1, rs1, rs2, val_f, ra_p, len2.data_ptr(), len2)
+            return mel.view().clone(), ml.to(torch.int64), ralpha
+

@@ -210,6 +210,13 @@ def layernorm_dot(x_ptr, gamma, beta, eps, w, b, rowmask_ptr, mode, offset, out,
             "efts_layernorm_dot")
 
 
+def mask_rows(x_ptr, rowmask_ptr, out: Optional[F32Rows], plane: Optional[Plane], rows, c) -> None:
+    """out[row] = x[row] * rowmask[row] (fp32 and/or operand plane): efts_act_bwd in identity mode"""
+    L.check(L.load().efts_act_bwd(x_ptr, None, None, rowmask_ptr, 0.0, 0, None if out is None else out.ptr,
+                                  None if plane is None else plane.ptr, 0 if plane is None else plane.ld,
+                                  1 if plane is None else plane.split, None, rows, c, _stream()), "efts_act_bwd")
+
+
 def losses_workspace(device) -> torch.Tensor:
     return torch.zeros(L.load().efts_losses_workspace_bytes() // 4, dtype=torch.float32, device=device)
 

@@ -179,3 +179,25 @@ def test_full_size_properties(model):
     assert float((ralpha.sum(1) - 1).abs().max()) <= 1e-4
     assert float((imv[:, 1:] - imv[:, :-1]).min()) >= 0.0
     assert float((imv[:, -1] - (T1 - 1)).abs().max()) <= 1e-3
+
+
+def test_batched_ragged_inference_equals_single_item(golden_dir, model):
+    """inference_batch (extension): every item of a ragged batch equals the B=1
+    reference-semantics inference of that item alone (and therefore the reference golden)."""
+    g = _golden(golden_dir, "inference_lj")
+    dev = _dev()
+    seqs = [torch.from_numpy(g[f"text{n}"])[0] for n in range(4)]
+    T1 = max(len(s) for s in seqs)
+    text = torch.zeros(4, T1, dtype=torch.int64)
+    for n, s in enumerate(seqs):
+        text[n, :len(s)] = s
+    lens = torch.tensor([len(s) for s in seqs])
+    mel, mel_len, ralpha = model.inference_batch(text.to(dev), lens.to(dev))
+    for n, s in enumerate(seqs):
+        t2 = int(g[f"t2_{n}"])
+        assert int(mel_len[n]) == t2
+        one, ra1 = model.inference(s[None].to(dev))
+        assert float((mel[n, :t2] - one[0]).abs().max()) <= 2e-4
+        assert float(mel[n, t2:].abs().max()) == 0.0 if mel.shape[1] > t2 else True
+        assert float((ralpha[n, :len(s), :t2] - ra1[0]).abs().max()) <= 1e-5
+        assert float((mel[n, :t2:2].cpu() - torch.from_numpy(g[f"mel_pred{n}"])[0]).abs().max()) <= MEL_TOL
