@@ -31,6 +31,8 @@ class _FusedStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_out3):
         eng = ctx.eng
+        if eng.join_reduce is not None:                      # data-parallel: the bucketed all-reduce launched during the
+            eng.join_reduce()                                # fused pass works in place on `flat`; join it before scaling
         eng.flat.mul_(g_loss)                               # d(loss) scaling (1.0 in the reference loop)
         grads = tuple(eng.g[n] for n in ctx.names)
         return (None, None, None, None, None) + grads

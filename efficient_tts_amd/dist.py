@@ -60,6 +60,7 @@ class DistributedEFTS(torch.nn.Module):
         if self.world > 1:
             self.reducer = BucketReducer(self.engine.flat, self.engine.bucket_ends, group)
             self.engine.bucket_hook = self.reducer.reduce
+            self.engine.join_reduce = self.reducer.finish
             # identical initial parameters on every rank (DDP broadcasts rank 0's)
             for p in module.parameters():
                 dist.broadcast(p.data, src=0, group=group)

@@ -235,6 +235,13 @@ class EfficientTTSCNN(torch.nn.Module):
         self._packed_sig = sig
         return pk
 
+    def _side_stream(self, device) -> "torch.cuda.Stream":
+        st = getattr(self, "_side", None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device)
+            object.__setattr__(self, "_side", st)
+        return st
+
     def _workspace(self, key, device) -> _Workspace:
         if key not in self._ws:
             if len(self._ws) >= 4:                      # bound cached shapes (each holds full activations)
@@ -357,8 +364,17 @@ class EfficientTTSCNN(torch.nn.Module):
         O.row_masks(tl, rs1, gap1, len1)                                          # :137
         O.row_masks(ml, rs2, gap2, len2)                                          # :139
 
-        key_p, val_f, val_p = self._text_side(ws, pk, text, rs1, gap1, len1)      # :144-157
-
+        # The text side (embed, 5 convs, K/V) and the duration predictor do not depend on the mel side
+        # (prenet, 3 convs): they run on a second HIP stream so their small grids fill the tail rounds
+        # of the mel-length kernels instead of serialising behind them.
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev)
+        side.wait_stream(main)
+        with O.on_stream(side):
+            key_p, val_f, val_p = self._text_side(ws, pk, text, rs1, gap1, len1)  # :144-157
+            k_ready = torch.cuda.Event()
+            k_ready.record(side)
+            dur = self._duration(ws, pk, rs1, val_p, gap1, len1.data_ptr(), 0)    # :219
         mel_in = ws.plane("mel_in", rs2, self.odim, self.split)                   # :161 prenet
         O.pack_rows(speech, None, mel_in, rs2)
         pre_f, pre_p = ws.f32("pre_f", rs2, C), ws.plane("pre_p", rs2, C, self.split)
@@ -366,6 +382,7 @@ class EfficientTTSCNN(torch.nn.Module):
         O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, act=L.ACT_LEAKY, slope=self.slope,
                bias=self.mel_prenet[0].bias, rowmask_ptr=gap2.data_ptr(), out_f32_ptr=pre_f.ptr, ldo=C, out_plane=pre_p)
         _, q_p = self._res_stack(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2, False)   # :162
+        main.wait_event(k_ready)
 
         scores = ws.tensor("scores", (B, T2, T1))                                 # :390 q.k/sqrt(D)
         O.gemm(a=q_p, b_ptr=key_p.ptr, ldb=key_p.ld, m=T2, n=T1, batch=B, a_batch_stride=rs2.Tp * q_p.ld,
@@ -382,7 +399,7 @@ class EfficientTTSCNN(torch.nn.Module):
         O.reconst_alpha(e, tl, ml, float(self.sigma), ralpha, ra_p, B, T1, T2, rs2.Tp)   # :184-186
 
         mel = self._expand_decode(ws, pk, B, T1, rs1, rs2, val_f, ra_p, len2.data_ptr(), gap2)   # :190-200
-        dur = self._duration(ws, pk, rs1, val_p, gap1, len1.data_ptr(), 0)        # :219
+        main.wait_stream(side)                                                     # duration predictor done
 
         out3 = torch.empty(3, dtype=torch.float32, device=dev)                     # :220-227
         O.masked_losses(mel.ptr, self.odim, speech, ml, dur, lde, tl, out3, ws.tensor("loss_ws", (1024,)), B, T1,

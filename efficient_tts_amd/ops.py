@@ -37,6 +37,26 @@ class stream_scope:
         _cached_stream = self.prev
 
 
+class on_stream:
+    """Route the C-ABI launches (and torch's own ops) to `stream` inside a stream_scope."""
+
+    def __init__(self, stream: "torch.cuda.Stream"):
+        self.stream = stream
+
+    def __enter__(self):
+        global _cached_stream
+        self.prev = _cached_stream
+        self.ctx = torch.cuda.stream(self.stream)
+        self.ctx.__enter__()
+        _cached_stream = self.stream.cuda_stream
+        return self
+
+    def __exit__(self, *a):
+        global _cached_stream
+        _cached_stream = self.prev
+        self.ctx.__exit__(*a)
+
+
 def _stream() -> int:
     return _cached_stream if _cached_stream is not None else torch.cuda.current_stream().cuda_stream
 

@@ -90,6 +90,7 @@ class TrainEngine:
         self.wt: Dict[str, PackedWeight] = {}
         self._sig = None
         self.bucket_hook: Optional[Callable[[int], None]] = None
+        self.join_reduce: Optional[Callable[[], None]] = None
 
     def stale(self, model) -> bool:
         """True when the model's parameter set no longer matches the layout captured at construction
