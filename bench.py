@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
-    ap.add_argument("--workload", default="fwd64", choices=["fwd64", "fwd16_long", "train32"])
+    ap.add_argument("--workload", default="fwd64", choices=["fwd64", "fwd16_long", "train32", "infer_lj"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="1 (default): replay the step from a captured hipGraph -- ~75 launches per forward are host-bound in eager mode (3.0 vs 2.6 ms); the roofline events then come from 3 eager steps right after the timed region. 0: eager, events inside the timed region")
     return ap.parse_args()
@@ -97,6 +97,63 @@ def cpu_baseline(T1, T2):
                        f"best of 8/16/32/64 threads ({med:.3f} s/iter at {nt} threads)")
 
 
+def run_infer_lj(a, world, rank, dev):
+    """BASELINE config 1 plumbing on the GPU: free-running inference() of the first 10 LJSpeech test
+    utterances (what nntts/bin/inference.py:97 iterates), one at a time (B = 1, as the reference), plus
+    the same 10 as ONE ragged batch (inference_batch).  RTF = acoustic-model time / audio duration
+    (T2 * 256 / 22050 s); the reference's RTF print also includes the vocoder (inference.py:111)."""
+    import numpy as np
+    from efficient_tts_amd import EfficientTTSCNN
+    from oracle import efts_oracle as O               # weights (deterministic fill) + the CPU baseline leg
+    g = np.load(os.path.join(ROOT, "tests", "golden", "inference_lj.npz"))
+    ids = [torch.from_numpy(g[f"ids{n}"]) for n in range(10)]
+    model = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, sigma=0.01, precision=a.precision)
+    P = O.fill_params()
+    model.load_state_dict(P)
+    model = model.to(dev).eval()
+    model.remove_weight_norm()
+    dids = [x[None].to(dev) for x in ids]
+    T1 = max(len(x) for x in ids)
+    batch = torch.zeros(10, T1, dtype=torch.int64)
+    for n, x in enumerate(ids):
+        batch[n, :len(x)] = x
+    lens = torch.tensor([len(x) for x in ids])
+    batch, lens = batch.to(dev), lens.to(dev)
+    for _ in range(max(a.warmup, 1)):
+        frames = sum(model.inference(x)[0].shape[1] for x in dids)
+        model.inference_batch(batch, lens)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        for x in dids:
+            model.inference(x)
+    torch.cuda.synchronize()
+    dt1 = (time.perf_counter() - t0) / a.steps
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        model.inference_batch(batch, lens)
+    torch.cuda.synchronize()
+    dtb = (time.perf_counter() - t0) / a.steps
+    audio = frames * 256 / 22050.0
+    res = dict(metric="mel-frames/sec (EFTS-CNN free-running inference, 10 LJSpeech test utterances, B=1 each)", value=frames / dt1,
+               unit="mel-frames/s", n_gpus=1, steps=a.steps, warmup=a.warmup, ms_per_step=dt1 * 1e3, higher_is_better=True,
+               scaling="weak", vs_baseline=None, dtype=a.precision, data="LJSpeech test phoneme ids (reference filelist), deterministic weights",
+               config=dict(workload="inference() x 10 utterances, B=1", frames=frames, precision=a.precision),
+               rtf=dt1 / audio, batched=dict(value=frames / dtb, ms=dtb * 1e3, rtf=dtb / audio, note="same 10 utterances as one ragged batch (inference_batch)"))
+    if not a.no_cpu_baseline:
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        with torch.no_grad():
+            for x in ids[:2]:
+                O.inference(P, x[None])
+            t0 = time.perf_counter()
+            for x in ids:
+                O.inference(P, x[None])
+            dc = time.perf_counter() - t0
+        res["cpu_baseline"] = dict(value=frames / dc, unit="mel-frames/s", cores=torch.get_num_threads(), kind="port", rtf=dc / audio,
+                                   sample="oracle inference() fp32 on the same 10 utterances, one pass")
+    print(json.dumps(res), flush=True)
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,6 +169,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from efficient_tts_amd import EfficientTTSCNN, ops as P
+    if a.workload == "infer_lj":
+        return run_infer_lj(a, world, rank, dev)
     wl = WORKLOADS[a.workload]
     B, T1, T2 = wl["B"], wl["T1"], wl["T2"]
     if a.workload == "train32":
@@ -196,7 +255,7 @@ def main():
 
     if rank == 0:
         frames = world * B * T2 * a.steps
-        res = dict(metric="mel-frames/sec (EFTS-CNN forward, batch 64/GPU, 80-mel LJSpeech shape)", value=frames / dt,
+        res = dict(metric=f"mel-frames/sec (EFTS-CNN forward, batch {B}/GPU, 80-mel LJSpeech shape)", value=frames / dt,
                    unit="mel-frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
                    higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype="bf16" if a.precision == "bf16" else "bf16x3 (split-bf16 MFMA, fp32-class)",
