@@ -112,7 +112,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 }
 
 template <int TAPS, int SPLIT, int WM>
-__global__ __launch_bounds__(WM * 128, (WM == 4) ? 2 : 2) void gemm_kernel(GemmKernelArgs p) {
+__global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmKernelArgs p) {
     using C = Cfg<TAPS, WM>;
     constexpr int BM = C::BM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -132,7 +132,8 @@ __global__ __launch_bounds__(WM * 128, (WM == 4) ? 2 : 2) void gemm_kernel(GemmK
     const int nA = (C::A_PIECES - wave + C::NW - 1) / C::NW;     // A window pieces this wave issues
     const int c4 = (tid & 31) << 2;
     constexpr int RPP = C::THREADS / 32;                          // tile rows per epilogue sweep
-    constexpr int NPS = 128 / RPP;                                // sweeps per 128-row half
+    constexpr int HROWS = (WM >= 2) ? 128 : 64;                   // rows staged per epilogue pass
+    constexpr int NPS = HROWS / RPP;                              // sweeps per pass
     const int z2 = blockIdx.z;
     const float* resid = p.resid ? p.resid + (long)z * p.r_bs : nullptr;
     const float* rowmask = p.rowmask ? p.rowmask + (long)z * p.m_bs : nullptr;
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 4) ? 2 : 2) void gemm_kernel(GemmK
     // load, float4 store, and 8-byte bf16 (hi / lo) operand-plane stores.
     float* cs = (float*)smem;   // 64 KiB; the main loop's last barrier has retired all LDS reads
 #pragma unroll
-    for (int half = 0; half < WM / 2; ++half) {
+    for (int half = 0; half < (WM >= 2 ? WM / 2 : 1); ++half) {
         if ((wm >> 1) == half) {
             const float* bias = p.bias;
 #pragma unroll
@@ -792,7 +793,7 @@ static void launch_gemm_p3(dim3 grid, hipStream_t st, const GemmKernelArgs& k) {
 template <int T, int S>
 static void set_lds_attr() {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<T, S, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<T, S, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<T, 4>::LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<T, S, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
@@ -857,11 +858,29 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
         }
     }
     if (big_rows < a->m) {
-        k.m_base = big_rows; k.m_end = a->m;
+        // 128x128 tiles, one workgroup per tile, 2 resident per CU.  If the tile count leaves a
+        // thinly filled last round (e.g. 1604 tiles on 512 slots = 3.13 rounds), the rows of that
+        // partial round go to 64x128 tiles (2-wave workgroups) in a second launch: the tail then costs
+        // about half a round instead of a whole one.  Measured SLOWER (244 vs 231 us: freed slots already let
+        // the last workgroups run alone at full speed), so it is opt-in: EFTS_GEMM_TAIL=1.
+        int main_end = a->m;
+        {
+            const char* e = getenv("EFTS_GEMM_TAIL");
+            const int tail_on = e ? atoi(e) : 0;
+            const long slots = 2L * efts_num_cus();
+            const long mt128 = (a->m - big_rows + 127) / 128;
+            const long tiles = mt128 * k.ntiles;
+            const long full = tiles / slots, rem = tiles - full * slots;
+            if (tail_on && a->batch == 1 && nb2 == 1 && full >= 1 && rem > 0 && rem * 10 <= slots * 6) {
+                const long main_mt = (full * slots) / k.ntiles;
+                main_end = big_rows + (int)(main_mt * 128);
+            }
+        }
+        k.m_base = big_rows; k.m_end = main_end;
         k.mtiles = (k.m_end - k.m_base + 127) / 128;
         const int nt_all = k.mtiles * k.ntiles;
         // one workgroup per tile by default; EFTS_GEMM_PERSIST=1 runs 2 persistent workgroups per CU
-        // instead (measured neutral on MI355X, DESIGN.md section 6)
+        // instead (measured neutral on MI355X, DESIGN.md section 5)
         int cap = nt_all;
         { const char* e = getenv("EFTS_GEMM_PERSIST"); if (e && atoi(e) == 1) cap = 2 * efts_num_cus(); }
         if (a->batch > 1) cap = nt_all;
@@ -873,6 +892,12 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
             else { if (a->taps == 5) launch_gemm_p3<5, 2>(grid, st, k); else launch_gemm_p3<3, 2>(grid, st, k); }
         } else {
             EFTS_LAUNCH_TS(2);
+        }
+        if (main_end < a->m) {
+            k.m_base = main_end; k.m_end = a->m;
+            k.mtiles = (k.m_end - k.m_base + 63) / 64;
+            dim3 grid(k.mtiles * k.ntiles, a->batch, nb2);
+            EFTS_LAUNCH_TS(1);
         }
     }
 #undef EFTS_LAUNCH_TS

@@ -201,3 +201,25 @@ def test_batched_ragged_inference_equals_single_item(golden_dir, model):
         assert float(mel[n, t2:].abs().max()) == 0.0 if mel.shape[1] > t2 else True
         assert float((ralpha[n, :len(s), :t2] - ra1[0]).abs().max()) <= 1e-5
         assert float((mel[n, :t2:2].cpu() - torch.from_numpy(g[f"mel_pred{n}"])[0]).abs().max()) <= MEL_TOL
+
+
+@pytest.mark.parametrize("B,T1,T2,tl,sl", [(1, 9, 33, [9], [33]), (3, 30, 77, [30, 17, 1], [77, 40, 5]),
+                                           (2, 130, 300, [130, 64], [300, 299])])
+def test_odd_shapes_and_ragged_lengths_vs_oracle(model, B, T1, T2, tl, sl):
+    """shapes that are not multiples of any tile (scalar epilogue path, partial K chunks), B = 1, a
+    length-1 text and very short mels, T1 > 128 (two key tiles): forward vs the oracle."""
+    dev = _dev()
+    gen = torch.Generator().manual_seed(B * 1000 + T1 + T2)
+    text = torch.randint(0, 76, (B, T1), generator=gen)
+    mel = (-4.0 + 2.0 * torch.randn(B, T2, 80, generator=gen)).clamp(-11.5, 2.0)
+    tlt, slt = torch.tensor(tl), torch.tensor(sl)
+    for b in range(B):
+        text[b, tl[b]:] = 0
+        mel[b, sl[b]:] = 0
+    with torch.no_grad():
+        loss, stats, imv, ralpha, mel_pred, _ = model(text.to(dev), tlt.to(dev), mel.to(dev), slt.to(dev))
+        o = O.forward(O.fill_params(), text, tlt, mel, slt)
+    assert float((mel_pred.cpu() - o["mel_pred"]).abs().max()) <= MEL_TOL
+    assert float((ralpha.cpu() - o["reconst_alpha"]).abs().max()) <= 1e-3
+    assert float((imv.cpu() - o["imv"]).abs().max()) <= 2e-3
+    assert abs(float(loss) - float(o["loss"])) <= 2e-4 * float(o["loss"])
