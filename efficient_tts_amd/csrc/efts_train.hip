@@ -488,7 +488,7 @@ __global__ void embed_bwd_kernel(const long* __restrict__ ids, const float* __re
 // clip_grad_norm_ + Adam(amsgrad, coupled L2) on flat fp32 buffers
 // (trainer.py:154-158; egs/lj/conf/efficient_tts_cnn_phnseq_noDropout.v1.yaml:34-40)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
     __shared__ float sh[4];
     float s = 0.f;
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
@@ -496,7 +496,16 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
         else for (long k = i; k < n; ++k) s += g[k] * g[k];
     }
     s = block_sum256t(s, sh);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+// second stage: ONE block adds the per-block partials in a fixed order, so data-parallel replicas that
+// hold identical gradients compute bit-identical norms (and stay in lock-step without parameter syncs)
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    s = block_sum256t(s, sh);
+    if (threadIdx.x == 0) out[0] += s;
 }
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, float* __restrict__ vmax, long n,
@@ -638,10 +647,13 @@ extern "C" int efts_embed_bwd(const int64_t* ids, const float* g, float* dtable,
     return efts_check_launch("efts_embed_bwd");
 }
 
-extern "C" int efts_sumsq(const float* g, int64_t n, float* out1, void* stream) {
-    if (!g || !out1 || n <= 0) return efts_fail(EFTS_EINVAL, "efts_sumsq: bad arguments");
+extern "C" size_t efts_sumsq_workspace_bytes(void) { return 1024 * sizeof(float); }
+
+extern "C" int efts_sumsq(const float* g, int64_t n, float* out1, void* workspace, void* stream) {
+    if (!g || !out1 || !workspace || n <= 0) return efts_fail(EFTS_EINVAL, "efts_sumsq: bad arguments");
     if ((uintptr_t)g & 15) return efts_fail(EFTS_EALIGN, "efts_sumsq: buffer must be 16-byte aligned");
-    hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, ST, g, (long)n, out1);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, ST, g, (long)n, (float*)workspace);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, ST, (const float*)workspace, 1024, out1);
     return efts_check_launch("efts_sumsq");
 }
 

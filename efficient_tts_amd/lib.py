@@ -68,7 +68,8 @@ _SIGS = {
     "efts_imv_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "efts_attn_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "efts_embed_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
-    "efts_sumsq": (i32, [vp, i64, vp, vp]),
+    "efts_sumsq_workspace_bytes": (C.c_size_t, []),
+    "efts_sumsq": (i32, [vp, i64, vp, vp, vp]),
     "efts_adam_amsgrad": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
 }
 

@@ -37,6 +37,7 @@ class EftsAdam(torch.optim.Optimizer):
         self.v = torch.zeros_like(eng.flat)
         self.vmax = torch.zeros_like(eng.flat)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.sumsq_ws = torch.zeros(L.load().efts_sumsq_workspace_bytes() // 4, dtype=torch.float32, device=dev)
         self.t = 0
         super().__init__([p for _, p in eng.layout], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
@@ -51,7 +52,7 @@ class EftsAdam(torch.optim.Optimizer):
         lib = L.load()
         if self.grad_norm > 0:
             self.sumsq.zero_()
-            L.check(lib.efts_sumsq(eng.flat.data_ptr(), n, self.sumsq.data_ptr(), st), "efts_sumsq")
+            L.check(lib.efts_sumsq(eng.flat.data_ptr(), n, self.sumsq.data_ptr(), self.sumsq_ws.data_ptr(), st), "efts_sumsq")
         L.check(lib.efts_adam_amsgrad(self.flat_p.data_ptr(), eng.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                       self.vmax.data_ptr(), n, self.sumsq.data_ptr() if self.grad_norm > 0 else None,
                                       self.grad_norm, float(grad_scale), float(grp["lr"]), float(grp["betas"][0]),

@@ -244,9 +244,11 @@ int efts_attn_bwd(const float* scores, int64_t ld, const float* soft_idx, const 
 int efts_embed_bwd(const int64_t* ids, const float* g, float* dtable, int32_t B, int32_t T, int32_t Tp, int32_t c,
                    int32_t num_symbols, void* stream);
 /* clip_grad_norm_ + torch.optim.Adam(amsgrad=True, coupled weight decay) on flat fp32 buffers
- * (trainer.py:154-158; YAML :34-40).  efts_sumsq ACCUMULATES sum(g^2) into *out1 (zero it first);
+ * (trainer.py:154-158; YAML :34-40).  efts_sumsq ACCUMULATES sum(g^2) into *out1 (zero it first) with a
+ * deterministic two-stage reduction (workspace >= efts_sumsq_workspace_bytes());
  * efts_adam_amsgrad scales g by gscale * min(1, max_norm / (gscale*sqrt(sumsq) + 1e-6)). */
-int efts_sumsq(const float* g, int64_t n, float* out1, void* stream);
+size_t efts_sumsq_workspace_bytes(void);
+int efts_sumsq(const float* g, int64_t n, float* out1, void* workspace, void* stream);
 int efts_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, const float* sumsq,
                       float max_norm, float gscale, float lr, float beta1, float beta2, float eps, float weight_decay,
                       int32_t step, void* stream);
