@@ -575,6 +575,215 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v3(GemmKernelArgs p) {
 
 
 // =============================================================================================
+// gemm_kernel_v4: 128x128 tile, 4 waves of 64x64, 64-byte LDS rows, 3-stage ring, 42 KiB LDS -> THREE workgroups
+// per CU (occupancy experiment); derived from gemm_kernel_v3 below:
+// gemm_kernel_v3: 256x128 tile, 4 waves of 128x64 (8 accumulator blocks, 128 VGPR), 64-byte LDS rows
+// (32 bf16 / 16 hi + 16 lo per step), 4-stage weight ring with COUNTED vmcnt so LDS-DMA stays in
+// flight across three steps, still 2 workgroups per CU (66 KiB LDS each).  Per FLOP it moves 0.59x
+// the DMA bytes (the weight tile is amortised over 256 rows) and issues 0.75x the ds_read_b128 of
+// the 128x128 kernel.  A 128-byte global chunk is consumed as two 64-byte half-chunks.
+// =============================================================================================
+
+
+template <int TAPS, int SPLIT>
+__global__ __launch_bounds__(256, 3) void gemm_kernel_v4(GemmKernelArgs p) {
+    constexpr int A_PIECES = 128 / 16 + (TAPS == 1 ? 0 : 1);       // 8 or 9 pieces of 16 rows
+    constexpr int V4_NST = 3;
+    constexpr int A_BYTES = A_PIECES * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#define V4_ABUF(i) (smem + ((i) & 1) * A_BYTES)
+#define V4_WBUF(i) (smem + 2 * A_BYTES + ((i) % V4_NST) * V3_W_BYTES)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int z = blockIdx.y, z2 = blockIdx.z;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int nhc = p.nchunk * 2;                      // half-chunks
+    const int nsteps = nhc * TAPS;
+    const int nA = (A_PIECES - wave + 3) / 4;
+
+    const int ntot = p.mtiles * p.ntiles;
+    int bid = blockIdx.x;
+    {
+        const int q = ntot >> 3, r = ntot & 7;
+        const int xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = bid / p.ntiles, nt = bid - mt * p.ntiles;
+    const int m0 = p.m_base + mt * 128, n0 = nt * BN;
+    const char* A = p.a + (long)z * p.a_bs + (long)z2 * p.a_bs2;
+    const char* Bw = p.b + (long)z * p.b_bs + (long)z2 * p.b_bs2;
+    const int a_first = m0 - p.pad;
+    const int b_max = p.n - 1 - n0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto issue_w = [&](int sn) {
+        const int hc = sn / TAPS, kn = sn - hc * TAPS;
+        const char* wb = Bw + (long)kn * p.b_tap_stride + (long)n0 * p.ldb + (long)(hc >> 1) * 128;
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) dma_piece64<SPLIT>(wb, p.ldb, 0, b_max, wave * 2 + pc, lane, hc & 1, V4_WBUF(sn));
+    };
+    auto issue_a = [&](int hc) {
+        const char* ab = A + (long)(hc >> 1) * 128;
+        for (int pc = wave; pc < A_PIECES; pc += 4) dma_piece64<SPLIT>(ab, p.lda, a_first, 0x7fffffff, pc, lane, hc & 1, V4_ABUF(hc));
+    };
+
+    // prologue: window 0, weights of steps 0..2; wait for window 0 + W(0)
+    issue_a(0);
+    issue_w(0);
+    int pro = 0;
+    if (nsteps > 1) { issue_w(1); pro += 2; }
+    wait_vmcnt(pro);
+    __builtin_amdgcn_s_barrier();
+
+    int s = 0;
+    for (int hc = 0; hc < nhc; ++hc) {
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k, ++s) {
+            const bool do_w = (s + 2 < nsteps);
+            const bool do_a = (k == 0) && (hc + 1 < nhc);
+            if (TAPS == 1 && do_a) issue_a(hc + 1);
+            if (do_w) issue_w(s + 2);
+            if (TAPS != 1 && do_a) issue_a(hc + 1);
+
+            const char* at = V4_ABUF(hc);
+            const char* wt = V4_WBUF(s);
+            const int arow = wm * 64 + lrow + k;
+            const int brow = wn * 64 + lrow;
+            if constexpr (SPLIT == 1) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int slot = kk * 2 + lhalf;
+                    bf16x8 af[2], bfr[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bfr[j] = *(const bf16x8*)(wt + lds_off64(brow + j * 32, slot));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8*)(at + lds_off64(arow + i * 32, slot));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
+            } else {
+                bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bh[j] = *(const bf16x8*)(wt + lds_off64(brow + j * 32, lhalf));
+                    bl[j] = *(const bf16x8*)(wt + lds_off64(brow + j * 32, 2 + lhalf));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ah[i] = *(const bf16x8*)(at + lds_off64(arow + i * 32, lhalf));
+                    al[i] = *(const bf16x8*)(at + lds_off64(arow + i * 32, 2 + lhalf));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            // Counted wait.  DMAs retire in issue order; after this step the weights of step s+1 (and
+            // for taps 1 the next window) must have landed, while the weights of s+2 / s+3 and a
+            // window issued this or the previous step stay in flight across the barrier.
+            int n = 0;
+            if (TAPS == 1) {
+                n = do_w ? 2 : 0;
+            } else {
+                if (do_w) n += 2;
+                if (do_a) n += nA;
+                if (k == 1 && hc + 1 < nhc) n += nA;
+            }
+            wait_vmcnt(n);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue: two 64-row halves through a [64][128] fp32 LDS tile (wave row wm owns half wm)
+    float* cs = (float*)smem;
+    const float* resid = p.resid ? p.resid + (long)z * p.r_bs : nullptr;
+    const float* rowmask = p.rowmask ? p.rowmask + (long)z * p.m_bs : nullptr;
+    float* of = p.out_f32 ? p.out_f32 + (long)z * p.o_bs + (long)z2 * p.o_bs2 : nullptr;
+    char* ob = p.out_bf16 ? p.out_bf16 + (long)z * p.ob_bs : nullptr;
+    const int c4 = (tid & 31) << 2;
+    const int col = n0 + c4;
+    const bool vec = p.vec_ok && (col + 3 < p.n);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (wm == half) {
+            const float* bias = p.bias;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cl = wn * 64 + j * 32 + lrow;
+                const float bv = (bias && n0 + cl < p.n) ? bias[n0 + cl] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                        float v = acc[i][j][r] * p.alpha + bv;
+                        if (p.act == EFTS_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                        else if (p.act == EFTS_ACT_RELU) v = v > 0.f ? v : 0.f;
+                        cs[rl * 128 + cl] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (col < p.n && !(p.dbg & 1)) {
+#pragma unroll 4
+            for (int ps = 0; ps < 8; ++ps) {
+                const int rl = ps * 8 + (tid >> 5);
+                const int row = m0 + half * 64 + rl;
+                if (row >= p.m_end) break;
+                float4 v = *(const float4*)(cs + rl * 128 + c4);
+                const float rm = rowmask ? rowmask[row] : 1.f;
+                if (vec) {
+                    if (resid) {
+                        const float4 x = *(const float4*)(resid + (long)row * p.ldr + col);
+                        v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                    }
+                    v.x *= rm; v.y *= rm; v.z *= rm; v.w *= rm;
+                    if (of) *(float4*)(of + (long)row * p.ldo + col) = v;
+                    if (ob) plane_store4(ob + (long)row * p.ldob, col, v.x, v.y, v.z, v.w, p.out_split);
+                } else {
+                    float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (col + u >= p.n) break;
+                        float t = vv[u];
+                        if (resid) t += resid[(long)row * p.ldr + col + u];
+                        t *= rm;
+                        if (of) of[(long)row * p.ldo + col + u] = t;
+                        if (ob) {
+                            const unsigned short hi = f32_to_bf16(t);
+                            char* d = ob + (long)row * p.ldob + plane_off_hi(col + u, p.out_split);
+                            *(unsigned short*)d = hi;
+                            if (p.out_split == 2) *(unsigned short*)(d + 64) = f32_to_bf16(t - bf16_to_f32(hi));
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+
+// =============================================================================================
 // gemm_kernel_p3: the 128x128 / 4-wave / 128-byte-row kernel with a 3-stage weight ring and COUNTED
 // vmcnt (weights are prefetched two steps ahead and stay in flight across the step barrier), paid for
 // by single-buffering the A window (17 KiB + 3 x 16 KiB = 65 KiB -> still 2 workgroups per CU).  The
@@ -784,6 +993,11 @@ static void launch_gemm_v3(dim3 grid, hipStream_t st, const GemmKernelArgs& k) {
     hipLaunchKernelGGL((gemm_kernel_v3<T, S>), grid, dim3(256), lds, st, k);
 }
 template <int T, int S>
+static void launch_gemm_v4(dim3 grid, hipStream_t st, const GemmKernelArgs& k) {
+    constexpr int lds = 2 * (128 / 16 + (T == 1 ? 0 : 1)) * 1024 + 3 * V3_W_BYTES;
+    hipLaunchKernelGGL((gemm_kernel_v4<T, S>), grid, dim3(256), lds, st, k);
+}
+template <int T, int S>
 static void launch_gemm_p3(dim3 grid, hipStream_t st, const GemmKernelArgs& k) {
     constexpr int lds = 17 * 1024 + 3 * W_BYTES;
     static bool attr = false;
@@ -885,9 +1099,13 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
         { const char* e = getenv("EFTS_GEMM_PERSIST"); if (e && atoi(e) == 1) cap = 2 * efts_num_cus(); }
         if (a->batch > 1) cap = nt_all;
         dim3 grid(nt_all < cap ? nt_all : cap, a->batch, nb2);
-        int p3 = 0;
+        int p3 = 0, v4 = 0;
         { const char* e = getenv("EFTS_GEMM_P3"); p3 = e ? atoi(e) : 0; }
-        if (p3 && a->taps > 1 && cap == nt_all) {
+        { const char* e = getenv("EFTS_GEMM_V4"); v4 = e ? atoi(e) : 0; }
+        if (v4 && cap == nt_all) {
+            if (a->split == 1) { if (a->taps == 5) launch_gemm_v4<5, 1>(grid, st, k); else if (a->taps == 3) launch_gemm_v4<3, 1>(grid, st, k); else launch_gemm_v4<1, 1>(grid, st, k); }
+            else { if (a->taps == 5) launch_gemm_v4<5, 2>(grid, st, k); else if (a->taps == 3) launch_gemm_v4<3, 2>(grid, st, k); else launch_gemm_v4<1, 2>(grid, st, k); }
+        } else if (p3 && a->taps > 1 && cap == nt_all) {
             if (a->split == 1) { if (a->taps == 5) launch_gemm_p3<5, 1>(grid, st, k); else launch_gemm_p3<3, 1>(grid, st, k); }
             else { if (a->taps == 5) launch_gemm_p3<5, 2>(grid, st, k); else launch_gemm_p3<3, 2>(grid, st, k); }
         } else {
