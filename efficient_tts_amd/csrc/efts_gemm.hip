@@ -975,6 +975,195 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_p3(GemmKernelArgs p) {
     }
 }
 
+
+// =============================================================================================
+// gemm_kernel_w4: "wave-private weights".  128x128 tile, 4 waves, but each wave owns a 128x32 column
+// slab (4 accumulator blocks) and streams ITS OWN 32 weight rows (4 KiB per step) into a private
+// 2-slot LDS ring, waiting only on its own counted vmcnt.  The shared A window is still loaded
+// cooperatively, so the workgroup needs ONE s_barrier per K-chunk (8 per tile) instead of one per
+// step (40 per tile): between chunk boundaries the four waves run free and drift apart, which
+// overlaps one wave's DMA wait with another's MFMAs inside the workgroup.  Same 66 KiB LDS -> 2
+// workgroups per CU.  Costs 1.25 ds_read_b128 per MFMA instead of 1.0.
+// =============================================================================================
+template <int TAPS, int SPLIT>
+__global__ __launch_bounds__(256, 2) void gemm_kernel_w4(GemmKernelArgs p) {
+    constexpr int A_PIECES = 16 + (TAPS == 1 ? 0 : 1);
+    constexpr int A_BYTES = A_PIECES * 1024;
+    constexpr int WP_BYTES = 32 * 128;                  // one private weight slot: 32 rows x 128 B
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#define W4_ABUF(i) (smem + ((i) & 1) * A_BYTES)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* const wring = smem + 2 * A_BYTES + wave * (2 * WP_BYTES);
+    const int z = blockIdx.y, z2 = blockIdx.z;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int nsteps = p.nchunk * TAPS;
+    const int nA = (A_PIECES - wave + 3) / 4;
+
+    const int ntot = p.mtiles * p.ntiles;
+    int bid = blockIdx.x;
+    {
+        const int q = ntot >> 3, r = ntot & 7;
+        const int xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = bid / p.ntiles, nt = bid - mt * p.ntiles;
+    const int m0 = p.m_base + mt * 128, n0 = nt * BN;
+    const char* A = p.a + (long)z * p.a_bs + (long)z2 * p.a_bs2;
+    const char* Bw = p.b + (long)z * p.b_bs + (long)z2 * p.b_bs2;
+    const int a_first = m0 - p.pad;
+    const int b_last = p.n - 1 - n0;                    // last valid weight row of this n-tile (>= 0)
+    const int wrow0 = min(wave * 32, b_last);           // this wave's first weight row (clamped into range)
+    const int wmax = b_last - wrow0;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    auto issue_w = [&](int sn) {                        // this wave's 32 weight rows of step sn -> private slot sn & 1
+        const int cn = sn / TAPS, kn = sn - cn * TAPS;
+        const char* wb = Bw + (long)kn * p.b_tap_stride + (long)(n0 + wrow0) * p.ldb + (long)cn * 128;
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) dma_piece(wb, p.ldb, 0, wmax, pc, lane, wring + (sn & 1) * WP_BYTES);
+    };
+    auto issue_a = [&](int cn) {
+        const char* ab = A + (long)cn * 128;
+        for (int pc = wave; pc < A_PIECES; pc += 4) dma_piece(ab, p.lda, a_first, 0x7fffffff, pc, lane, W4_ABUF(cn));
+    };
+
+    issue_a(0);
+    issue_w(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int s = 0;
+    bool a_prev = false;                                // a window was issued in the previous step
+    for (int c = 0; c < p.nchunk; ++c) {
+        if (c > 0) {
+            // chunk boundary: every wave has finished reading window c-1 and its pieces of window c
+            // landed two steps ago (counted waits below) -> one barrier publishes window c
+            __builtin_amdgcn_s_barrier();
+        }
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k, ++s) {
+            const bool do_w = (s + 1 < nsteps);
+            const bool do_a = (k == 0) && (c + 1 < p.nchunk);
+            if (TAPS == 1 && do_a) issue_a(c + 1);       // taps 1: the next window is needed at the very next
+            if (do_w) issue_w(s + 1);                     //         barrier, so it goes first and is waited for
+            if (TAPS != 1 && do_a) issue_a(c + 1);
+            // own weights of step s must have landed; younger DMAs stay in flight
+            {
+                int n = do_w ? 4 : 0;
+                if (TAPS != 1) n += (do_a ? nA : 0) + (a_prev ? nA : 0);
+                wait_vmcnt(n);
+            }
+            a_prev = do_a;
+            const char* at = W4_ABUF(c);
+            const char* wt = wring + (s & 1) * WP_BYTES;
+            const int arow = lrow + k;
+            if constexpr (SPLIT == 1) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int slot = kk * 2 + lhalf;
+                    const bf16x8 bfr = *(const bf16x8*)(wt + lds_off(lrow, slot));
+                    bf16x8 af[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(at + lds_off(arow + i * 32, slot));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr, acc[i], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int slot = kk * 2 + lhalf;
+                    const bf16x8 bh = *(const bf16x8*)(wt + lds_off(lrow, slot));
+                    const bf16x8 bl = *(const bf16x8*)(wt + lds_off(lrow, slot + 4));
+                    bf16x8 ah[4], al[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        ah[i] = *(const bf16x8*)(at + lds_off(arow + i * 32, slot));
+                        al[i] = *(const bf16x8*)(at + lds_off(arow + i * 32, slot + 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+            // the private slot read in this step is overwritten by the DMA issued at the top of step
+            // s+1 by THIS wave: its ds_reads have retired (their data fed the MFMAs above)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    float* cs = (float*)smem;
+    const float* resid = p.resid ? p.resid + (long)z * p.r_bs : nullptr;
+    const float* rowmask = p.rowmask ? p.rowmask + (long)z * p.m_bs : nullptr;
+    float* of = p.out_f32 ? p.out_f32 + (long)z * p.o_bs + (long)z2 * p.o_bs2 : nullptr;
+    char* ob = p.out_bf16 ? p.out_bf16 + (long)z * p.ob_bs : nullptr;
+    const int c4 = (tid & 31) << 2;
+    const int col = n0 + c4;
+    const bool vec = p.vec_ok && (col + 3 < p.n);
+    {
+        const int cl = wave * 32 + lrow;
+        const float bv = (p.bias && n0 + cl < p.n) ? p.bias[n0 + cl] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                float v = acc[i][r] * p.alpha + bv;
+                if (p.act == EFTS_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                else if (p.act == EFTS_ACT_RELU) v = v > 0.f ? v : 0.f;
+                cs[rl * 128 + cl] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (col < p.n && !(p.dbg & 1)) {
+#pragma unroll 4
+        for (int ps = 0; ps < 16; ++ps) {
+            const int rl = ps * 8 + (tid >> 5);
+            const int row = m0 + rl;
+            if (row >= p.m_end) break;
+            float4 v = *(const float4*)(cs + rl * 128 + c4);
+            const float rm = rowmask ? rowmask[row] : 1.f;
+            if (vec) {
+                if (resid) {
+                    const float4 x = *(const float4*)(resid + (long)row * p.ldr + col);
+                    v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                }
+                v.x *= rm; v.y *= rm; v.z *= rm; v.w *= rm;
+                if (of) *(float4*)(of + (long)row * p.ldo + col) = v;
+                if (ob) plane_store4(ob + (long)row * p.ldob, col, v.x, v.y, v.z, v.w, p.out_split);
+            } else {
+                float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (col + u >= p.n) break;
+                    float t = vv[u];
+                    if (resid) t += resid[(long)row * p.ldr + col + u];
+                    t *= rm;
+                    if (of) of[(long)row * p.ldo + col + u] = t;
+                    if (ob) {
+                        const unsigned short hi = f32_to_bf16(t);
+                        char* d = ob + (long)row * p.ldob + plane_off_hi(col + u, p.out_split);
+                        *(unsigned short*)d = hi;
+                        if (p.out_split == 2) *(unsigned short*)(d + 64) = f32_to_bf16(t - bf16_to_f32(hi));
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace efts
 
 using namespace efts;
@@ -996,6 +1185,13 @@ template <int T, int S>
 static void launch_gemm_v4(dim3 grid, hipStream_t st, const GemmKernelArgs& k) {
     constexpr int lds = 2 * (128 / 16 + (T == 1 ? 0 : 1)) * 1024 + 3 * V3_W_BYTES;
     hipLaunchKernelGGL((gemm_kernel_v4<T, S>), grid, dim3(256), lds, st, k);
+}
+template <int T, int S>
+static void launch_gemm_w4(dim3 grid, hipStream_t st, const GemmKernelArgs& k) {
+    constexpr int lds = 2 * (16 + (T == 1 ? 0 : 1)) * 1024 + 4 * 2 * 4096;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_kernel_w4<T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL((gemm_kernel_w4<T, S>), grid, dim3(256), lds, st, k);
 }
 template <int T, int S>
 static void launch_gemm_p3(dim3 grid, hipStream_t st, const GemmKernelArgs& k) {
@@ -1102,7 +1298,12 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
         int p3 = 0, v4 = 0;
         { const char* e = getenv("EFTS_GEMM_P3"); p3 = e ? atoi(e) : 0; }
         { const char* e = getenv("EFTS_GEMM_V4"); v4 = e ? atoi(e) : 0; }
-        if (v4 && cap == nt_all) {
+        int w4 = 0;
+        { const char* e = getenv("EFTS_GEMM_W4"); w4 = e ? atoi(e) : 0; }
+        if (w4 && cap == nt_all) {
+            if (a->split == 1) { if (a->taps == 5) launch_gemm_w4<5, 1>(grid, st, k); else if (a->taps == 3) launch_gemm_w4<3, 1>(grid, st, k); else launch_gemm_w4<1, 1>(grid, st, k); }
+            else { if (a->taps == 5) launch_gemm_w4<5, 2>(grid, st, k); else if (a->taps == 3) launch_gemm_w4<3, 2>(grid, st, k); else launch_gemm_w4<1, 2>(grid, st, k); }
+        } else if (v4 && cap == nt_all) {
             if (a->split == 1) { if (a->taps == 5) launch_gemm_v4<5, 1>(grid, st, k); else if (a->taps == 3) launch_gemm_v4<3, 1>(grid, st, k); else launch_gemm_v4<1, 1>(grid, st, k); }
             else { if (a->taps == 5) launch_gemm_v4<5, 2>(grid, st, k); else if (a->taps == 3) launch_gemm_v4<3, 2>(grid, st, k); else launch_gemm_v4<1, 2>(grid, st, k); }
         } else if (p3 && a->taps > 1 && cap == nt_all) {
