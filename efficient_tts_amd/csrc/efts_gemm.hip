@@ -60,6 +60,7 @@ struct GemmKernelArgs {
     float alpha, slope;
     int act, out_split;
     int vec_ok;   // all fp32 row strides / pointers allow float4 access
+    int spread;   // EFTS_GEMM_SPREAD: spread the A-window DMA over the tap steps with counted waits
     int stagger;  // persistent mode: cycles the second half of the grid idles before its first tile
     int dbg;   // ablation switches (EFTS_GEMM_DBG): 1 = skip epilogue stores, 2 = no DMA in loop, 4 = no MFMA
 };
@@ -207,9 +208,23 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmKernelArgs p) {
             // ---- stage operands NST-1 steps ahead (they land while this and the next step compute)
             const bool do_w = (s + C::NST - 1 < nsteps) && !(p.dbg & 2);
             const bool do_a = (k == 0) && (c + 1 < p.nchunk) && !(p.dbg & 2);
+            // spread mode (2-stage ring, taps > 1): the next window is issued in TAPS-1 small groups, one
+            // per tap step, AFTER that step's weight tile, and the step barrier uses a counted vmcnt that
+            // lets the group just issued stay in flight: no 17-piece burst and two steps of latency budget
+            // per window piece instead of a vmcnt(0) in the step that issued it.
+            const bool spread = p.spread && TAPS > 1 && C::NST == 2;
+            int n_inflight = 0;
             if (TAPS == 1 && do_a) issue_a(c + 1);          // taps 1: the window changes every step
             if (do_w) issue_w(s + C::NST - 1);
-            if (TAPS != 1 && do_a) issue_a(c + 1);
+            if (spread) {
+                if (c + 1 < p.nchunk && k < TAPS - 1) {
+                    const char* ab = A + (long)(c + 1) * 128;
+                    for (int pc = k * C::NW + wave; pc < C::A_PIECES; pc += C::NW * (TAPS - 1)) {
+                        dma_piece(ab, p.lda, a_first, a_max, pc, lane, EFTS_ABUF(c + 1));
+                        ++n_inflight;
+                    }
+                }
+            } else if (TAPS != 1 && do_a) issue_a(c + 1);
             // ---- MFMAs of this (chunk, tap)
             const char* at = EFTS_ABUF(c);
             const char* wt = EFTS_WBUF(s);
@@ -267,6 +282,9 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmKernelArgs p) {
                     if (k == 1 && c + 1 < p.nchunk && !(p.dbg & 2)) n += nA;   // window issued one step ago
                 }
                 wait_vmcnt(n);
+                __builtin_amdgcn_s_barrier();
+            } else if (spread) {
+                wait_vmcnt(n_inflight);
                 __builtin_amdgcn_s_barrier();
             } else {
                 __syncthreads();   // next operands landed (vmcnt(0)) and this step's reads are done
@@ -1238,6 +1256,7 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
                (!a->out_bf16 || ((a->ldob & 7) == 0 && ((uintptr_t)a->out_bf16 & 7) == 0 && (a->outb_batch_stride & 7) == 0));
     { const char* e = getenv("EFTS_GEMM_DBG"); k.dbg = e ? atoi(e) : 0; }
     { const char* e = getenv("EFTS_GEMM_STAGGER"); k.stagger = e ? atoi(e) : 0; }
+    { const char* e = getenv("EFTS_GEMM_SPREAD"); k.spread = e ? atoi(e) : 0; }
     hipStream_t st = (hipStream_t)stream;
 
     // Tile plan.  Default: the 128x128 / 2-stage kernel everywhere.  EFTS_GEMM_TILE=256 routes
