@@ -1182,6 +1182,192 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_w4(GemmKernelArgs p) {
     }
 }
 
+
+// =============================================================================================
+// gemm_kernel_t256: 256x128 tile, 4 waves of 128x64 (acc[4][2]), full 128-byte LDS rows, SINGLE A window
+// (33 KiB) + 2-stage weight ring (2 x 16 KiB) = 65 KiB -> 2 workgroups per CU.  Per FLOP it issues
+// 0.57x the LDS-DMA pieces of the 128x128 kernel (weights amortised over 256 rows) as FULL cache
+// lines, which is what the round-1 ablations point at: every 128-row variant saturates at the same
+// main-loop time, i.e. at the CU's LDS-DMA throughput.  The window of the next chunk is loaded at the
+// chunk boundary (exposed once per 5 steps, covered by the co-resident workgroup).  taps > 1 only.
+// =============================================================================================
+template <int TAPS, int SPLIT>
+__global__ __launch_bounds__(256, 2) void gemm_kernel_t256(GemmKernelArgs p) {
+    constexpr int A_PIECES = 33, A_BYTES = A_PIECES * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#define T256_WBUF(i) (smem + A_BYTES + ((i) & 1) * W_BYTES)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int z = blockIdx.y, z2 = blockIdx.z;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int nsteps = p.nchunk * TAPS;
+
+    const int ntot = p.mtiles * p.ntiles;
+    int bid = blockIdx.x;
+    {
+        const int q = ntot >> 3, r = ntot & 7;
+        const int xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = bid / p.ntiles, nt = bid - mt * p.ntiles;
+    const int m0 = p.m_base + mt * 256, n0 = nt * BN;
+    const char* A = p.a + (long)z * p.a_bs + (long)z2 * p.a_bs2;
+    const char* Bw = p.b + (long)z * p.b_bs + (long)z2 * p.b_bs2;
+    const int a_first = m0 - p.pad;
+    const int b_max = p.n - 1 - n0;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto issue_w = [&](int sn) {
+        const int cn = sn / TAPS, kn = sn - cn * TAPS;
+        const char* wb = Bw + (long)kn * p.b_tap_stride + (long)n0 * p.ldb + (long)cn * 128;
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) dma_piece(wb, p.ldb, 0, b_max, wave * 4 + pc, lane, T256_WBUF(sn));
+    };
+    auto issue_a = [&](int cn) {
+        const char* ab = A + (long)cn * 128;
+        for (int pc = wave; pc < A_PIECES; pc += 4) dma_piece(ab, p.lda, a_first, 0x7fffffff, pc, lane, smem);
+    };
+
+    issue_a(0);
+    issue_w(0);
+    __syncthreads();
+
+    int s = 0;
+    for (int c = 0; c < p.nchunk; ++c) {
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k, ++s) {
+            if (k == 0 && c > 0) {
+                issue_a(c);                       // previous step's barrier retired every read of window c-1
+                if (s + 1 < nsteps) issue_w(s + 1);
+                __syncthreads();
+            } else if (s + 1 < nsteps) {
+                issue_w(s + 1);
+            }
+            const char* at = smem;
+            const char* wt = T256_WBUF(s);
+            const int arow = wm * 128 + lrow + k;
+            const int brow = wn * 64 + lrow;
+            if constexpr (SPLIT == 1) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int slot = kk * 2 + lhalf;
+                    bf16x8 af[4], bfr[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bfr[j] = *(const bf16x8*)(wt + lds_off(brow + j * 32, slot));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(at + lds_off(arow + i * 32, slot));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int slot = kk * 2 + lhalf;
+                    bf16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        bh[j] = *(const bf16x8*)(wt + lds_off(brow + j * 32, slot));
+                        bl[j] = *(const bf16x8*)(wt + lds_off(brow + j * 32, slot + 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        ah[i] = *(const bf16x8*)(at + lds_off(arow + i * 32, slot));
+                        al[i] = *(const bf16x8*)(at + lds_off(arow + i * 32, slot + 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    float* cs = (float*)smem;
+    const float* resid = p.resid ? p.resid + (long)z * p.r_bs : nullptr;
+    const float* rowmask = p.rowmask ? p.rowmask + (long)z * p.m_bs : nullptr;
+    float* of = p.out_f32 ? p.out_f32 + (long)z * p.o_bs + (long)z2 * p.o_bs2 : nullptr;
+    char* ob = p.out_bf16 ? p.out_bf16 + (long)z * p.ob_bs : nullptr;
+    const int c4 = (tid & 31) << 2;
+    const int col = n0 + c4;
+    const bool vec = p.vec_ok && (col + 3 < p.n);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (wm == half) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cl = wn * 64 + j * 32 + lrow;
+                const float bv = (p.bias && n0 + cl < p.n) ? p.bias[n0 + cl] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                        float v = acc[i][j][r] * p.alpha + bv;
+                        if (p.act == EFTS_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                        else if (p.act == EFTS_ACT_RELU) v = v > 0.f ? v : 0.f;
+                        cs[rl * 128 + cl] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (col < p.n && !(p.dbg & 1)) {
+#pragma unroll 4
+            for (int ps = 0; ps < 16; ++ps) {
+                const int rl = ps * 8 + (tid >> 5);
+                const int row = m0 + half * 128 + rl;
+                if (row >= p.m_end) break;
+                float4 v = *(const float4*)(cs + rl * 128 + c4);
+                const float rm = rowmask ? rowmask[row] : 1.f;
+                if (vec) {
+                    if (resid) {
+                        const float4 x = *(const float4*)(resid + (long)row * p.ldr + col);
+                        v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                    }
+                    v.x *= rm; v.y *= rm; v.z *= rm; v.w *= rm;
+                    if (of) *(float4*)(of + (long)row * p.ldo + col) = v;
+                    if (ob) plane_store4(ob + (long)row * p.ldob, col, v.x, v.y, v.z, v.w, p.out_split);
+                } else {
+                    float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (col + u >= p.n) break;
+                        float t = vv[u];
+                        if (resid) t += resid[(long)row * p.ldr + col + u];
+                        t *= rm;
+                        if (of) of[(long)row * p.ldo + col + u] = t;
+                        if (ob) {
+                            const unsigned short hi = f32_to_bf16(t);
+                            char* d = ob + (long)row * p.ldob + plane_off_hi(col + u, p.out_split);
+                            *(unsigned short*)d = hi;
+                            if (p.out_split == 2) *(unsigned short*)(d + 64) = f32_to_bf16(t - bf16_to_f32(hi));
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace efts
 
 using namespace efts;
@@ -1203,6 +1389,13 @@ template <int T, int S>
 static void launch_gemm_v4(dim3 grid, hipStream_t st, const GemmKernelArgs& k) {
     constexpr int lds = 2 * (128 / 16 + (T == 1 ? 0 : 1)) * 1024 + 3 * V3_W_BYTES;
     hipLaunchKernelGGL((gemm_kernel_v4<T, S>), grid, dim3(256), lds, st, k);
+}
+template <int T, int S>
+static void launch_gemm_t256(dim3 grid, hipStream_t st, const GemmKernelArgs& k) {
+    constexpr int lds = 33 * 1024 + 2 * W_BYTES;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_kernel_t256<T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL((gemm_kernel_t256<T, S>), grid, dim3(256), lds, st, k);
 }
 template <int T, int S>
 static void launch_gemm_w4(dim3 grid, hipStream_t st, const GemmKernelArgs& k) {
@@ -1263,10 +1456,11 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     // non-batched launches to gemm_kernel_v3 (256x128 tile, 64-byte LDS rows, 4-stage ring, counted
     // vmcnt): correct, and measured 5-8 % SLOWER on MI355X this round, kept for
     // the next round's work on the staging path.
-    int big_rows = 0;
+    int big_rows = 0, t256 = 0;
     {
         const char* e = getenv("EFTS_GEMM_TILE");
-        if (e && atoi(e) == 256 && a->batch == 1 && nb2 == 1) big_rows = a->m;
+        if (e && (atoi(e) == 256 || (atoi(e) == 2560 && a->taps > 1)) && a->batch == 1 && nb2 == 1) big_rows = a->m;
+        t256 = e && atoi(e) == 2560;
     }
 #define EFTS_LAUNCH_TS(W)                                                                                   \
     do {                                                                                                    \
@@ -1280,7 +1474,10 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
         k.m_base = 0; k.m_end = big_rows < a->m ? big_rows : a->m;
         k.mtiles = (k.m_end - k.m_base + 255) / 256;
         dim3 grid(k.mtiles * k.ntiles, a->batch, nb2);
-        if (a->split == 1) {
+        if (t256) {
+            if (a->split == 1) { if (a->taps == 5) launch_gemm_t256<5, 1>(grid, st, k); else launch_gemm_t256<3, 1>(grid, st, k); }
+            else { if (a->taps == 5) launch_gemm_t256<5, 2>(grid, st, k); else launch_gemm_t256<3, 2>(grid, st, k); }
+        } else if (a->split == 1) {
             if (a->taps == 5) launch_gemm_v3<5, 1>(grid, st, k); else if (a->taps == 3) launch_gemm_v3<3, 1>(grid, st, k); else launch_gemm_v3<1, 1>(grid, st, k);
         } else {
             if (a->taps == 5) launch_gemm_v3<5, 2>(grid, st, k); else if (a->taps == 3) launch_gemm_v3<3, 2>(grid, st, k); else launch_gemm_v3<1, 2>(grid, st, k);

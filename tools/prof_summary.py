@@ -25,9 +25,10 @@ if con:
         print(f"{short(r[0]):72s} {r[1]:6d} {r[2]:14.1f} {r[3]:10.2f} {r[4]:6.2f}")
     print("\n## kernel-trace: efts kernels by grid size (name, grid, calls, avg duration us)")
     try:
-        for r in con.execute("select name, grid_size, count(*), avg(end - start) / 1000.0 from kernels "
-                             "where name like '%efts::%' group by name, grid_size order by 4 * count(*) desc limit 24"):
-            print(f"{short(r[0]):72s} grid={r[1]:9d} n={r[2]:4d} avg={r[3]:9.2f} us")
+        for r in con.execute("select name, grid_x * grid_y * grid_z, count(*), avg(duration) / 1000.0, sum(duration) / 1000.0, "
+                             "max(vgpr_count), max(lds_size) from kernels where name like '%efts::%' "
+                             "group by name, grid_x, grid_y, grid_z order by 5 desc limit 24"):
+            print(f"{short(r[0]):60s} grid={r[1]:9d} n={r[2]:4d} avg={r[3]:9.2f} us total={r[4]:10.1f} us vgpr={r[5]} lds={r[6]}")
     except Exception as e:
         print("(kernels view unavailable:", e, ")")
 for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_l2"):
