@@ -25,4 +25,4 @@ def time_layer(split, B=64, T=int(os.environ.get("PT","800")), C=512, iters=20):
     ms = e0.elapsed_time(e1) / iters
     fl = 2.0 * B * T * C * C * 5
     print(f"dbg={os.environ.get('EFTS_GEMM_DBG','0')} split={split}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TF", flush=True)
-for s in (1, 2): time_layer(s)
+for s in [int(v) for v in os.environ.get("PSPLIT","1,2").split(",")]: time_layer(s)
