@@ -40,18 +40,19 @@ def build(force: bool = False, verbose: bool = True) -> str:
             continue
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [cc, *FLAGS, "-c", path, "-o", obj]
+        cmd = [cc, *FLAGS, *os.environ.get("EFTS_CFLAGS", "").split(), "-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    out = os.environ.get("EFTS_LIB_OUT", LIB)   # experiments: build a variant next to the product library
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":

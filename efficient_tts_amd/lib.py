@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libefts_hip.so")
+LIB_PATH = os.environ.get("EFTS_LIB", os.path.join(HERE, "libefts_hip.so"))   # EFTS_LIB: kernel experiments only
 
 GAP = 2
 GUARD_LO = 8

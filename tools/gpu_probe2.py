@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from efficient_tts_amd import lib as L, ops as P
 dev = torch.device("cuda:0"); L.load(); L.require_device()
-def time_layer(split, B=64, T=int(os.environ.get("PT","800")), C=512, iters=20):
+def time_layer(split, B=64, T=int(os.environ.get("PT","800")), C=512, iters=int(os.environ.get("PIT","100"))):
     rs = P.Rows(B, T)
     a = P.Plane.for_rows(rs, C, split, dev)
     x = torch.randn(B, T, C, device=dev)
