@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
-    ap.add_argument("--workload", default="fwd64", choices=["fwd64", "fwd16_long", "train32", "infer_lj"])
+    ap.add_argument("--workload", default="fwd64", choices=["fwd64", "fwd16_long", "train32", "infer_lj", "infer64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="1 (default): replay the step from a captured hipGraph -- ~75 launches per forward are host-bound in eager mode (3.0 vs 2.6 ms); the roofline events then come from 3 eager steps right after the timed region. 0: eager, events inside the timed region")
     return ap.parse_args()
@@ -95,6 +95,46 @@ def cpu_baseline(T1, T2):
     return dict(value=Bc * T2 / med, unit="mel-frames/s", cores=nt, host_cpus=cores, kind="port",
                 sample=f"oracle forward fp32, B={Bc} x (T1={T1}, T2={T2}), median of 3 after 1 warm-up, "
                        f"best of 8/16/32/64 threads ({med:.3f} s/iter at {nt} threads)")
+
+
+def run_infer64(a, world, rank, dev):
+    """BASELINE config 2, variant (ii) of SURVEY.md: batched FREE-RUNNING inference at B=64 (inference_batch),
+    128 phonemes per item, durations forced to 800/128 = 6.25 frames per phoneme after the duration predictor
+    has run (so every item yields T2 = 800 and the predictor is still executed and timed)."""
+    from efficient_tts_amd import EfficientTTSCNN
+    import torch.distributed as dist
+    B, T1, T2 = 64, 128, 800
+    torch.manual_seed(0)
+    model = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, sigma=0.01, precision=a.precision).to(dev).eval()
+    model.remove_weight_norm()
+    g = torch.Generator().manual_seed(1234 + rank)
+    text = torch.randint(0, 76, (B, T1), generator=g).to(dev)
+    tl = torch.full((B,), T1, dtype=torch.int64, device=dev)
+    for _ in range(max(a.warmup, 1)):
+        mel, ml, _ = model.inference_batch(text, tl, force_delta=T2 / T1)
+    assert int(ml.min()) == T2 and int(ml.max()) == T2 and mel.shape == (B, T2, 80)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        model.inference_batch(text, tl, force_delta=T2 / T1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    dt /= a.steps
+    if rank == 0:
+        res = dict(metric="mel-frames/sec (EFTS-CNN batched free-running inference, batch 64/GPU, 80-mel)", value=world * B * T2 / dt,
+                   unit="mel-frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt * 1e3, higher_is_better=True,
+                   scaling="weak", vs_baseline=None, dtype=a.precision if a.precision == "bf16" else "bf16x3 (split-bf16 MFMA, fp32-class)",
+                   data="synthetic", config={"workload": "EFTS-CNN inference_batch B=64 phon=128, durations forced to 6.25 -> mel=800 (eager, one host sync per call)",
+                                              "batch_per_gpu": B, "phoneme_len": T1, "mel_len": T2, "precision": a.precision,
+                                              "parallelism": f"replicas x{world}"},
+                   rtf=dt / (world * B * T2 * 256 / 22050.0), roofline=None, cpu_baseline=None)
+        print(json.dumps(res), flush=True)
 
 
 def run_infer_lj(a, world, rank, dev):
@@ -173,6 +213,8 @@ def main():
     from efficient_tts_amd import EfficientTTSCNN, ops as P
     if a.workload == "infer_lj":
         return run_infer_lj(a, world, rank, dev)
+    if a.workload == "infer64":
+        return run_infer64(a, world, rank, dev)
     wl = WORKLOADS[a.workload]
     B, T1, T2 = wl["B"], wl["T1"], wl["T2"]
     if a.workload == "train32":

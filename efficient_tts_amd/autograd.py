@@ -1,7 +1,8 @@
 """torch.autograd bridge: `loss.backward()` on the value returned by EfficientTTSCNN.forward()
 (the reference contract, nntts/trainers/efficient_tts_trainer.py:152-153) runs the hand-written HIP
 backward.  The fused engine computes forward and backward in one pass; the autograd Function hands
-the per-parameter gradients (views of the engine's flat buffer) to torch when backward is called."""
+the per-parameter gradients (views of the engine's flat buffer) to the parameters' `.grad` when
+backward is called."""
 from __future__ import annotations
 
 import torch
@@ -24,7 +25,7 @@ class _FusedStep(torch.autograd.Function):
         eng = engine_of(model)
         out3, _ = eng.forward_backward(text, text_lengths, speech, speech_lengths)
         ctx.eng = eng
-        ctx.names = [n for n, _ in model.named_parameters()]
+        ctx.named = list(model.named_parameters())
         ctx.mark_non_differentiable(out3)
         return out3[0].clone(), out3
 
@@ -34,8 +35,14 @@ class _FusedStep(torch.autograd.Function):
         if eng.join_reduce is not None:                      # data-parallel: the bucketed all-reduce launched during the
             eng.join_reduce()                                # fused pass works in place on `flat`; join it before scaling
         eng.flat.mul_(g_loss)                               # d(loss) scaling (1.0 in the reference loop)
-        grads = tuple(eng.g[n] for n in ctx.names)
-        return (None, None, None, None, None) + grads
+        # The per-parameter gradients ARE views of the engine's flat buffer (what the fused clip + Adam and
+        # the bucketed all-reduce work on).  They are attached as `.grad` directly: handing them to
+        # autograd's AccumulateGrad would clone all ~75 of them every step.  Consequence: gradients do
+        # not accumulate across backward() calls (the reference loop zero_grads every step,
+        # efficient_tts_trainer.py:150-156).
+        for n, p in ctx.named:
+            p.grad = eng.g[n]
+        return (None, None, None, None, None) + (None,) * len(ctx.named)
 
 
 def training_forward(model, text, text_lengths, speech, speech_lengths):

@@ -444,7 +444,7 @@ class EfficientTTSCNN(torch.nn.Module):
 
     # ------------------------------------------------------------------ batched ragged inference (extension)
     @torch.no_grad()
-    def inference_batch(self, text: torch.Tensor, text_lengths: torch.Tensor):
+    def inference_batch(self, text: torch.Tensor, text_lengths: torch.Tensor, force_delta: Optional[float] = None):
         """Free-running synthesis of B utterances at once -- an extension the reference cannot do
         (its inference() is B == 1 only: efficient_tts.py:361).  Every item is computed exactly as if it
         were alone: positions beyond an item's own length are kept at zero after EVERY layer (true
@@ -452,7 +452,10 @@ class EfficientTTSCNN(torch.nn.Module):
         accumulated per item and each item gets its own mel length T2_b = round(sum of durations).
 
         Returns (mel_pred [B, max T2_b, odim] zero-padded, mel_lengths [B] int64, reconst_alpha
-        [B, T1, max T2_b]).  One host sync (max T2_b), like the reference's single `.item()`."""
+        [B, T1, max T2_b]).  One host sync (max T2_b), like the reference's single `.item()`.
+
+        force_delta (benchmark hook): the duration predictor still runs, but every
+        valid phoneme then gets this many frames, so a synthetic batch yields a known, equal T2."""
         self._require(text)
         with O.stream_scope():
             dev = text.device
@@ -476,6 +479,8 @@ class EfficientTTSCNN(torch.nn.Module):
                    rowmask_ptr=len1.data_ptr(), out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p)
             delta = self._duration(ws, pk, rs1, val_p, len1, len1.data_ptr(), 1)          # zero beyond each length
             d2 = delta.view(B, rs1.Tp)[:, :T1].contiguous()
+            if force_delta is not None:
+                d2 = (torch.arange(T1, device=dev)[None, :] < tl[:, None]).to(torch.float32) * float(force_delta)
             e = ws.tensor("e", (B, T1))
             O.cumsum_rows(d2, e, B, T1)
             last = e.gather(1, (text_lengths.to(dev).long() - 1).clamp(min=0)[:, None]).squeeze(1)
