@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
-    ap.add_argument("--workload", default="fwd64", choices=["fwd64", "fwd16_long", "train32", "infer_lj", "infer64"])
+    ap.add_argument("--workload", default="fwd64", choices=["fwd64", "fwd16_long", "train32", "infer_lj", "infer64", "logmel64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="1 (default): replay the step from a captured hipGraph -- ~75 launches per forward are host-bound in eager mode (3.0 vs 2.6 ms); the roofline events then come from 3 eager steps right after the timed region. 0: eager, events inside the timed region")
     return ap.parse_args()
@@ -137,6 +137,65 @@ def run_infer64(a, world, rank, dev):
         print(json.dumps(res), flush=True)
 
 
+def run_logmel64(a, world, rank, dev):
+    """Row f-3: the on-device log-mel front-end on 64 utterances of 800 frames (204 800 samples each):
+    frame_pack -> DFT as an MFMA product (bf16x3) -> magnitude / mel / log.  Inputs resident in HBM."""
+    from efficient_tts_amd import ops as P
+    from efficient_tts_amd.frontend import LogMelFrontend
+    import torch.distributed as dist
+    B, T2 = 64, 800
+    g = torch.Generator().manual_seed(1234 + rank)
+    audio = (torch.rand(B, T2 * 256, generator=g) * 2 - 1).mul_(0.3).to(dev)
+    lengths = torch.full((B,), T2 * 256)
+    fe = LogMelFrontend(dev)
+    for _ in range(max(a.warmup, 1)):
+        mel, frames = fe(audio, lengths)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        fe(audio, lengths)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    dt /= a.steps
+    rows = B * (T2 + 2)
+    P.PROFILE, P.PROFILE_TAG = [], (1, rows, 1026)
+    for _ in range(3):
+        fe(audio, lengths)
+    torch.cuda.synchronize()
+    durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in P.PROFILE]
+    P.PROFILE, P.PROFILE_TAG = None, None
+    avg = sum(durs) / max(len(durs), 1)
+    flop = 2.0 * B * T2 * 1024 * 1026
+    roof = dict(bound="mfma", kernel="gemm_kernel<taps=1,split=2> (real DFT 1024 -> 513 re + 513 im as an MFMA product)",
+                achieved=flop / avg / 1e12, peak=PEAK_MFMA_BF16_TFLOPS, unit="TFLOP/s", frac=flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS,
+                traffic=None, avg_launch_us=avg * 1e6, launches_measured=len(durs), algorithmic_flop_per_launch=flop,
+                mfma_issue_frac=3 * flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS)
+    if rank == 0:
+        res = dict(metric="mel-frames/sec (on-device log-mel front-end, 64 x 800 frames, n_fft 1024 / hop 256 / 80 mel)",
+                   value=world * B * T2 / dt, unit="mel-frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt * 1e3,
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16x3 (split-bf16 MFMA, fp32-class)", data="synthetic",
+                   config={"workload": "log-mel front-end B=64 x 204800 samples -> 800 frames x 80 mel", "batch_per_gpu": B, "mel_len": T2,
+                           "parallelism": f"replicas x{world}"}, roofline=roof)
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle import logmel_oracle as LO          # cpu_baseline leg: the oracle as the thing timed
+            ya = audio[:8].cpu()
+            torch.set_num_threads(min(os.cpu_count() or 1, 16))
+            LO.mel_spectrogram(ya)
+            ts = []
+            for _ in range(5):
+                t1 = time.perf_counter(); LO.mel_spectrogram(ya); ts.append(time.perf_counter() - t1)
+            med = sorted(ts)[len(ts) // 2]
+            res["cpu_baseline"] = dict(value=8 * T2 / med, unit="mel-frames/s", cores=min(os.cpu_count() or 1, 16), kind="port",
+                                       sample=f"oracle mel_spectrogram (torch.stft fp32), 8 x 204800 samples, median of 5 ({med*1e3:.1f} ms)")
+        print(json.dumps(res), flush=True)
+
+
 def run_infer_lj(a, world, rank, dev):
     """BASELINE config 1 plumbing on the GPU: free-running inference() of the first 10 LJSpeech test
     utterances (what nntts/bin/inference.py:97 iterates), one at a time (B = 1, as the reference), plus
@@ -215,6 +274,8 @@ def main():
         return run_infer_lj(a, world, rank, dev)
     if a.workload == "infer64":
         return run_infer64(a, world, rank, dev)
+    if a.workload == "logmel64":
+        return run_logmel64(a, world, rank, dev)
     wl = WORKLOADS[a.workload]
     B, T1, T2 = wl["B"], wl["T1"], wl["T2"]
     if a.workload == "train32":

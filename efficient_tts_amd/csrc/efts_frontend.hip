@@ -1,0 +1,105 @@
+// efts_frontend.hip -- on-device log-mel front-end: the step right
+// before the acoustic-model path.  Reference: nntts/datasets/meldataset.py:49-82 (mel_spectrogram)
+// and the per-item + collate plumbing of nntts/datasets/taco2_data.py:66-76,122-139.
+//
+//   audio [B][L] --frame_pack--> windowed frames as bf16x3 operand planes [B*Tp][1024]
+//         --efts_gemm (taps 1) x DFT plane [1026][1024]--> re/im spectrum fp32 [B*Tp][1028]
+//         --logmel--> log(clamp(mel_basis . sqrt(re^2+im^2+1e-9), 1e-5))  -> [B][T][80] (zero past each length)
+//
+// The STFT is a dense MFMA product on the same contraction kernel as the model (no rocFFT, no host
+// round trip): 2.1 MFLOP per frame, less than one ResConv layer.  frame_pack and logmel are HBM-bound.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "efts_internal.h"
+
+namespace efts {
+
+// one block (256 threads) per row (b, t); each thread handles n_fft / 256 consecutive samples (n_fft = 1024 -> 4)
+__global__ __launch_bounds__(256) void frame_pack_kernel(const float* __restrict__ audio, long ld_audio, const int* __restrict__ lengths,
+                                                         const float* __restrict__ window, char* __restrict__ plane, long ld_plane,
+                                                         int T, int Tp, int n_fft, int hop, int split) {
+    const int row = blockIdx.x;
+    const int b = row / Tp, t = row - b * Tp;
+    const int L = lengths[b];
+    const int nfr = L / hop;                 // frames of this item: (L + 2*pad - n_fft) / hop + 1 with pad = (n_fft - hop) / 2
+    const int pad = (n_fft - hop) / 2;
+    const bool valid = t < T && t < nfr;
+    const float* a = audio + (long)b * ld_audio;
+    char* dst = plane + (long)row * ld_plane;
+    for (int k = threadIdx.x * 4; k < n_fft; k += 1024) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float x = 0.f;
+            if (valid) {
+                int s = t * hop + k + u - pad;       // index into the un-padded signal
+                s = s < 0 ? -s : s;                  // reflect (torch 'reflect': no edge repeat), meldataset.py:69
+                s = s >= L ? 2 * (L - 1) - s : s;
+                x = a[s] * window[k + u];
+            }
+            v[u] = x;
+        }
+        plane_store4(dst, k, v[0], v[1], v[2], v[3], split);
+    }
+}
+
+// one wave per row: magnitudes into LDS, then lane m (and m + 64) accumulates its triangular filter
+__global__ __launch_bounds__(64) void logmel_kernel(const float* __restrict__ spec, long ld_spec, const float* __restrict__ basis,
+                                                    const int* __restrict__ ranges, const int* __restrict__ frames, float* __restrict__ out,
+                                                    int T, int Tp, int n_bins, int n_mels) {
+    extern __shared__ float mag[];
+    const int row = blockIdx.x;
+    const int b = row / Tp, t = row - b * Tp;
+    if (t >= T) return;
+    const int lane = threadIdx.x;
+    float* o = out + ((long)b * T + t) * n_mels;
+    if (t >= frames[b]) {                        // TextMelCollate pads the time axis with zeros AFTER the log (taco2_data.py:122-134)
+        for (int m = lane; m < n_mels; m += 64) o[m] = 0.f;
+        return;
+    }
+    const float* re = spec + (long)row * ld_spec;
+    const float* im = re + n_bins;
+    for (int k = lane; k < n_bins; k += 64) {
+        const float r = re[k], i = im[k];
+        mag[k] = sqrtf(r * r + i * i + 1e-9f);   // meldataset.py:75
+    }
+    __syncthreads();
+    for (int m = lane; m < n_mels; m += 64) {
+        const int lo = ranges[2 * m], hi = ranges[2 * m + 1];
+        const float* w = basis + (long)m * n_bins;
+        float acc = 0.f;
+        for (int k = lo; k < hi; ++k) acc += w[k] * mag[k];
+        o[m] = logf(fmaxf(acc, 1e-5f));          // meldataset.py:27-28,78
+    }
+}
+
+}  // namespace efts
+
+using namespace efts;
+
+extern "C" int efts_frame_pack(const float* audio, int64_t ld_audio, const int32_t* lengths, const float* window, void* plane,
+                               int64_t ld_plane, int32_t B, int32_t T, int32_t Tp, int32_t n_fft, int32_t hop, int32_t split,
+                               void* stream) {
+    if (!audio || !lengths || !window || !plane) return efts_fail(EFTS_EINVAL, "efts_frame_pack: null pointer");
+    if (B <= 0 || T <= 0 || Tp < T) return efts_fail(EFTS_ESHAPE, "efts_frame_pack: bad B / T / Tp");
+    if (n_fft <= 0 || (n_fft & 3) || hop <= 0 || hop > n_fft || ((n_fft - hop) & 1))
+        return efts_fail(EFTS_ESHAPE, "efts_frame_pack: n_fft must be a multiple of 4, 0 < hop <= n_fft, n_fft - hop even");
+    if (!(split == 1 || split == 2)) return efts_fail(EFTS_EINVAL, "efts_frame_pack: split must be 1 or 2");
+    const int64_t need = (int64_t)((n_fft + (split == 1 ? 63 : 31)) / (split == 1 ? 64 : 32)) * 128;
+    if (ld_plane < need || (ld_plane & 15)) return efts_fail(EFTS_ESHAPE, "efts_frame_pack: plane row stride too small / unaligned");
+    hipLaunchKernelGGL(frame_pack_kernel, dim3(B * Tp), dim3(256), 0, (hipStream_t)stream, audio, (long)ld_audio, lengths, window,
+                       (char*)plane, (long)ld_plane, T, Tp, n_fft, hop, split);
+    return efts_check_launch("efts_frame_pack");
+}
+
+extern "C" int efts_logmel(const float* spec, int64_t ld_spec, const float* basis, const int32_t* ranges, const int32_t* frames,
+                           float* out, int32_t B, int32_t T, int32_t Tp, int32_t n_bins, int32_t n_mels, void* stream) {
+    if (!spec || !basis || !ranges || !frames || !out) return efts_fail(EFTS_EINVAL, "efts_logmel: null pointer");
+    if (B <= 0 || T <= 0 || Tp < T || n_bins <= 0 || n_mels <= 0) return efts_fail(EFTS_ESHAPE, "efts_logmel: bad shape");
+    if (ld_spec < 2 * (int64_t)n_bins) return efts_fail(EFTS_ESHAPE, "efts_logmel: spectrum row stride smaller than 2*n_bins");
+    if (n_bins * 4 > 64 * 1024) return efts_fail(EFTS_ESHAPE, "efts_logmel: n_bins too large for the LDS tile");
+    hipLaunchKernelGGL(logmel_kernel, dim3(B * Tp), dim3(64), n_bins * sizeof(float), (hipStream_t)stream, spec, (long)ld_spec, basis,
+                       ranges, frames, out, T, Tp, n_bins, n_mels);
+    return efts_check_launch("efts_logmel");
+}

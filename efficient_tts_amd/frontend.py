@@ -1,0 +1,119 @@
+"""On-device log-mel front-end: audio -> the `speech` tensor EfficientTTSCNN.forward() takes.
+
+Replaces, for a whole batch on the GPU, what the reference does per item on CPU dataloader workers:
+`mel_spectrogram` (nntts/datasets/meldataset.py:49-82) called from `TextMelLoader.get_mel`
+(nntts/datasets/taco2_data.py:66-76), plus the mel padding of `TextMelCollate` (:122-139).
+Pipeline (csrc/efts_frontend.hip): frame_pack (reflect pad + hann window -> bf16x3 operand planes)
+-> efts_gemm against a real-DFT plane (MFMA) -> logmel (magnitude, Slaney mel filterbank, log clamp).
+No CPU fallback: the HIP library is required.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import ops as O
+from .ops import F32Rows, PackedWeight, Plane, Rows
+
+
+def slaney_mel_filterbank(sr: int, n_fft: int, n_mels: int, fmin: float, fmax: float) -> np.ndarray:
+    """The filterbank the reference obtains from librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax)
+    (meldataset.py:65; librosa >= 0.8 defaults htk=False, norm='slaney'), computed here from the
+    published definition so that the package has no librosa dependency: Slaney's mel scale (linear at
+    200/3 Hz per mel below 1 kHz, logarithmic with 27 mels per factor 6.4 above), triangles between
+    neighbouring centre frequencies on the rFFT bin grid, each scaled to unit area in Hz."""
+    def to_mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        return np.where(f >= 1000.0, 15.0 + np.log(np.maximum(f, 1e-10) / 1000.0) * (27.0 / np.log(6.4)), f * 3.0 / 200.0)
+
+    def to_hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        return np.where(m >= 15.0, 1000.0 * np.exp((m - 15.0) * (np.log(6.4) / 27.0)), m * 200.0 / 3.0)
+
+    bins = np.linspace(0.0, sr / 2.0, n_fft // 2 + 1)
+    edges = to_hz(np.linspace(to_mel(fmin), to_mel(fmax), n_mels + 2))
+    fb = np.zeros((n_mels, bins.size))
+    for m in range(n_mels):
+        lo, ce, hi = edges[m], edges[m + 1], edges[m + 2]
+        rise = (bins - lo) / (ce - lo)
+        fall = (hi - bins) / (hi - ce)
+        fb[m] = np.clip(np.minimum(rise, fall), 0.0, None) * (2.0 / (hi - lo))
+    return fb.astype(np.float32)
+
+
+class LogMelFrontend:
+    """mel, frames = LogMelFrontend(device)(audio, lengths)
+
+    audio: [B, L] float32 in [-1, 1] (or int16, scaled by 1/32768 as TextMelLoader.get_mel does), on the
+    device or the host; lengths: [B] sample counts.  Returns mel [B, T, 80] float32 (zero past each item's
+    frame count, T = max frames) and frames [B] int64 -- the (speech, speech_lengths) of the model."""
+
+    def __init__(self, device, sampling_rate: int = 22050, n_fft: int = 1024, hop_size: int = 256, win_size: int = 1024,
+                 num_mels: int = 80, fmin: float = 0.0, fmax: float = 8000.0, max_wav_value: float = 32768.0):
+        if win_size != n_fft:
+            raise ValueError("win_size must equal n_fft (the reference's configuration)")
+        self.dev = torch.device(device)
+        self.n_fft, self.hop, self.n_mels, self.n_bins = n_fft, hop_size, num_mels, n_fft // 2 + 1
+        self.max_wav_value = max_wav_value
+        L.load()
+        L.require_device()
+        fb = slaney_mel_filterbank(sampling_rate, n_fft, num_mels, fmin, fmax)
+        rng = np.zeros((num_mels, 2), dtype=np.int32)
+        for m in range(num_mels):
+            nz = np.nonzero(fb[m])[0]
+            rng[m] = (nz[0], nz[-1] + 1) if nz.size else (0, 0)
+        self.basis = torch.from_numpy(fb).to(self.dev).contiguous()
+        self.ranges = torch.from_numpy(rng).to(self.dev).contiguous()
+        self.window = torch.hann_window(win_size, dtype=torch.float32).to(self.dev)           # periodic hann, meldataset.py:67
+        # real DFT as a B operand plane: rows 0..n_bins-1 = cos(2 pi f k / N), rows n_bins.. = -sin
+        k = np.arange(n_fft, dtype=np.float64)[None, :]
+        f = np.arange(self.n_bins, dtype=np.float64)[:, None]
+        ang = 2.0 * math.pi * f * k / n_fft
+        dft = np.concatenate([np.cos(ang), -np.sin(ang)], axis=0).astype(np.float32)
+        self.n_out = 2 * self.n_bins
+        self.ld_spec = O.roundup(self.n_out, 4)
+        with O.stream_scope():
+            self.dft = PackedWeight(self.n_out, n_fft, 1, 2, self.dev)
+            self.dft.pack(torch.from_numpy(dft).to(self.dev).contiguous())
+        self._ws = {}
+
+    def frames_of(self, lengths: torch.Tensor) -> torch.Tensor:
+        return torch.div(lengths.to(torch.int64), self.hop, rounding_mode="floor")
+
+    @torch.no_grad()
+    def __call__(self, audio: torch.Tensor, lengths: torch.Tensor, max_frames: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        if audio.dim() != 2:
+            raise ValueError("audio must be [B, L]")
+        B = audio.shape[0]
+        if audio.dtype == torch.int16:
+            audio = audio.to(self.dev).to(torch.float32) / self.max_wav_value                  # taco2_data.py:70
+        audio = audio.to(self.dev, torch.float32).contiguous()
+        lengths_h = lengths.detach().to("cpu", torch.int64)
+        if int(lengths_h.min()) <= (self.n_fft - self.hop) // 2:
+            raise ValueError("every item must be longer than the reflect padding (n_fft - hop) / 2")
+        if int(lengths_h.max()) > audio.shape[1]:
+            raise ValueError("lengths exceed the audio buffer")
+        frames_h = lengths_h // self.hop
+        T = int(frames_h.max()) if max_frames is None else int(max_frames)
+        li = lengths_h.to(torch.int32).to(self.dev)
+        fi = frames_h.to(torch.int32).to(self.dev)
+        rs = Rows(B, T)
+        key = (B, T)
+        if key not in self._ws:
+            if len(self._ws) > 4:
+                self._ws.pop(next(iter(self._ws)))
+            self._ws[key] = (Plane.for_rows(rs, self.n_fft, 2, self.dev), F32Rows(rs, self.ld_spec, self.dev))
+        fr, spec = self._ws[key]
+        out = torch.empty(B, T, self.n_mels, dtype=torch.float32, device=self.dev)
+        lib = L.load()
+        with O.stream_scope():
+            L.check(lib.efts_frame_pack(audio.data_ptr(), audio.shape[1], li.data_ptr(), self.window.data_ptr(), fr.ptr, fr.ld,
+                                        B, T, rs.Tp, self.n_fft, self.hop, 2, O._stream()), "efts_frame_pack")
+            O.gemm(a=fr, b_ptr=self.dft.ptr, ldb=self.dft.ld, m=rs.rows, n=self.n_out, out_f32_ptr=spec.ptr, ldo=self.ld_spec)
+            L.check(lib.efts_logmel(spec.ptr, self.ld_spec, self.basis.data_ptr(), self.ranges.data_ptr(), fi.data_ptr(),
+                                    out.data_ptr(), B, T, rs.Tp, self.n_bins, self.n_mels, O._stream()), "efts_logmel")
+        return out, frames_h.to(self.dev)

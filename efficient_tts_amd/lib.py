@@ -71,6 +71,9 @@ _SIGS = {
     "efts_sumsq_workspace_bytes": (C.c_size_t, []),
     "efts_sumsq": (i32, [vp, i64, vp, vp, vp]),
     "efts_adam_amsgrad": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
+    # log-mel front-end
+    "efts_frame_pack": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
+    "efts_logmel": (i32, [vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
 }
 
 _lib: Optional[C.CDLL] = None

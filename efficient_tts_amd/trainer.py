@@ -41,6 +41,7 @@ class EfficientTTSTrainer(object):
         self.total_train_loss = defaultdict(float)
         self.total_eval_loss = defaultdict(float)
         self._pending = []                # LazyStats of the steps since the last log (read at log time)
+        self.frontend = None              # optional LogMelFrontend: batches then carry (audio, audio_lengths) instead of mels
 
     # ------------------------------------------------------------------ loop (trainer.py:62-76,167-191)
     def run(self):
@@ -78,8 +79,23 @@ class EfficientTTSTrainer(object):
                 self.scheduler.load_state_dict(state_dict["scheduler"])
 
     # ------------------------------------------------------------------ one step (trainer.py:121-165)
-    def _train_step(self, batch):
+    def _to_device(self, batch):
         text, text_lengths, mel, mel_lengths = [x.to(self.device) for x in batch]
+        if self.frontend is not None:     # waveform batch (efficient_tts_amd.datasets.TextMelCollate): log-mel on the GPU
+            # optional shape bucketing (config "bucket_frames" / "bucket_phones", 0 = exact batch maximum as the
+            # reference pads): fewer distinct (T1, T2) shapes -> the engine's per-shape workspaces are re-used
+            bf, bp = int(self.config.get("bucket_frames", 0)), int(self.config.get("bucket_phones", 0))
+            frames = self.frontend.frames_of(mel_lengths)
+            tmax = int(frames.max())
+            if bf > 0:
+                tmax = (tmax + bf - 1) // bf * bf
+            mel, mel_lengths = self.frontend(mel, mel_lengths, max_frames=tmax)
+            if bp > 0 and text.shape[1] % bp:
+                text = torch.nn.functional.pad(text, (0, bp - text.shape[1] % bp))
+        return text, text_lengths, mel, mel_lengths
+
+    def _train_step(self, batch):
+        text, text_lengths, mel, mel_lengths = self._to_device(batch)
         loss, stats, *_ = self.model(text=text, text_lengths=text_lengths, speech=mel, speech_lengths=mel_lengths)
         self._pending.append(stats)
         self.optimizer.zero_grad()
@@ -132,7 +148,7 @@ class EfficientTTSTrainer(object):
     # ------------------------------------------------------------------ eval (trainer.py:193-252)
     @torch.no_grad()
     def _eval_step(self, batch, plot=False):
-        text, text_lengths, mel, mel_lengths = [x.to(self.device) for x in batch]
+        text, text_lengths, mel, mel_lengths = self._to_device(batch)
         loss, stats, imv, alpha, mel_pred, mel_gt = self._raw_model()(text=text, text_lengths=text_lengths, speech=mel,
                                                                       speech_lengths=mel_lengths)
         self.total_eval_loss["eval/loss"] += stats["loss"]

@@ -253,6 +253,29 @@ int efts_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax,
                       float max_norm, float gscale, float lr, float beta1, float beta2, float eps, float weight_decay,
                       int32_t step, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Log-mel front-end: the data format right before the path.
+ * Replaces nntts/datasets/meldataset.py:49-82 (mel_spectrogram, computed per item on CPU dataloader
+ * workers by TextMelLoader.get_mel, taco2_data.py:66-76) and the mel half of TextMelCollate
+ * (taco2_data.py:122-139) with a batched device pipeline:
+ *   efts_frame_pack : audio fp32 [B][ld_audio] in [-1,1], per-item sample counts `lengths` ->
+ *                     A operand plane rows (b*Tp + t), K = n_fft: frame t of item b =
+ *                     reflect_pad(audio_b, (n_fft-hop)/2)[t*hop + k] * window[k]  (:69-73);
+ *                     frames past L_b / hop and gap rows are zero.
+ *   efts_gemm       : taps 1, against a B plane of the real DFT (rows 0..n_bins-1 = cos, rows
+ *                     n_bins..2*n_bins-1 = -sin), fp32 output [rows][ld_spec >= 2*n_bins].
+ *   efts_logmel     : out[b][t][m] = log(max(sum_k basis[m][k] * sqrt(re^2+im^2+1e-9), 1e-5)) for
+ *                     t < frames[b], else 0 (:75-78, :27-28; zero padding after the log as the
+ *                     collate does).  basis fp32 [n_mels][n_bins]; ranges int32 [n_mels][2] = the
+ *                     [lo, hi) span of non-zero basis entries of each filter.  out is the contiguous
+ *                     [B][T][n_mels] tensor EfficientTTSCNN.forward takes as `speech`.
+ * ---------------------------------------------------------------------------------- */
+int efts_frame_pack(const float* audio, int64_t ld_audio, const int32_t* lengths, const float* window, void* plane,
+                    int64_t ld_plane, int32_t B, int32_t T, int32_t Tp, int32_t n_fft, int32_t hop, int32_t split,
+                    void* stream);
+int efts_logmel(const float* spec, int64_t ld_spec, const float* basis, const int32_t* ranges, const int32_t* frames,
+                float* out, int32_t B, int32_t T, int32_t Tp, int32_t n_bins, int32_t n_mels, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

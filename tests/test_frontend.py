@@ -1,0 +1,99 @@
+"""Log-mel front-end: oracle known-answer checks on CPU, HIP parity on the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import logmel_oracle as LO
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "logmel_small.npz")
+LOGMEL_TOL = 1e-3        # |log-mel (HIP, bf16x3 MFMA DFT) - log-mel (oracle, fp32 torch.stft)|; measured 1.6e-4
+
+
+def test_mel_basis_known_answers():
+    """Properties of librosa's Slaney filterbank for (22050, 1024, 80, 0, 8000) that do not depend on our code:
+    shape, unit area in Hz per filter, contiguous triangles, every rFFT bin below fmax in at most two filters,
+    linear (equal-width) filters below 1 kHz, nothing above fmax."""
+    b = LO.slaney_mel_basis()
+    assert b.shape == (80, 513) and b.dtype == np.float32
+    hz_per_bin = 22050 / 1024
+    area = b.sum(1) * hz_per_bin
+    assert np.allclose(area[5:], 1.0, atol=0.08)                   # slaney norm: unit area (bin sampling makes it approximate)
+    assert ((b > 0).sum(0) <= 2).all()
+    fmax_bin = int(np.floor(8000 / hz_per_bin))
+    assert (b[:, fmax_bin + 1:] == 0).all()
+    peaks = b.argmax(1)
+    assert (np.diff(peaks) >= 1).all()
+    lin = peaks[(peaks * hz_per_bin) < 900]
+    assert np.ptp(np.diff(lin)) <= 1                               # equally spaced centres on the linear part
+    for m in range(80):                                            # one contiguous run of non-zeros per filter
+        nz = np.nonzero(b[m])[0]
+        assert nz.size and (np.diff(nz) == 1).all()
+
+
+def test_oracle_matches_committed_fixture_and_naive_dft():
+    g = np.load(GOLD)
+    audio = torch.from_numpy(g["audio"]).float() / 32768.0
+    mel, frames = LO.batch_logmel(audio, torch.from_numpy(g["lengths"]))
+    assert frames.tolist() == g["frames"].tolist() == [int(l) // 256 for l in g["lengths"]]
+    assert np.abs(mel.numpy() - g["mel"]).max() < 1e-5
+    # the STFT leg against a float64 DFT written out by hand, one frame of item 0
+    y = audio[0, :int(g["lengths"][0])].double()
+    yp = torch.nn.functional.pad(y[None, None], (384, 384), mode="reflect")[0, 0]
+    t = 5
+    fr = yp[t * 256: t * 256 + 1024] * torch.hann_window(1024, dtype=torch.float64)
+    k = torch.arange(1024, dtype=torch.float64)
+    f = torch.arange(513, dtype=torch.float64)[:, None]
+    re = (fr * torch.cos(2 * np.pi * f * k / 1024)).sum(1)
+    im = -(fr * torch.sin(2 * np.pi * f * k / 1024)).sum(1)
+    mag = torch.sqrt(re * re + im * im + 1e-9)
+    ref = torch.log(torch.clamp(torch.from_numpy(LO.slaney_mel_basis()).double() @ mag, min=1e-5))
+    assert (mel[0, t].double() - ref).abs().max() < 2e-4
+    assert (mel[2, int(frames[2]):] == 0).all()                    # collate zero padding after the log
+
+
+@pytest.mark.gpu
+def test_frontend_matches_oracle_on_fixture():
+    from efficient_tts_amd.frontend import LogMelFrontend
+    g = np.load(GOLD)
+    fe = LogMelFrontend("cuda:0")
+    a16 = torch.from_numpy(g["audio"])
+    lengths = torch.from_numpy(g["lengths"])
+    mel, frames = fe(a16, lengths)                                  # int16 in, scaled by 1/32768 like TextMelLoader.get_mel
+    assert frames.tolist() == g["frames"].tolist()
+    assert mel.shape == g["mel"].shape
+    err = np.abs(mel.cpu().numpy() - g["mel"]).max()
+    assert err < LOGMEL_TOL, err
+    mel2, _ = fe(a16.float().cuda() / 32768.0, lengths.cuda())      # float input already on the device
+    assert torch.equal(mel, mel2)
+
+
+@pytest.mark.gpu
+def test_frontend_edge_cases_and_model_handoff():
+    from efficient_tts_amd import EfficientTTSCNN
+    from efficient_tts_amd.frontend import LogMelFrontend
+    fe = LogMelFrontend("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    # ragged batch incl. the shortest legal item (one frame more than the reflect padding allows) and a non-multiple of hop
+    lengths = torch.tensor([385 + 256, 256 * 7 + 255, 256 * 40, 1000])
+    audio = (torch.rand(4, int(lengths.max()), generator=g) * 2 - 1) * 0.5
+    for b, l in enumerate(lengths):
+        audio[b, int(l):] = 123.0                                   # garbage past the length must never be read
+    mel, frames = fe(audio, lengths)
+    ref, rfr = LO.batch_logmel(audio, lengths)
+    assert frames.tolist() == rfr.tolist() == [2, 7, 40, 3]
+    assert (mel.cpu() - ref).abs().max() < LOGMEL_TOL
+    with pytest.raises(ValueError):
+        fe(audio[:, :300], torch.tensor([300, 300, 300, 300]))      # not longer than the reflect padding
+    with pytest.raises(ValueError):
+        fe(audio, lengths + 100000)
+    # the output IS the model's (speech, speech_lengths)
+    torch.manual_seed(0)
+    model = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True).cuda().eval()
+    text = torch.randint(1, 76, (4, 12), device="cuda")
+    tl = torch.tensor([12, 10, 12, 6], device="cuda")
+    # forward wants lengths sorted like the collate does; only shapes / finiteness are checked here
+    with torch.no_grad():
+        out = model(text, tl, mel, frames)
+    assert torch.isfinite(out[0]).all() and out[4].shape == mel.shape
