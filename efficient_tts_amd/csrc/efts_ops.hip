@@ -397,13 +397,28 @@ __global__ __launch_bounds__(256) void losses_stage1(const float* __restrict__ m
     __shared__ float sh[4];
     const long nmel = (long)B * T2 * odim;
     float sm = 0.f;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nmel; idx += (long)LOSS_BLOCKS * 256) {
-        const long fr = idx / odim;
-        const int o = (int)(idx - fr * odim);
-        const int b = (int)(fr / T2), j = (int)(fr - (long)b * T2);
-        if (j < mlen[b]) {
-            const float d = mp[((long)b * T2p + j) * ldm + o] - sp[idx];
-            sm += d * d;
+    if ((odim & 3) == 0 && (ldm & 3) == 0 && nmel < 0x7fffffffL && (((uintptr_t)mp | (uintptr_t)sp) & 15) == 0) {
+        // float4 path, 32-bit index math (the 64-bit divisions of the scalar path made this kernel ALU-bound)
+        const unsigned q = (unsigned)odim >> 2, nv = (unsigned)(nmel >> 2);
+        for (unsigned v = blockIdx.x * 256 + threadIdx.x; v < nv; v += LOSS_BLOCKS * 256) {
+            const unsigned fr = v / q, o4 = (v - fr * q) << 2;
+            const unsigned b = fr / (unsigned)T2, j = fr - b * (unsigned)T2;
+            if ((int)j < mlen[b]) {
+                const float4 a = *(const float4*)(mp + ((long)b * T2p + j) * ldm + o4);
+                const float4 t = *(const float4*)(sp + (long)fr * odim + o4);
+                const float d0 = a.x - t.x, d1 = a.y - t.y, d2 = a.z - t.z, d3 = a.w - t.w;
+                sm += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        }
+    } else {
+        for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nmel; idx += (long)LOSS_BLOCKS * 256) {
+            const long fr = idx / odim;
+            const int o = (int)(idx - fr * odim);
+            const int b = (int)(fr / T2), j = (int)(fr - (long)b * T2);
+            if (j < mlen[b]) {
+                const float d = mp[((long)b * T2p + j) * ldm + o] - sp[idx];
+                sm += d * d;
+            }
         }
     }
     float sd = 0.f;
