@@ -62,9 +62,11 @@ def synth(B, T1, T2, seed, dev):
     return text, tl, mel, sl
 
 
-def cpu_baseline(T1, T2):
+def cpu_baseline(T1, T2, hip_check=None):
     """The oracle (CPU port of the reference path) timed on this box's host cores: forward at
-    B=16 (bounded sample of the same workload), fp32, all cores."""
+    B=16 (bounded sample of the same workload), fp32, all cores.  hip_check(P, text, tl, mel, sl) ->
+    mel_pred of the HIP model with the oracle's parameters on the first 2 items; the oracle then acts as
+    the checker and the measured max-abs difference is reported next to the throughput."""
     from oracle import efts_oracle as O          # the cpu_baseline leg: oracle as the thing timed
     cores = os.cpu_count() or 1
     P = O.fill_params()
@@ -92,9 +94,16 @@ def cpu_baseline(T1, T2):
         if med > 4 * best[0]:
             break
     med, nt = best
-    return dict(value=Bc * T2 / med, unit="mel-frames/s", cores=nt, host_cpus=cores, kind="port",
-                sample=f"oracle forward fp32, B={Bc} x (T1={T1}, T2={T2}), median of 3 after 1 warm-up, "
-                       f"best of 8/16/32/64 threads ({med:.3f} s/iter at {nt} threads)")
+    res = dict(value=Bc * T2 / med, unit="mel-frames/s", cores=nt, host_cpus=cores, kind="port",
+               sample=f"oracle forward fp32, B={Bc} x (T1={T1}, T2={T2}), median of 3 after 1 warm-up, "
+                      f"best of 8/16/32/64 threads ({med:.3f} s/iter at {nt} threads)")
+    if hip_check is not None:
+        with torch.no_grad():
+            ref = O.forward(P, text[:2], tl[:2], mel[:2], sl[:2])
+        got = hip_check(P, text[:2], tl[:2], mel[:2], sl[:2])
+        res["hip_vs_oracle_mel_max_abs"] = float((got.detach().cpu() - ref["mel_pred"]).abs().max())
+        res["hip_vs_oracle_note"] = "same parameters and inputs (2 items, full length); north_star tolerance 1e-3 applies to the bf16x3 mode"
+    return res
 
 
 def run_infer64(a, world, rank, dev):
@@ -370,7 +379,14 @@ def main():
                    tflops=FWD_FLOP_PER_ITEM * B * T2 / 800 * world * a.steps / dt / 1e12 if (T1, T2) == (128, 800) else None,
                    loss=loss, roofline=roof)
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(T1, T2)
+            def hip_check(Pd, text_c, tl_c, mel_c, sl_c):
+                m2 = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, use_weighted_masking=False,
+                                     sigma=0.01, precision=a.precision)
+                m2.load_state_dict(Pd)
+                m2 = m2.to(dev).eval()
+                with torch.no_grad():
+                    return m2(text_c.to(dev), tl_c.to(dev), mel_c.to(dev), sl_c.to(dev))[4]
+            res["cpu_baseline"] = cpu_baseline(T1, T2, hip_check)
         print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist
