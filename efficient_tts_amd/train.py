@@ -8,6 +8,8 @@ ranges that become final early: mel head + decoder first, text encoder + embeddi
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -21,6 +23,9 @@ _lib = L.load
 
 def _ptr(t):
     return None if t is None else t.data_ptr()
+
+
+_WGRAD_WGS = int(os.environ.get("EFTS_WGRAD_WGS", "480"))   # split-K target: 480 workgroups per wgrad launch measured best (6.30 vs 6.60 ms/step at 640)
 
 
 class _TPlane(Plane):
@@ -139,7 +144,7 @@ class TrainEngine:
         ck = O.chunk_k(split)
         tiles = ((cout + 127) // 128) * ((cin + 127) // 128)
         nch_total = (rows + ck - 1) // ck
-        S = max(1, min(32, (640 + tiles * taps - 1) // (tiles * taps), nch_total))    # ~640 workgroups per launch
+        S = max(1, min(32, (_WGRAD_WGS + tiles * taps - 1) // (tiles * taps), nch_total))    # ~_WGRAD_WGS workgroups per launch
         nch = (nch_total + S - 1) // S
         kpad = O.roundup(S * nch * ck, 64)
         zt = ws.get(("zt", cout, kpad, split), lambda: _TPlane(cout, kpad, split, self.dev))
