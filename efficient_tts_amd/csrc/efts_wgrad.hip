@@ -1,0 +1,237 @@
+// efts_wgrad.hip -- weight gradient of the k5 residual convolutions straight from the ROW-MAJOR
+// operand planes the forward / dgrad contractions already use (no transposed copies):
+//
+//   part[k][s][co][ci] = sum_{t in split s} dZ[t][co] * X[t + k - 2][ci]         (k = 0..4)
+//
+// Replaces, for the (512, 512, 5) layers, efts_pack_t (one transposed plane of dZ + FIVE shifted
+// transposed planes of X per layer, 183 MB of HBM traffic) + the split-K efts_gemm.
+// (reference: autograd of F.conv1d in nntts/layers/efts_modules.py:48-51)
+//
+// The contraction runs over t, i.e. over the ROWS of both planes.  MFMA wants each lane to hold 8
+// consecutive k (= t) values of one output row/column, which in a row-major LDS image are strided:
+// gfx950's ds_read_b64_tr_b16 (transposing LDS read) delivers exactly that, 4 t-values per read.
+//   * workgroup tile: 128 co x 64 ci x all 5 taps, one K-split of the rows; 2x2 waves of 64 co x 32 ci,
+//     accumulators 5 taps x 2 blocks x 16 = 160 VGPRs.
+//   * per step 64 rows (bf16x3 planes: 32 rows, twice the chunks): dZ tile [2 chunks][64 t][128 B] + X window
+//     [72 t][128 B] (rows t0-2 .. t0+69) = 25 KiB by LDS-DMA (asm, counted vmcnt), 3-stage ring = 75 KiB, two workgroups per CU.
+//     The tap shift is a ROW offset into the X window (as in the forward kernel), so one window
+//     serves all 5 taps: 40 MFMAs per wave and step against 25 KiB staged (the transposed-plane GEMM:
+//     16 MFMAs per 19 KiB).
+//   * LDS image: row-major, 16-byte slots XORed with ((row >> 1) & 1) << 2, which makes the 4-row x
+//     64-byte footprint of a 32-lane transposing read cover all 64 banks exactly once.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "efts_internal.h"
+
+namespace efts {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int WG_NST = 3;
+
+// Tile constants.  SPLIT 1 (bf16 planes, 64 channels per 128-byte chunk): 64 rows per step, dZ = 2 chunks,
+// X = 1 chunk.  SPLIT 2 (bf16x3 planes, 32 hi + 32 lo channels per chunk): 32 rows per step, dZ = 4 chunks,
+// X = 2 chunks -- the same 128 co x 64 ci tile and about the same LDS per stage.
+template <int SPLIT>
+struct WgCfg {
+    static constexpr int ROWS = SPLIT == 1 ? 64 : 32;            // t rows per step
+    static constexpr int CA = SPLIT == 1 ? 2 : 4;                // dZ chunks per tile
+    static constexpr int CB = SPLIT == 1 ? 1 : 2;                // X chunks per tile
+    static constexpr int BROWS = ROWS + 8;                       // window rows (4 halo rows, rounded up to a DMA piece)
+    static constexpr int A_BYTES = CA * ROWS * 128;              // 16384
+    static constexpr int B_BYTES = CB * BROWS * 128;             // 9216 / 10240
+    static constexpr int STAGE = A_BYTES + B_BYTES;
+    static constexpr int LDS = WG_NST * STAGE;                   // 76800 / 79872
+    static constexpr int APP = ROWS / 8;                         // DMA pieces per dZ chunk
+    static constexpr int BPP = BROWS / 8;                        // DMA pieces per X chunk
+    static constexpr int NBP = CB * BPP;                         // 9 / 10 window pieces per step
+    static constexpr int KK = ROWS / 16;                         // MFMA k-steps per step
+};
+
+__device__ __forceinline__ int tn_off(int row, int byte_in_row) {      // swizzled byte offset inside a [rows][128 B] image
+    return row * 128 + ((((byte_in_row >> 4) ^ (((row >> 1) & 1) << 2)) << 4) | (byte_in_row & 15));
+}
+
+__device__ __forceinline__ void tn_dma16(unsigned lds_addr, unsigned voff, const char* sbase) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+}
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+    bf16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return r;
+}
+
+// grid: x = (cout/128) * (cin/64) tiles, y = nsplit; split s covers steps [s*steps_per_split, ...) of ROWS rows each.
+template <int SPLIT>
+__global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const char* __restrict__ dz, long ldz, const char* __restrict__ x, long ldx,
+                                                           float* __restrict__ part, int steps_per_split, int steps_total, int cout, int cin, int nsplit) {
+    using C = WgCfg<SPLIT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = cin >> 6;
+    const int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
+    const int sp = blockIdx.y;
+    const int t_begin = sp * steps_per_split * C::ROWS;
+    int nsteps = steps_total - sp * steps_per_split;             // the last splits may be short or empty (they then write zeros)
+    nsteps = nsteps < 0 ? 0 : (nsteps > steps_per_split ? steps_per_split : nsteps);
+
+    // ---- DMA plan of this wave.  dZ: 16 pieces of 8 rows (chunk = piece / APP), wave w owns 4w..4w+3.
+    // X window: NBP pieces (chunk = piece / BPP), wave w owns the pieces p with p % 4 == w (2 or 3 of them).
+    unsigned voa[4], vob[3], ldb[3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int pc = wave * 4 + q;
+        const int row = (pc % C::APP) * 8 + (lane >> 3);
+        const int sl = (lane & 7) ^ (((row >> 1) & 1) << 2);
+        voa[q] = (unsigned)(row * (int)ldz + (pc / C::APP) * 128 + (sl << 4));
+    }
+    const int nb = (C::NBP - 1 - wave) / 4 + 1;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int pc = wave + 4 * q;
+        const int pcc = pc < C::NBP ? pc : 0;
+        const int row = (pcc % C::BPP) * 8 + (lane >> 3);
+        const int sl = (lane & 7) ^ (((row >> 1) & 1) << 2);
+        vob[q] = (unsigned)(row * (int)ldx + (pcc / C::BPP) * 128 + (sl << 4));
+        ldb[q] = (unsigned)(C::A_BYTES + pcc * 1024);
+    }
+    const char* a_src = dz + (long)t_begin * ldz + (long)(mt * C::CA) * 128;
+    const char* b_src = x + (long)(t_begin - 2) * ldx + (long)(nt * C::CB) * 128;
+    auto issue = [&](int st) {                      // operands of step st -> ring slot st % 3
+        const unsigned base = lds0 + (st % WG_NST) * C::STAGE;
+        const char* sa = a_src + (long)st * C::ROWS * ldz;
+        const char* sb = b_src + (long)st * C::ROWS * ldx;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tn_dma16(base + (wave * 4 + q) * 1024, voa[q], sa);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) tn_dma16(base + __builtin_amdgcn_readfirstlane(ldb[q]), vob[q], sb);
+        if (nb == 3) tn_dma16(base + __builtin_amdgcn_readfirstlane(ldb[2]), vob[2], sb);
+    };
+    auto wait_next = [&](bool issued) {             // the operands of the next step have landed; this step's issue may stay in flight
+        if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (nb == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    };
+
+    f32x16 acc[5][2];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][i][r] = 0.f;
+
+    // per-lane geometry of the transposing reads: 16-lane group g = lane >> 4 reads a [4 t][16 ch] block;
+    // lane q of the group supplies the address of row (q >> 2), channels 4 * (q & 3) .. +3 of that block
+    const int q16 = lane & 15;
+    const int t_lane = (lane >> 5) * 8 + (q16 >> 2);             // + kk * 16 + h * 4
+    const int ch_lane = ((lane >> 4) & 1) * 16 + (q16 & 3) * 4;  // channel inside the 32-channel block of this lane group pair
+
+    if (nsteps > 0) issue(0);
+    if (nsteps > 1) issue(1);
+    wait_next(nsteps > 1);
+    __builtin_amdgcn_s_barrier();
+
+    for (int st = 0; st < nsteps; ++st) {
+        const bool more = st + 2 < nsteps;
+        if (more) issue(st + 2);
+        const char* stage = smem + (st % WG_NST) * C::STAGE;
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) {
+            const int ra = kk * 16 + t_lane;
+            if constexpr (SPLIT == 1) {
+                const char* at = stage + wm * (C::ROWS * 128);                 // dZ chunk wm = this wave's 64 co
+                const char* bt = stage + C::A_BYTES;
+                bf16x8 af[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = tr_frag(at + tn_off(ra, (ch_lane + i * 32) * 2), at + tn_off(ra + 4, (ch_lane + i * 32) * 2));
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const int rb = ra + k;                                     // window row of t at tap k: (t - t0) + 2 + (k - 2)
+                    const bf16x8 bfr = tr_frag(bt + tn_off(rb, (wn * 32 + ch_lane) * 2), bt + tn_off(rb + 4, (wn * 32 + ch_lane) * 2));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr, acc[k][i], 0, 0, 0);
+                }
+            } else {
+                const char* bt = stage + C::A_BYTES + wn * (C::BROWS * 128);   // X chunk wn = this wave's 32 ci
+                bf16x8 ah[2], al[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const char* at = stage + (wm * 2 + i) * (C::ROWS * 128);   // dZ chunk of this 32-co block: 32 hi | 32 lo
+                    ah[i] = tr_frag(at + tn_off(ra, ch_lane * 2), at + tn_off(ra + 4, ch_lane * 2));
+                    al[i] = tr_frag(at + tn_off(ra, 64 + ch_lane * 2), at + tn_off(ra + 4, 64 + ch_lane * 2));
+                }
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const int rb = ra + k;
+                    const bf16x8 bh = tr_frag(bt + tn_off(rb, ch_lane * 2), bt + tn_off(rb + 4, ch_lane * 2));
+                    const bf16x8 bl = tr_frag(bt + tn_off(rb, 64 + ch_lane * 2), bt + tn_off(rb + 4, 64 + ch_lane * 2));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[k][i], 0, 0, 0);
+                        acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[k][i], 0, 0, 0);
+                        acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[k][i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (st + 1 < nsteps) wait_next(more);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- partials: C/D layout col n = lane & 31 (ci), row m = (r&3) + 8*(r>>2) + 4*(lane>>5) (co)
+    const int ci = nt * 64 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        float* o = part + ((long)(k * nsplit + sp) * cout) * cin;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = mt * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                o[(long)co * cin + ci] = acc[k][i][r];
+            }
+    }
+}
+
+}  // namespace efts
+
+using namespace efts;
+
+extern "C" int efts_wgrad_tn(const void* dz_plane, int64_t ldz, const void* x_plane, int64_t ldx, float* part, int32_t rows,
+                             int32_t cout, int32_t cin, int32_t taps, int32_t nsplit, int32_t split, void* stream) {
+    if (!dz_plane || !x_plane || !part) return efts_fail(EFTS_EINVAL, "efts_wgrad_tn: null pointer");
+    if (taps != 5 || !(split == 1 || split == 2)) return efts_fail(EFTS_EINVAL, "efts_wgrad_tn: implemented for taps 5, split 1 or 2");
+    if (rows <= 0 || nsplit <= 0 || cout <= 0 || cin <= 0 || (cout & 127) || (cin & 63))
+        return efts_fail(EFTS_ESHAPE, "efts_wgrad_tn: cout must be a multiple of 128, cin of 64");
+    if ((ldz & 15) || (ldx & 15) || ldz < (int64_t)cout * 2 * split || ldx < (int64_t)cin * 2 * split || ldz > (1 << 20) || ldx > (1 << 20) ||
+        ((uintptr_t)dz_plane & 15) || ((uintptr_t)x_plane & 15))
+        return efts_fail(EFTS_EALIGN, "efts_wgrad_tn: plane strides / alignment");
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<1>::LDS);
+        (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<2>::LDS);
+        attr = true;
+    }
+    const int rps = split == 1 ? WgCfg<1>::ROWS : WgCfg<2>::ROWS;
+    const int steps = (rows + rps - 1) / rps;                // rows past `rows` (< 70 of them) are zero guard rows
+    const int per = (steps + nsplit - 1) / nsplit;
+    dim3 grid((cout / 128) * (cin / 64), nsplit);
+    if (split == 1)
+        hipLaunchKernelGGL(wgrad_tn_kernel<1>, grid, dim3(256), WgCfg<1>::LDS, (hipStream_t)stream, (const char*)dz_plane, (long)ldz,
+                           (const char*)x_plane, (long)ldx, part, per, steps, cout, cin, nsplit);
+    else
+        hipLaunchKernelGGL(wgrad_tn_kernel<2>, grid, dim3(256), WgCfg<2>::LDS, (hipStream_t)stream, (const char*)dz_plane, (long)ldz,
+                           (const char*)x_plane, (long)ldx, part, per, steps, cout, cin, nsplit);
+    return efts_check_launch("efts_wgrad_tn");
+}

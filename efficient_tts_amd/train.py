@@ -25,6 +25,7 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_WGRAD_TN_SPLITS = int(os.environ.get("EFTS_WGRAD_TN_SPLITS", "8"))     # K-splits of the direct (row-major) k5 wgrad; 0 disables it
 _WGRAD_WGS = int(os.environ.get("EFTS_WGRAD_WGS", "480"))   # split-K target: 480 workgroups per wgrad launch measured best (6.30 vs 6.60 ms/step at 640)
 
 
@@ -160,6 +161,15 @@ class TrainEngine:
         L.check(_lib().efts_wgrad_reduce(part.data_ptr(), S, _ptr(v), _ptr(g), out_dw.data_ptr(), _ptr(out_dg), cout, cin, taps,
                                          O._stream()), "efts_wgrad_reduce")
 
+    def _wgrad_tn(self, ws, dz_p: Plane, x_p: Plane, cout, cin, rows, v, g, out_dw, out_dg):
+        """k5 wgrad straight from the row-major bf16 planes (csrc/efts_wgrad.hip): no transposed copies"""
+        S = _WGRAD_TN_SPLITS
+        part = ws.get(("part", 5, S, cout, cin), lambda: torch.empty(5, S, cout, cin, device=self.dev))
+        L.check(_lib().efts_wgrad_tn(dz_p.ptr, dz_p.ld, x_p.ptr, x_p.ld, part.data_ptr(), rows, cout, cin, 5, S, dz_p.split, O._stream()),
+                "efts_wgrad_tn")
+        L.check(_lib().efts_wgrad_reduce(part.data_ptr(), S, _ptr(v), _ptr(g), out_dw.data_ptr(), _ptr(out_dg), cout, cin, 5,
+                                         O._stream()), "efts_wgrad_reduce")
+
     # ------------------------------------------------------------------ forward with saved activations
     def _stack_fwd(self, ws, tag, blk, pk, rs, x_f, x_p, gap_ptr, last_split):
         m, C = self.m, self.m.n_channels
@@ -172,7 +182,7 @@ class TrainEngine:
             o_p = ws.plane(f"T{tag}_p{i}", rs, C, last_split if last else m.split)
             O.gemm(a=x_p, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=5, m=rs.rows, n=C, act=L.ACT_LEAKY, slope=m.slope,
                    bias=layer.conv[0].bias, resid_ptr=x_f.ptr, ldr=C, rowmask_ptr=gap_ptr, out_f32_ptr=o_f.ptr, ldo=C, out_plane=o_p)
-            saved.append((x_f, o_f))
+            saved.append((x_f, o_f, x_p))
             x_f, x_p = o_f, o_p
         return x_f, x_p, saved
 
@@ -181,17 +191,19 @@ class TrainEngine:
         m, C = self.m, self.m.n_channels
         layers = getattr(m, blk).layers
         for i in reversed(range(len(layers))):
-            x_f, y_f = saved[i]
+            x_f, y_f, x_pl = saved[i]
             conv = layers[i].conv[0]
             pre = f"{blk}.layers.{i}.conv.0."
             dz_f = ws.f32(f"B{tag}_dz", rs, C)
             dz_p = ws.plane(f"B{tag}_dzp", rs, C, m.split)
             self._act_bwd(G.ptr, y_f.ptr, x_f.ptr, gap_ptr, 1, dz_f, dz_p, self.g[pre + "bias"], rs.rows, C)
-            if hasattr(conv, "weight_g"):
-                self._wgrad(ws, dz_f.ptr, C, x_f.ptr, C, C, 5, rs.rows, conv.weight_v.detach(), conv.weight_g.detach(),
-                            self.g[pre + "weight_v"], self.g[pre + "weight_g"])
+            wn = hasattr(conv, "weight_g")
+            v_, g_ = (conv.weight_v.detach(), conv.weight_g.detach()) if wn else (None, None)
+            dw_, dg_ = (self.g[pre + "weight_v"], self.g[pre + "weight_g"]) if wn else (self.g[pre + "weight"], None)
+            if _WGRAD_TN_SPLITS > 0 and C % 128 == 0 and x_pl.split == dz_p.split:
+                self._wgrad_tn(ws, dz_p, x_pl, C, C, rs.rows, v_, g_, dw_, dg_)
             else:
-                self._wgrad(ws, dz_f.ptr, C, x_f.ptr, C, C, 5, rs.rows, None, None, self.g[pre + "weight"], None)
+                self._wgrad(ws, dz_f.ptr, C, x_f.ptr, C, C, 5, rs.rows, v_, g_, dw_, dg_)
             wt = self.wt[f"{blk}.{i}"]
             Gn = ws.f32(f"B{tag}_G{i & 1}", rs, C)
             last = i == 0
