@@ -194,13 +194,16 @@ class TrainEngine:
             x_f, y_f, x_pl = saved[i]
             conv = layers[i].conv[0]
             pre = f"{blk}.layers.{i}.conv.0."
-            dz_f = ws.f32(f"B{tag}_dz", rs, C)
             dz_p = ws.plane(f"B{tag}_dzp", rs, C, m.split)
+            direct = _WGRAD_TN_SPLITS > 0 and C % 128 == 0 and x_pl.split == dz_p.split
+            # the direct wgrad and the dgrad both read dZ as the bf16 plane: its fp32 copy is only written for the
+            # transposed-plane path
+            dz_f = None if direct else ws.f32(f"B{tag}_dz", rs, C)
             self._act_bwd(G.ptr, y_f.ptr, x_f.ptr, gap_ptr, 1, dz_f, dz_p, self.g[pre + "bias"], rs.rows, C)
             wn = hasattr(conv, "weight_g")
             v_, g_ = (conv.weight_v.detach(), conv.weight_g.detach()) if wn else (None, None)
             dw_, dg_ = (self.g[pre + "weight_v"], self.g[pre + "weight_g"]) if wn else (self.g[pre + "weight"], None)
-            if _WGRAD_TN_SPLITS > 0 and C % 128 == 0 and x_pl.split == dz_p.split:
+            if direct:
                 self._wgrad_tn(ws, dz_p, x_pl, C, C, rs.rows, v_, g_, dw_, dg_)
             else:
                 self._wgrad(ws, dz_f.ptr, C, x_f.ptr, C, C, 5, rs.rows, v_, g_, dw_, dg_)
