@@ -228,6 +228,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //   dx = rstd (dyg - mean(dyg) - xhat mean(dyg xhat)), dyg = dy gamma ; dz = dx * [x > 0] * rowmask
 //   dgamma += dy xhat, dbeta += dy, dbias_conv += dz, (mode 1) dw += ddur * y, db += ddur
 // ---------------------------------------------------------------------------------------------
+#ifndef EFTS_LNB_ROWS
+#define EFTS_LNB_ROWS 8
+#endif
+constexpr int LNB_ROWS = EFTS_LNB_ROWS;    // rows per block: the duration predictor only has B*T1 (~4k) rows, 32 per block left half the CUs idle
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps,
                                                             const float* __restrict__ dy_in, const float* __restrict__ ddur,
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const float inv_keep = drop ? 1.f / (1.f - drop_p) : 1.f;
     float db_loc = 0.f;
     // each wave walks rows blockIdx.x*ROWS + wv, +4, ...
-    constexpr int ROWS = 32;
+    constexpr int ROWS = LNB_ROWS;
     for (int rr = wv; rr < ROWS; rr += 4) {
         const int row = blockIdx.x * ROWS + rr;
         if (row >= rows) break;
@@ -625,7 +629,7 @@ extern "C" int efts_layernorm_bwd(const float* x, const float* gamma, const floa
                                   uint32_t drop_seed, void* stream) {
     if (!x || !gamma || !beta || (!dy && !ddur) || (ddur && !w) || !dgamma || !dbeta) return efts_fail(EFTS_EINVAL, "efts_layernorm_bwd: null pointer");
     if (c % 256 || c > 2048) return efts_fail(EFTS_ESHAPE, "efts_layernorm_bwd: c must be a multiple of 256, <= 2048");
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + 31) / 32), dim3(256), (size_t)4 * c * sizeof(float), ST, x, gamma, beta, eps, dy, ddur, w,
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + LNB_ROWS - 1) / LNB_ROWS), dim3(256), (size_t)4 * c * sizeof(float), ST, x, gamma, beta, eps, dy, ddur, w,
                        rowmask, dz, (char*)plane, (long)ld_plane, split, dgamma, dbeta, dbias, dw, db, rows, c, drop_p, drop_seed);
     return efts_check_launch("efts_layernorm_bwd");
 }
