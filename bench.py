@@ -360,7 +360,9 @@ def main():
             traffic = json.load(open(tf)).get(f"{a.precision}:{a.workload}")
         except Exception:
             traffic = None
-    roof = dict(bound="mfma", kernel=f"gemm_kernel<taps=5,split={model.split}> (k5 Conv1d 512->512, {B}x{T2} frames)",
+    big = model.split == 1 and ((B * (T2 + 2) + 251) // 252) * 4 >= 512      # efts_gemm's own rule for the 256-row kernel
+    kname = "conv5_kernel<split=1> (256-row tiles)" if big else f"gemm_kernel<taps=5,split={model.split}> (124-row tiles)"
+    roof = dict(bound="mfma", kernel=f"{kname}: k5 Conv1d 512->512, {B}x{T2} frames",
                 achieved=conv_flop / avg / 1e12, peak=PEAK_MFMA_BF16_TFLOPS, unit="TFLOP/s",
                 frac=conv_flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS, traffic=traffic,
                 avg_launch_us=avg * 1e6, launches_measured=n_launch, algorithmic_flop_per_launch=conv_flop,

@@ -223,3 +223,31 @@ def test_odd_shapes_and_ragged_lengths_vs_oracle(model, B, T1, T2, tl, sl):
     assert float((ralpha.cpu() - o["reconst_alpha"]).abs().max()) <= 1e-3
     assert float((imv.cpu() - o["imv"]).abs().max()) <= 2e-3
     assert abs(float(loss) - float(o["loss"])) <= 2e-4 * float(o["loss"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_conv5_kernel_equals_gemm_kernel(golden_dir, precision, monkeypatch):
+    """The 256-row k5 kernel (conv5_kernel, used for large launches) against the 124-row gemm_kernel on the same
+    batch: identical summation order per output element, so the results must agree to the last bits; plus the
+    golden / oracle gate of the active mode.  EFTS_CONV5 is read per launch: 1 forces the 256-row kernel, 0 disables it."""
+    g = np.load(os.path.join(golden_dir, "fwd_full.npz"))
+    args = [torch.from_numpy(g[k]).cuda() for k in ("text", "text_lengths", "speech", "speech_lengths")]
+    from efficient_tts_amd import EfficientTTSCNN
+    m = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, sigma=0.01, precision=precision)
+    m.load_state_dict(O.fill_params())
+    m = m.cuda().eval()
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("EFTS_CONV5", flag)
+        with torch.no_grad():
+            o = m(*args)
+        torch.cuda.synchronize()
+        outs[flag] = (float(o[0]), o[4].clone(), o[3].clone())
+    monkeypatch.delenv("EFTS_CONV5")
+    assert (outs["0"][1] - outs["1"][1]).abs().max().item() <= 1e-6
+    assert (outs["0"][2] - outs["1"][2]).abs().max().item() <= 1e-6
+    assert abs(outs["0"][0] - outs["1"][0]) <= 1e-6 * abs(outs["0"][0])
+    if precision == "bf16x3":
+        stride = int(g["mel_pred_stride"])
+        assert np.abs(outs["1"][1].cpu().numpy()[:, ::stride] - g["mel_pred"]).max() <= 1e-3
