@@ -360,7 +360,7 @@ def main():
             traffic = json.load(open(tf)).get(f"{a.precision}:{a.workload}")
         except Exception:
             traffic = None
-    big = model.split == 1 and ((B * (T2 + 2) + 251) // 252) * 4 >= 512      # efts_gemm's own rule for the 256-row kernel
+    big = model.split == 1 and ((B * (T2 + 2) + 251) // 252) * 4 >= 400      # efts_gemm's own rule for the 256-row kernel
     kname = "conv5_kernel<split=1> (256-row tiles)" if big else f"gemm_kernel<taps=5,split={model.split}> (124-row tiles)"
     roof = dict(bound="mfma", kernel=f"{kname}: k5 Conv1d 512->512, {B}x{T2} frames",
                 achieved=conv_flop / avg / 1e12, peak=PEAK_MFMA_BF16_TFLOPS, unit="TFLOP/s",

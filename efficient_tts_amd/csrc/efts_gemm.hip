@@ -456,7 +456,7 @@ constexpr int C5_WIN = 256;
 constexpr int C5_BM = C5_WIN - 4;
 constexpr int C5_A_BYTES = C5_WIN * 128;                       // 32768
 constexpr int C5_LDS = C5_A_BYTES + NST * TILE_BYTES;          // 81920
-constexpr long C5_DEFAULT_MIN_TILES = 512;                     // bf16 planes only by default (measured +1.5 % there, -2.5 % on bf16x3)
+constexpr long C5_DEFAULT_MIN_TILES = 400;                     // bf16 planes only by default (measured +1.5 % there, -2.5 % on bf16x3)
 
 template <int SPLIT>
 __global__ __launch_bounds__(256, 2) void conv5_kernel(GemmKernelArgs p) {
