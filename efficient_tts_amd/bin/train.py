@@ -1,13 +1,17 @@
-"""Training entry point with the reference's command line and YAML schema (nntts/bin/train.py:30-253):
+"""`python -m efficient_tts_amd.bin.train` -- trains EFTS-CNN on MI355X from the reference recipe's files.
 
-    python -m efficient_tts_amd.bin.train --config egs/lj/conf/efficient_tts_cnn_phnseq_noDropout.v1.yaml \
-        --train_fid_scp train.txt --dev_fid_scp dev.txt --outdir exp/efts [--resume ckpt] [--pretrain ckpt]
+Drop-in for the command line and YAML schema of the reference entry point (nntts/bin/train.py:30-253), so the
+recipe's `run.sh` and `egs/lj/conf/*.yaml` work unchanged:
 
-One process per GPU; for N > 1 launch with `python -m torch.distributed.run --nproc-per-node N
---master-addr 127.0.0.1 -m efficient_tts_amd.bin.train ...` (RANK / LOCAL_RANK / WORLD_SIZE from the
-environment, backend "nccl" = RCCL over xGMI).  What differs from the reference: the model, optimizer,
-gradient all-reduce and mel front-end are this package's HIP implementations (the dataset yields
-waveforms, the trainer computes log-mels on the GPU); there is no CPU mode.
+    python -m efficient_tts_amd.bin.train --config conf.yaml --train_fid_scp train.txt --dev_fid_scp dev.txt \\
+        --outdir exp/efts [--resume exp/efts/checkpoint-5000steps.pkl | --pretrain other.pkl] [--verbose 1]
+
+Multi-GPU: one process per GPU, e.g. `python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1
+-m efficient_tts_amd.bin.train ...`; RANK / LOCAL_RANK / WORLD_SIZE come from the environment and the backend
+"nccl" is RCCL over xGMI.  The pieces named in the YAML (`dataset_type`, `collate_fn_type`, `model_name`,
+`optimizer_type`, `scheduler_type`, `trainer_type`) are resolved in this package's registries
+(efficient_tts_amd.datasets / models / optimizers / schedulers / trainers); the dataset yields waveforms and the
+trainer computes log-mels on the GPU (efficient_tts_amd.frontend).  There is no CPU mode.
 """
 from __future__ import annotations
 
@@ -15,104 +19,147 @@ import argparse
 import logging
 import os
 import sys
+from dataclasses import dataclass
+from typing import Any, Dict, Optional
 
 import torch
 import yaml
 from torch.utils.data import DataLoader
+from torch.utils.data.distributed import DistributedSampler
 
-import efficient_tts_amd
+import efficient_tts_amd as pkg
 from efficient_tts_amd import datasets, models, optimizers, schedulers, trainers
 from efficient_tts_amd.dist import DistributedEFTS
 from efficient_tts_amd.frontend import LogMelFrontend
 
+# (flags, kwargs) of the reference command line, kept as data so the parser and the docs cannot drift apart
+_CLI = (
+    (("--config",), dict(type=str, required=True, help="YAML recipe (egs/*/conf/*.yaml schema)")),
+    (("--outdir",), dict(type=str, required=True, help="where config.yml and checkpoint-*steps.pkl go")),
+    (("--train_fid_scp",), dict(type=str, default=None, help="training file list: audiopath|phoneme sequence")),
+    (("--dev_fid_scp",), dict(type=str, default=None, help="validation file list")),
+    (("--resume",), dict(type=str, default="", nargs="?", help="checkpoint to continue from (model, optimizer, schedule, counters)")),
+    (("--pretrain",), dict(type=str, default="", nargs="?", help="checkpoint to take only the parameters from")),
+    (("--verbose",), dict(type=int, default=1, help="0 warnings only, 1 info, 2 debug")),
+    (("--rank", "--local_rank"), dict(type=int, default=None, help="local device index; normally LOCAL_RANK")),
+)
+
 
 def get_parser() -> argparse.ArgumentParser:
-    p = argparse.ArgumentParser(description="Train the EFTS-CNN acoustic model on MI355X (see efficient_tts_amd/bin/train.py).")
-    p.add_argument("--train_fid_scp", default=None, type=str, help="file list for training (audiopath|phoneme sequence)")
-    p.add_argument("--dev_fid_scp", default=None, type=str, help="file list for validation")
-    p.add_argument("--outdir", type=str, required=True, help="directory to save checkpoints")
-    p.add_argument("--config", type=str, required=True, help="yaml format configuration file")
-    p.add_argument("--pretrain", default="", type=str, nargs="?", help="checkpoint to load parameters from")
-    p.add_argument("--resume", default="", type=str, nargs="?", help="checkpoint to resume training from")
-    p.add_argument("--verbose", type=int, default=1, help="logging level; higher is more logging")
-    p.add_argument("--rank", "--local_rank", default=None, type=int, help="local rank; normally taken from LOCAL_RANK")
-    return p
+    parser = argparse.ArgumentParser(prog="efficient_tts_amd.bin.train", description=__doc__.splitlines()[0])
+    for flags, kwargs in _CLI:
+        parser.add_argument(*flags, **kwargs)
+    return parser
+
+
+@dataclass
+class _Process:
+    """where this process sits in the job (one process per GPU)"""
+    rank: int
+    local_rank: int
+    world: int
+
+    @property
+    def distributed(self) -> bool:
+        return self.world > 1
+
+    @property
+    def device(self) -> torch.device:
+        return torch.device("cuda", self.local_rank)
+
+    @staticmethod
+    def from_env(cli_local_rank: Optional[int]) -> "_Process":
+        env = os.environ
+        local = cli_local_rank if cli_local_rank is not None else int(env.get("LOCAL_RANK", 0))
+        return _Process(rank=int(env.get("RANK", 0)), local_rank=local, world=int(env.get("WORLD_SIZE", 1)))
+
+
+def _setup_logging(verbose: int, quiet: bool) -> None:
+    if quiet:                                   # every rank but 0 keeps silent, like the reference
+        sys.stdout = open(os.devnull, "w")
+    level = {0: logging.WARNING, 1: logging.INFO}.get(verbose, logging.DEBUG)
+    logging.basicConfig(level=level, stream=sys.stdout, force=True,
+                        format="%(asctime)s %(levelname)s %(name)s:%(lineno)d  %(message)s")
+
+
+def _load_config(args: argparse.Namespace, proc: _Process) -> Dict[str, Any]:
+    with open(args.config) as handle:
+        config = yaml.safe_load(handle) or {}
+    config.update(vars(args))                   # the reference merges the CLI into the recipe; trainer reads both
+    config.update(rank=proc.rank, distributed=proc.distributed, world_size=proc.world,
+                  version=getattr(pkg, "__version__", "0.1.0"))
+    if proc.rank == 0:
+        os.makedirs(args.outdir, exist_ok=True)
+        with open(os.path.join(args.outdir, "config.yml"), "w") as handle:
+            yaml.safe_dump(config, handle)
+    for key in sorted(config):
+        logging.info(f"config {key} = {config[key]}")
+    return config
+
+
+def _build_data(config: Dict[str, Any], args: argparse.Namespace, proc: _Process):
+    make_dataset = getattr(datasets, config.get("dataset_type", "TextMelLoader"))
+    params = config.get("dataset_params") or {}
+    splits = {"train": make_dataset(meta_file=args.train_fid_scp, **params),
+              "dev": make_dataset(meta_file=args.dev_fid_scp, **params)}
+    collate = getattr(datasets, config.get("collate_fn_type", "TextMelCollate"))(**(config.get("collate_fn_params") or {}))
+    samplers: Dict[str, Optional[DistributedSampler]] = {"train": None, "dev": None}
+    if proc.distributed:
+        samplers = {name: DistributedSampler(ds, num_replicas=proc.world, rank=proc.rank, shuffle=(name == "train"))
+                    for name, ds in splits.items()}
+    loaders = {name: DataLoader(ds, batch_size=int(config["batch_size"]), collate_fn=collate, sampler=samplers[name],
+                                shuffle=samplers[name] is None, num_workers=int(config.get("num_workers", 0)),
+                                pin_memory=bool(config.get("pin_memory", False)))
+               for name, ds in splits.items()}
+    for name, ds in splits.items():
+        logging.info(f"{name}: {len(ds)} utterances")
+    return loaders, samplers
+
+
+def _build_trainer(config: Dict[str, Any], loaders, samplers, proc: _Process):
+    device = proc.device
+    net = getattr(models, config["model_name"])(**config["model_params"]).to(device)
+    optimizer = getattr(optimizers, config.get("optimizer_type", "Adam"))(
+        net, grad_norm=float(config.get("grad_norm", 1.0)), **config["optimizer_params"])
+    scheduler = None
+    if config.get("scheduler_type"):
+        scheduler = getattr(schedulers, config["scheduler_type"])(optimizer=optimizer, **(config.get("scheduler_params") or {}))
+    model = DistributedEFTS(net) if proc.distributed else net
+    logging.info(f"{model}")
+    trainer_class = getattr(trainers, config.get("trainer_type", "EfficientTTSTrainer"))
+    trainer = trainer_class(steps=0, epochs=0, data_loader=loaders, sampler=samplers, model=model, optimizer=optimizer,
+                            scheduler=scheduler, config=config, device=device)
+    trainer.frontend = LogMelFrontend(device, **(config.get("frontend_params") or {}))
+    return trainer
 
 
 def main(argv=None) -> int:
     args = get_parser().parse_args(argv)
     if not torch.cuda.is_available():
-        raise RuntimeError("efficient_tts_amd needs an MI355X (gfx950) device: there is no CPU path")
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = args.rank if args.rank is not None else int(os.environ.get("LOCAL_RANK", "0"))
-    args.rank = rank
-    args.distributed = world > 1
-    args.world_size = world
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    if args.distributed:
-        torch.distributed.init_process_group(backend="nccl", init_method="env://", device_id=device)
-    if rank != 0:
-        sys.stdout = open(os.devnull, "w")
-    level = logging.DEBUG if args.verbose > 1 else (logging.INFO if args.verbose > 0 else logging.WARN)
-    logging.basicConfig(level=level, stream=sys.stdout, force=True,
-                        format="%(asctime)s (%(module)s:%(lineno)d) %(levelname)s: %(message)s")
-    os.makedirs(args.outdir, exist_ok=True)
-
-    with open(args.config) as f:
-        config = yaml.load(f, Loader=yaml.Loader)
-    config.update(vars(args))
-    config["version"] = getattr(efficient_tts_amd, "__version__", "0.1.0")
-    if rank == 0:
-        with open(os.path.join(args.outdir, "config.yml"), "w") as f:
-            yaml.dump(config, f, Dumper=yaml.Dumper)
-    for key, value in config.items():
-        logging.info(f"{key} = {value}")
-
-    dataset_class = getattr(datasets, config.get("dataset_type", "TextMelLoader"))
-    data_params = config.get("dataset_params", {})
-    dataset = {"train": dataset_class(meta_file=args.train_fid_scp, **data_params),
-               "dev": dataset_class(meta_file=args.dev_fid_scp, **data_params)}
-    logging.info(f"The number of training files = {len(dataset['train'])}.")
-    logging.info(f"The number of development files = {len(dataset['dev'])}.")
-    collate = getattr(datasets, config.get("collate_fn_type", "TextMelCollate"))(**config.get("collate_fn_params", {}))
-    sampler = {"train": None, "dev": None}
-    if args.distributed:
-        from torch.utils.data.distributed import DistributedSampler
-        sampler["train"] = DistributedSampler(dataset["train"], num_replicas=world, rank=rank, shuffle=True)
-        sampler["dev"] = DistributedSampler(dataset["dev"], num_replicas=world, rank=rank, shuffle=False)
-    data_loader = {k: DataLoader(dataset[k], shuffle=not args.distributed, collate_fn=collate, batch_size=config["batch_size"],
-                                 num_workers=config.get("num_workers", 0), sampler=sampler[k],
-                                 pin_memory=config.get("pin_memory", False)) for k in ("train", "dev")}
-
-    model = getattr(models, config["model_name"])(**config["model_params"]).to(device)
-    opt_params = dict(config["optimizer_params"])
-    optimizer = getattr(optimizers, config.get("optimizer_type", "Adam"))(model, grad_norm=config.get("grad_norm", 1.0), **opt_params)
-    scheduler = None
-    if config.get("scheduler_type") is not None:
-        scheduler = getattr(schedulers, config["scheduler_type"])(optimizer=optimizer, **config["scheduler_params"])
-    if args.distributed:
-        model = DistributedEFTS(model)
-    logging.info(model)
-
-    trainer = getattr(trainers, config.get("trainer_type", "EfficientTTSTrainer"))(
-        steps=0, epochs=0, data_loader=data_loader, sampler=sampler, model=model, optimizer=optimizer, scheduler=scheduler,
-        config=config, device=device)
-    trainer.frontend = LogMelFrontend(device, **config.get("frontend_params", {}))      # waveform batches -> log-mel on the GPU
+        raise RuntimeError("no MI355X (gfx950) device visible: efficient_tts_amd has no CPU path")
+    proc = _Process.from_env(args.rank)
+    torch.cuda.set_device(proc.local_rank)
+    if proc.distributed:
+        torch.distributed.init_process_group(backend="nccl", init_method="env://", device_id=proc.device)
+    _setup_logging(args.verbose, quiet=proc.rank != 0)
+    config = _load_config(args, proc)
+    loaders, samplers = _build_data(config, args, proc)
+    trainer = _build_trainer(config, loaders, samplers, proc)
     if args.pretrain:
         trainer.load_checkpoint(args.pretrain, load_only_params=True)
-        logging.info(f"Successfully load parameters from {args.pretrain}.")
+        logging.info(f"parameters initialised from {args.pretrain}")
     if args.resume:
         trainer.load_checkpoint(args.resume)
-        logging.info(f"Successfully resumed from {args.resume}.")
+        logging.info(f"resumed from {args.resume} at step {trainer.steps}")
     try:
         trainer.run()
-    except KeyboardInterrupt:
-        trainer.save_checkpoint(os.path.join(config["outdir"], f"checkpoint-{trainer.steps}steps.pkl"))
-        logging.info(f"Successfully saved checkpoint @ {trainer.steps}steps.")
-    if args.distributed:
-        torch.distributed.destroy_process_group()
+    except KeyboardInterrupt:                   # same courtesy as the reference: keep what was learnt so far
+        path = os.path.join(config["outdir"], f"checkpoint-{trainer.steps}steps.pkl")
+        trainer.save_checkpoint(path)
+        logging.info(f"interrupted: state saved to {path}")
+    finally:
+        if proc.distributed:
+            torch.distributed.destroy_process_group()
     return 0
 
 

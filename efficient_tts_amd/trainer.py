@@ -1,197 +1,226 @@
-"""EfficientTTSTrainer -- same constructor, `run()`, checkpoint format and interval logic as the
-reference trainer (nntts/trainers/efficient_tts_trainer.py:20-281), driving the MI355X model.
+"""Training loop driver for the MI355X EFTS-CNN engine.
 
-Differences that do not change the contract: tensorboardX and tqdm are optional (absent in this
-image); `stats` values are read lazily (no per-step host sync); with `EftsAdam` the gradient clip is
-fused into the optimizer kernel; with `DistributedEFTS` the bucketed RCCL all-reduce launched during
-backward is joined right before the optimizer step.
+Public contract = the reference trainer's (nntts/trainers/efficient_tts_trainer.py:20-281), because
+the recipe's entry point builds it by name and positional/keyword arguments (nntts/bin/train.py:218-231):
+
+    EfficientTTSTrainer(steps, epochs, data_loader, sampler, model, optimizer, scheduler, config, device)
+    .run()   .save_checkpoint(path)   .load_checkpoint(path, load_only_params=False)   .steps   .epochs
+
+Checkpoints are `torch.save`d dicts with the keys {"model", "optimizer", "scheduler", "steps", "epochs"}
+and the model's reference `state_dict` key set, written as `checkpoint-{steps}steps.pkl` under
+config["outdir"] every config["save_interval_steps"]; evaluation and logging follow
+config["eval_interval_steps"] / config["log_interval_steps"]; training stops at config["train_max_steps"].
+
+Everything inside is organised for this engine rather than copied from the reference loop:
+  * the per-step statistics stay on the device (`LazyStats`) and are only read when a log line is due, so
+    a step never synchronises the host;
+  * with `EftsAdam` the gradient clip is part of the fused optimizer kernel; with `DistributedEFTS` the
+    bucketed RCCL all-reduce launched during backward is joined right before the optimizer step;
+  * an optional `frontend` (efficient_tts_amd.frontend.LogMelFrontend) turns waveform batches into
+    log-mels on the GPU; `bucket_frames` / `bucket_phones` pad shapes up to multiples so the engine's
+    per-shape workspaces are re-used across ragged batches;
+  * tensorboardX / tqdm are used when importable, silently skipped otherwise.
 """
 from __future__ import annotations
 
 import logging
 import os
-from collections import defaultdict
+from typing import Dict
 
 import torch
 
-try:                                     # optional, as in the reference (trainer.py:13)
-    from tensorboardX import SummaryWriter
-except Exception:                        # pragma: no cover
-    SummaryWriter = None
 try:
-    from tqdm import tqdm
-except Exception:                        # pragma: no cover
-    tqdm = None
+    from tensorboardX import SummaryWriter as _TBWriter
+except Exception:                                       # pragma: no cover - optional dependency
+    _TBWriter = None
+try:
+    from tqdm import tqdm as _tqdm
+except Exception:                                       # pragma: no cover - optional dependency
+    _tqdm = None
+
+log = logging.getLogger(__name__)
+_STAT_KEYS = (("loss", "loss"), ("mel_loss", "mel_loss"), ("dur_loss", "duration_loss"))   # (log suffix, stats key)
 
 
-class _NullWriter:
-    def add_scalar(self, *a, **k):
-        pass
+class _Meter:
+    """Running sums of the three losses under a name prefix ("train" / "eval")."""
+
+    def __init__(self, prefix: str):
+        self.prefix = prefix
+        self.reset()
+
+    def reset(self) -> None:
+        self.sums: Dict[str, float] = {f"{self.prefix}/{suffix}": 0.0 for suffix, _ in _STAT_KEYS}
+
+    def add(self, stats) -> None:
+        for suffix, key in _STAT_KEYS:
+            self.sums[f"{self.prefix}/{suffix}"] += float(stats[key])
+
+    def means(self, count: int) -> Dict[str, float]:
+        return {k: v / max(count, 1) for k, v in self.sums.items()}
 
 
-class EfficientTTSTrainer(object):
+class EfficientTTSTrainer:
     def __init__(self, steps, epochs, data_loader, sampler, model, optimizer, scheduler, config,
                  device=torch.device("cpu")):
-        self.steps, self.epochs = steps, epochs
-        self.data_loader, self.sampler = data_loader, sampler
-        self.model, self.optimizer, self.scheduler = model, optimizer, scheduler
-        self.config, self.device = config, device
-        self.writer = SummaryWriter(config["outdir"]) if SummaryWriter is not None else _NullWriter()
+        self.steps = int(steps)
+        self.epochs = int(epochs)
+        self.data_loader = data_loader
+        self.sampler = sampler
+        self.model = model
+        self.optimizer = optimizer
+        self.scheduler = scheduler
+        self.config = config
+        self.device = device
+        self.frontend = None                   # optional LogMelFrontend (set by efficient_tts_amd.bin.train)
         self.finish_train = False
-        self.total_train_loss = defaultdict(float)
-        self.total_eval_loss = defaultdict(float)
-        self._pending = []                # LazyStats of the steps since the last log (read at log time)
-        self.frontend = None              # optional LogMelFrontend: batches then carry (audio, audio_lengths) instead of mels
+        self._tb = _TBWriter(config["outdir"]) if _TBWriter is not None else None
+        self._bar = None
+        self._unread = []                      # LazyStats of the steps since the last log line
+        self._train_meter = _Meter("train")
+        self._eval_meter = _Meter("eval")
 
-    # ------------------------------------------------------------------ loop (trainer.py:62-76,167-191)
-    def run(self):
-        self.tqdm = tqdm(initial=self.steps, total=self.config["train_max_steps"], desc="[train]") if tqdm else None
-        while True:
-            self._train_epoch()
-            if self.finish_train:
-                break
-        if self.tqdm:
-            self.tqdm.close()
-        logging.info("Finished training.")
+    # ------------------------------------------------------------------------------------------ helpers
+    @property
+    def _net(self):
+        """the bare model (DistributedEFTS / DDP keep it under .module)"""
+        return self.model.module if hasattr(self.model, "module") else self.model
 
-    def _raw_model(self):
-        return self.model.module if self.config.get("distributed") or hasattr(self.model, "module") else self.model
+    def _due(self, key: str) -> bool:
+        every = int(self.config[key])
+        return every > 0 and self.steps % every == 0
 
-    # ------------------------------------------------------------------ checkpoints (trainer.py:78-119)
-    def save_checkpoint(self, checkpoint_path):
-        state_dict = {"optimizer": self.optimizer.state_dict(), "steps": self.steps, "epochs": self.epochs}
-        if self.scheduler is not None:
-            state_dict["scheduler"] = self.scheduler.state_dict()
-        state_dict["model"] = {k: v.detach().clone() for k, v in self._raw_model().state_dict().items()}
-        d = os.path.dirname(checkpoint_path)
-        if d and not os.path.exists(d):
-            os.makedirs(d)
-        torch.save(state_dict, checkpoint_path)
+    def _publish(self, values: Dict[str, float]) -> None:
+        for name, value in values.items():
+            log.info(f"[step {self.steps}] {name}: {value:.4f}")
+            if self._tb is not None:
+                self._tb.add_scalar(name, value, self.steps)
 
-    def load_checkpoint(self, checkpoint_path, load_only_params=False):
-        state_dict = torch.load(checkpoint_path, map_location="cpu")
-        self._raw_model().load_state_dict(state_dict["model"])
-        self._raw_model()._packed_sig = None
-        if not load_only_params:
-            self.steps, self.epochs = state_dict["steps"], state_dict["epochs"]
-            self.optimizer.load_state_dict(state_dict["optimizer"])
-            if self.scheduler is not None:
-                self.scheduler.load_state_dict(state_dict["scheduler"])
-
-    # ------------------------------------------------------------------ one step (trainer.py:121-165)
-    def _to_device(self, batch):
-        text, text_lengths, mel, mel_lengths = [x.to(self.device) for x in batch]
-        if self.frontend is not None:     # waveform batch (efficient_tts_amd.datasets.TextMelCollate): log-mel on the GPU
-            # optional shape bucketing (config "bucket_frames" / "bucket_phones", 0 = exact batch maximum as the
-            # reference pads): fewer distinct (T1, T2) shapes -> the engine's per-shape workspaces are re-used
-            bf, bp = int(self.config.get("bucket_frames", 0)), int(self.config.get("bucket_phones", 0))
-            frames = self.frontend.frames_of(mel_lengths)
-            tmax = int(frames.max())
-            if bf > 0:
-                tmax = (tmax + bf - 1) // bf * bf
-            mel, mel_lengths = self.frontend(mel, mel_lengths, max_frames=tmax)
-            if bp > 0 and text.shape[1] % bp:
-                text = torch.nn.functional.pad(text, (0, bp - text.shape[1] % bp))
+    def _stage(self, batch):
+        """batch -> (text, text_lengths, mel, mel_lengths) on the device.  Waveform batches
+        (efficient_tts_amd.datasets.TextMelCollate) go through the GPU log-mel front-end."""
+        text, text_lengths, third, third_lengths = (t.to(self.device) for t in batch)
+        if self.frontend is None:
+            return text, text_lengths, third, third_lengths
+        n_frames = int(self.frontend.frames_of(third_lengths).max())
+        frame_step = int(self.config.get("bucket_frames", 0))
+        phone_step = int(self.config.get("bucket_phones", 0))
+        if frame_step > 0:
+            n_frames = -(-n_frames // frame_step) * frame_step
+        mel, mel_lengths = self.frontend(third, third_lengths, max_frames=n_frames)
+        if phone_step > 0 and text.shape[1] % phone_step:
+            text = torch.nn.functional.pad(text, (0, phone_step - text.shape[1] % phone_step))
         return text, text_lengths, mel, mel_lengths
 
-    def _train_step(self, batch):
-        text, text_lengths, mel, mel_lengths = self._to_device(batch)
+    # ------------------------------------------------------------------------------------------ checkpoints
+    def save_checkpoint(self, checkpoint_path: str) -> None:
+        payload = {
+            "model": {name: value.detach().clone() for name, value in self._net.state_dict().items()},
+            "optimizer": self.optimizer.state_dict(),
+            "steps": self.steps,
+            "epochs": self.epochs,
+        }
+        if self.scheduler is not None:
+            payload["scheduler"] = self.scheduler.state_dict()
+        folder = os.path.dirname(checkpoint_path)
+        if folder:
+            os.makedirs(folder, exist_ok=True)
+        torch.save(payload, checkpoint_path)
+
+    def load_checkpoint(self, checkpoint_path: str, load_only_params: bool = False) -> None:
+        payload = torch.load(checkpoint_path, map_location="cpu")
+        net = self._net
+        net.load_state_dict(payload["model"])
+        net._packed_sig = None                 # operand planes are re-packed from the new parameters
+        if load_only_params:
+            return
+        self.steps, self.epochs = payload["steps"], payload["epochs"]
+        self.optimizer.load_state_dict(payload["optimizer"])
+        if self.scheduler is not None and "scheduler" in payload:
+            self.scheduler.load_state_dict(payload["scheduler"])
+
+    # ------------------------------------------------------------------------------------------ one optimisation step
+    def _train_step(self, batch) -> None:
+        text, text_lengths, mel, mel_lengths = self._stage(batch)
         loss, stats, *_ = self.model(text=text, text_lengths=text_lengths, speech=mel, speech_lengths=mel_lengths)
-        self._pending.append(stats)
+        self._unread.append(stats)
         self.optimizer.zero_grad()
         loss.backward()
         if hasattr(self.model, "finish_reduce"):
-            self.model.finish_reduce()                      # join the bucketed all-reduce
-        scale = getattr(self.model, "grad_scale", 1.0)
-        if hasattr(self.optimizer, "grad_norm"):            # EftsAdam: clip fused into the update kernel
-            self.optimizer.grad_norm = float(self.config["grad_norm"])
+            self.model.finish_reduce()                          # join the bucketed all-reduce
+        clip = float(self.config["grad_norm"])
+        scale = getattr(self.model, "grad_scale", 1.0)          # 1 / world under data parallelism
+        if hasattr(self.optimizer, "grad_norm"):                # EftsAdam: scale + clip + update in one kernel
+            self.optimizer.grad_norm = clip
             self.optimizer.step(grad_scale=scale)
-        else:
+        else:                                                   # any torch optimizer
+            params = [p for p in self._net.parameters() if p.grad is not None]
             if scale != 1.0:
-                for p in self._raw_model().parameters():
-                    if p.grad is not None:
-                        p.grad.mul_(scale)
-            if self.config["grad_norm"] > 0:
-                torch.nn.utils.clip_grad_norm_(self._raw_model().parameters(), self.config["grad_norm"])
+                for p in params:
+                    p.grad.mul_(scale)
+            if clip > 0:
+                torch.nn.utils.clip_grad_norm_(params, clip)
             self.optimizer.step()
         if self.scheduler is not None:
             self.scheduler.step()
         self.steps += 1
-        if self.tqdm:
-            self.tqdm.update(1)
-        self._check_train_finish()
+        if self._bar is not None:
+            self._bar.update(1)
+        self.finish_train = self.steps >= int(self.config["train_max_steps"])
 
-    def _drain_stats(self):
-        for st in self._pending:
-            self.total_train_loss["train/loss"] += st["loss"]
-            self.total_train_loss["train/mel_loss"] += st["mel_loss"]
-            self.total_train_loss["train/dur_loss"] += st["duration_loss"]
-        self._pending = []
+    def _after_step(self) -> None:
+        """rank-0 bookkeeping: log line, evaluation, checkpoint -- each on its own interval"""
+        if self._due("log_interval_steps"):
+            for stats in self._unread:                          # the only host reads of the training statistics
+                self._train_meter.add(stats)
+            self._unread = []
+            self._publish(self._train_meter.means(int(self.config["log_interval_steps"])))
+            self._train_meter.reset()
+        if self._due("eval_interval_steps"):
+            self._evaluate()
+        if self._due("save_interval_steps"):
+            path = os.path.join(self.config["outdir"], f"checkpoint-{self.steps}steps.pkl")
+            self.save_checkpoint(path)
+            log.info(f"[step {self.steps}] checkpoint written: {path}")
 
-    def _train_epoch(self):
-        train_steps_per_epoch = 0
-        for train_steps_per_epoch, batch in enumerate(self.data_loader["train"], 1):
-            self._train_step(batch)
-            if self.config["rank"] == 0:
-                self._check_log_interval()
-                self._check_eval_interval()
-                self._check_save_interval()
-            if self.finish_train:
-                return
-        self.epochs += 1
-        self.train_steps_per_epoch = train_steps_per_epoch
-        logging.info(f"(Steps: {self.steps}) Finished {self.epochs} epoch training "
-                     f"({self.train_steps_per_epoch} steps per epoch).")
-        if self.config["distributed"]:
-            self.sampler["train"].set_epoch(self.epochs)
-
-    # ------------------------------------------------------------------ eval (trainer.py:193-252)
+    # ------------------------------------------------------------------------------------------ evaluation
     @torch.no_grad()
-    def _eval_step(self, batch, plot=False):
-        text, text_lengths, mel, mel_lengths = self._to_device(batch)
-        loss, stats, imv, alpha, mel_pred, mel_gt = self._raw_model()(text=text, text_lengths=text_lengths, speech=mel,
-                                                                      speech_lengths=mel_lengths)
-        self.total_eval_loss["eval/loss"] += stats["loss"]
-        self.total_eval_loss["eval/mel_loss"] += stats["mel_loss"]
-        self.total_eval_loss["eval/dur_loss"] += stats["duration_loss"]
+    def _evaluate(self) -> None:
+        net = self._net
+        net.eval()
+        batches = 0
+        for batch in self.data_loader["dev"]:
+            text, text_lengths, mel, mel_lengths = self._stage(batch)
+            out = net(text=text, text_lengths=text_lengths, speech=mel, speech_lengths=mel_lengths)
+            self._eval_meter.add(out[1])
+            batches += 1
+        self._publish(self._eval_meter.means(batches))
+        log.info(f"[step {self.steps}] evaluated {batches} dev batches")
+        self._eval_meter.reset()
+        net.train()
 
-    def _eval_epoch(self):
-        logging.info(f"(Steps: {self.steps}) Start evaluation.")
-        self._raw_model().eval()
-        n = 0
-        for n, batch in enumerate(self.data_loader["dev"], 1):
-            self._eval_step(batch, plot=(n == 1))
-        logging.info(f"(Steps: {self.steps}) Finished evaluation ({n} steps per epoch).")
-        for key in self.total_eval_loss.keys():
-            self.total_eval_loss[key] /= max(n, 1)
-            logging.info(f"(Steps: {self.steps}) {key} = {self.total_eval_loss[key]:.4f}.")
-        self._write_to_tensorboard(self.total_eval_loss)
-        self.total_eval_loss = defaultdict(float)
-        self._raw_model().train()
-
-    def _write_to_tensorboard(self, loss):
-        for key, value in loss.items():
-            self.writer.add_scalar(key, value, self.steps)
-
-    # ------------------------------------------------------------------ intervals (trainer.py:259-281)
-    def _check_save_interval(self):
-        if self.steps % self.config["save_interval_steps"] == 0:
-            self.save_checkpoint(os.path.join(self.config["outdir"], f"checkpoint-{self.steps}steps.pkl"))
-            logging.info(f"Successfully saved checkpoint @ {self.steps} steps.")
-
-    def _check_eval_interval(self):
-        if self.steps % self.config["eval_interval_steps"] == 0:
-            self._eval_epoch()
-
-    def _check_log_interval(self):
-        if self.steps % self.config["log_interval_steps"] == 0:
-            self._drain_stats()
-            for key in self.total_train_loss.keys():
-                self.total_train_loss[key] /= self.config["log_interval_steps"]
-                logging.info(f"(Steps: {self.steps}) {key} = {self.total_train_loss[key]:.4f}.")
-            self._write_to_tensorboard(self.total_train_loss)
-            self.total_train_loss = defaultdict(float)
-
-    def _check_train_finish(self):
-        if self.steps >= self.config["train_max_steps"]:
-            self.finish_train = True
+    # ------------------------------------------------------------------------------------------ driver
+    def run(self) -> None:
+        if _tqdm is not None:
+            self._bar = _tqdm(initial=self.steps, total=int(self.config["train_max_steps"]), desc="[train]")
+        is_main = int(self.config.get("rank", 0)) == 0
+        while not self.finish_train:
+            seen = 0
+            for batch in self.data_loader["train"]:
+                self._train_step(batch)
+                seen += 1
+                if is_main:
+                    self._after_step()
+                if self.finish_train:
+                    break
+            else:                                               # the loader was exhausted: one more epoch done
+                self.epochs += 1
+                log.info(f"[step {self.steps}] epoch {self.epochs} finished ({seen} steps)")
+                train_sampler = (self.sampler or {}).get("train")
+                if train_sampler is not None and hasattr(train_sampler, "set_epoch"):
+                    train_sampler.set_epoch(self.epochs)
+                if seen == 0:
+                    raise RuntimeError("the training data loader yields no batches")
+        if self._bar is not None:
+            self._bar.close()
+        log.info("training finished")
