@@ -67,6 +67,9 @@ struct GemmKernelArgs {
     long a_bs, b_bs, r_bs, m_bs, o_bs, ob_bs;
     long a_bs2, b_bs2, o_bs2;   // outer batch (blockIdx.z)
     int m;                      // rows per batch item
+    int dil, bm;                // tap dilation (rows between taps); output rows per tile = 128 - (taps - 1) * dil
+    int plane_act;              // 1: the operand plane receives act(out) (pre-activation consumers), slope = plane_slope
+    float plane_slope;
     int n, nchunk, pad;
     int mtiles, ntiles;
     float alpha, slope;
@@ -112,7 +115,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b, float* ra, flo
 
 template <int TAPS, int SPLIT, int DBG>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
-    constexpr int BM = WIN - (TAPS - 1);      // output rows per tile
+    const int BM = p.bm;                      // output rows per tile: WIN - (TAPS - 1) * dilation
     unsigned long long pt[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tq = 0;
 #define EFTS_STAMP(i) do { if constexpr (DBG == 2) { const unsigned long long tn = __builtin_readcyclecounter(); pt[i] += tn - tq; tq = tn; } } while (0)
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
             vow[q] = (unsigned)((r < b_max ? r : b_max) * (int)p.ldb + (sl << 4));
         }
     }
-    const char* a_base = A + (long)(m0 - p.pad) * p.lda;     // window row 0 (may start in the guard rows)
+    const char* a_base = A + (long)(m0 - p.pad * p.dil) * p.lda;     // window row 0 (may start in the guard rows)
     const char* w_base = Bw + (long)n0 * p.ldb;
     const unsigned lds_piece = lds0 + wave * 4096;            // this wave's first piece inside a tile
 
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
     auto compute = [&](int ab, int ws, int k) {
         const char* at = smem + ab * TILE_BYTES;
         const char* wt = smem + 2 * TILE_BYTES + ws * TILE_BYTES;
-        const int arow = wm * 64 + lrow + k;   // tile row of output row r at tap k is r + k
+        const int arow = wm * 64 + lrow + k * p.dil;   // tile row of output row r at tap k is r + k * dilation
         const int brow = wn * 64 + lrow;
         if (DBG && (dbg & 4)) return;
         // Operand fragments are double-buffered in registers: the ds_reads of k-slice kk+1 are issued
@@ -353,6 +356,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
                     float v = acc[i][j][r] * p.alpha + bv;
                     if (p.act == EFTS_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
                     else if (p.act == EFTS_ACT_RELU) v = v > 0.f ? v : 0.f;
+                    else if (p.act == EFTS_ACT_TANH) v = tanhf(v);
                     cs[rl * 128 + cl] = v;
                 }
             }
@@ -378,6 +382,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
                 __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo, ps * so, 0);
             }
             if (ob) {
+                if (p.plane_act) {
+                    v.x = v.x > 0.f ? v.x : v.x * p.plane_slope; v.y = v.y > 0.f ? v.y : v.y * p.plane_slope;
+                    v.z = v.z > 0.f ? v.z : v.z * p.plane_slope; v.w = v.w > 0.f ? v.w : v.w * p.plane_slope;
+                }
                 float r0, r1, r2, r3;
                 const u32x2 hi = {pack_bf16x2(v.x, v.y, &r0, &r1), pack_bf16x2(v.z, v.w, &r2, &r3)};
                 __builtin_amdgcn_raw_buffer_store_b64(hi, rb, vb, ps * sb, 0);
@@ -414,6 +422,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
                     t *= rm;
                     if (of) of[(long)row * p.ldo + col + u] = t;
                     if (ob) {
+                        if (p.plane_act) t = t > 0.f ? t : t * p.plane_slope;
                         const unsigned short hi = f32_to_bf16(t);
                         char* d = ob + (long)row * p.ldob + plane_off_hi(col + u, p.out_split);
                         *(unsigned short*)d = hi;
@@ -750,7 +759,9 @@ static void launch_debug(dim3 grid, hipStream_t st, GemmKernelArgs k, int prof) 
 extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     if (!a) return efts_fail(EFTS_EINVAL, "efts_gemm: null args");
     if (!(a->split == 1 || a->split == 2)) return efts_fail(EFTS_EINVAL, "efts_gemm: split must be 1 or 2");
-    if (!(a->taps == 1 || a->taps == 3 || a->taps == 5)) return efts_fail(EFTS_EINVAL, "efts_gemm: taps must be 1, 3 or 5");
+    if (!(a->taps == 1 || a->taps == 3 || a->taps == 5 || a->taps == 7 || a->taps == 11)) return efts_fail(EFTS_EINVAL, "efts_gemm: taps must be 1, 3, 5, 7 or 11");
+    const int dil = a->dilation > 0 ? a->dilation : 1;
+    if ((a->taps - 1) * dil > 64) return efts_fail(EFTS_ESHAPE, "efts_gemm: (taps - 1) * dilation must not exceed 64 rows");
     if (a->m <= 0 || a->n <= 0 || a->nchunk <= 0 || a->batch <= 0) return efts_fail(EFTS_ESHAPE, "efts_gemm: m, n, nchunk, batch must be positive");
     if (!a->a || !a->b) return efts_fail(EFTS_EINVAL, "efts_gemm: null operand");
     if (((uintptr_t)a->a & 15) || ((uintptr_t)a->b & 15) || (a->lda & 15) || (a->ldb & 15) || (a->b_tap_stride & 15) ||
@@ -773,7 +784,8 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     const int nb2 = a->batch2 > 1 ? a->batch2 : 1;
     if (nb2 > 1 && (a->out_bf16 || a->resid || a->rowmask)) return efts_fail(EFTS_EINVAL, "efts_gemm: batch2 supports fp32 output only");
     k.m = a->m; k.n = a->n; k.nchunk = a->nchunk; k.pad = (a->taps - 1) / 2;
-    const int bm = WIN - (a->taps - 1);
+    const int bm = WIN - (a->taps - 1) * dil;
+    k.dil = dil; k.bm = bm; k.plane_act = a->plane_act; k.plane_slope = a->plane_slope;
     k.mtiles = (a->m + bm - 1) / bm;
     k.ntiles = (a->n + BN - 1) / BN;
     k.alpha = a->alpha; k.slope = a->slope; k.act = a->act; k.out_split = a->out_split;
@@ -796,7 +808,7 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
 
     // k5 convolutions with enough rows take the 256-row kernel: EFTS_CONV5 = minimum number of
     // (252-row tile x column tile x batch) workgroups, 0 disables it
-    if (a->taps == 5 && nb2 == 1 && !dbg && !prof) {
+    if (a->taps == 5 && dil == 1 && !a->plane_act && a->act != EFTS_ACT_TANH && nb2 == 1 && !dbg && !prof) {
         long min_tiles = a->split == 1 ? C5_DEFAULT_MIN_TILES : 0x7fffffffL;
         { const char* e = getenv("EFTS_CONV5"); if (e) min_tiles = atol(e) > 0 ? atol(e) : 0x7fffffffL; }
         const int mt5 = (a->m + C5_BM - 1) / C5_BM;
@@ -812,9 +824,21 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
         k.dbg = dbg;
         if (a->split == 1) launch_debug<1>(grid, st, k, prof); else launch_debug<2>(grid, st, k, prof);
     } else if (a->split == 1) {
-        if (a->taps == 5) launch_one<5, 1, 0>(grid, st, k); else if (a->taps == 3) launch_one<3, 1, 0>(grid, st, k); else launch_one<1, 1, 0>(grid, st, k);
+        switch (a->taps) {
+            case 11: launch_one<11, 1, 0>(grid, st, k); break;
+            case 7: launch_one<7, 1, 0>(grid, st, k); break;
+            case 5: launch_one<5, 1, 0>(grid, st, k); break;
+            case 3: launch_one<3, 1, 0>(grid, st, k); break;
+            default: launch_one<1, 1, 0>(grid, st, k);
+        }
     } else {
-        if (a->taps == 5) launch_one<5, 2, 0>(grid, st, k); else if (a->taps == 3) launch_one<3, 2, 0>(grid, st, k); else launch_one<1, 2, 0>(grid, st, k);
+        switch (a->taps) {
+            case 11: launch_one<11, 2, 0>(grid, st, k); break;
+            case 7: launch_one<7, 2, 0>(grid, st, k); break;
+            case 5: launch_one<5, 2, 0>(grid, st, k); break;
+            case 3: launch_one<3, 2, 0>(grid, st, k); break;
+            default: launch_one<1, 2, 0>(grid, st, k);
+        }
     }
     return efts_check_launch("efts_gemm");
 }
@@ -830,6 +854,7 @@ extern "C" void efts_gemm_init(void) {
         (void)hipFuncSetAttribute((const void*)conv5_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, C5_LDS);
         (void)hipFuncSetAttribute((const void*)conv5_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, C5_LDS);
         set_lds_attr<5, 1>(); set_lds_attr<3, 1>(); set_lds_attr<1, 1>(); set_lds_attr<5, 2>(); set_lds_attr<3, 2>(); set_lds_attr<1, 2>();
+        set_lds_attr<7, 1>(); set_lds_attr<11, 1>(); set_lds_attr<7, 2>(); set_lds_attr<11, 2>();
         once = true;
     }
     if (getenv("EFTS_DEBUG")) {

@@ -16,7 +16,7 @@ GAP = 2
 GUARD_LO = 8
 GUARD_HI = 144
 TILE_M = 128
-ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -34,6 +34,7 @@ class GemmArgs(C.Structure):
         ("out_bf16", vp), ("ldob", i64), ("outb_batch_stride", i64),
         ("out_split", i32), ("batch2", i32),
         ("a_batch2_stride", i64), ("b_batch2_stride", i64), ("out_batch2_stride", i64),
+        ("dilation", i32), ("plane_act", i32), ("plane_slope", f32),
     ]
 
 

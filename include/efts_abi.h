@@ -54,6 +54,7 @@ extern "C" {
 #define EFTS_ACT_NONE 0
 #define EFTS_ACT_LEAKY 1 /* LeakyReLU, slope in args */
 #define EFTS_ACT_RELU 2
+#define EFTS_ACT_TANH 3 /* the vocoder's output layer */
 
 int efts_version(void);
 const char* efts_last_error(void);
@@ -78,7 +79,7 @@ typedef struct efts_gemm_args {
     int64_t b_tap_stride;
     int64_t b_batch_stride;
     int32_t split;  /* 1 = bf16, 2 = bf16x3 (hi/lo interleaved) */
-    int32_t taps;   /* 1, 3 or 5 */
+    int32_t taps;   /* 1, 3, 5, 7 or 11 */
     int32_t m;      /* rows per batch item */
     int32_t n;      /* output columns */
     int32_t nchunk; /* 128-byte K chunks per row */
@@ -101,6 +102,13 @@ typedef struct efts_gemm_args {
     int32_t out_split; /* 1 or 2: format of out_bf16 */
     int32_t batch2;    /* optional outer batch (grid.z), 0/1 = none; e.g. the taps of a wgrad */
     int64_t a_batch2_stride, b_batch2_stride, out_batch2_stride; /* bytes, bytes, elements */
+    /* dilated convolutions (HiFi-GAN residual blocks, nntts/vocoders/hifigan_model.py:30-58): rows between taps,
+     * 0 / 1 = dense; (taps - 1) * dilation <= 64; taps may also be 7 or 11. */
+    int32_t dilation;
+    /* 1: out_bf16 receives LeakyReLU(out, plane_slope) instead of out -- for consumers that apply the
+     * activation to their INPUT (pre-activation residual blocks); out_f32 stays un-activated. */
+    int32_t plane_act;
+    float plane_slope;
 } efts_gemm_args;
 
 int efts_gemm(const efts_gemm_args* a, void* stream);
