@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
-    ap.add_argument("--workload", default="fwd64", choices=["fwd64", "fwd16_long", "train32", "infer_lj", "infer64", "logmel64"])
+    ap.add_argument("--workload", default="fwd64", choices=["fwd64", "fwd16_long", "train32", "infer_lj", "infer64", "logmel64", "vocoder"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="1 (default): replay the step from a captured hipGraph -- ~75 launches per forward are host-bound in eager mode (3.0 vs 2.6 ms); the roofline events then come from 3 eager steps right after the timed region. 0: eager, events inside the timed region")
     return ap.parse_args()
@@ -205,6 +205,71 @@ def run_logmel64(a, world, rank, dev):
         print(json.dumps(res), flush=True)
 
 
+def run_vocoder(a, world, rank, dev):
+    """Row f-4: HiFi-GAN V1 generator (nntts/vocoders/hifigan_model.py, HiFiGAN_LJ_V1 config, random-init weights),
+    one 800-frame mel -> 204 800 samples (9.3 s of audio) per step."""
+    from efficient_tts_amd.vocoder import HiFiGANGenerator
+    import torch.distributed as dist
+    cfg = dict(resblock="1", upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=512,
+               resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], num_mels=80)
+    T2 = 800
+    torch.manual_seed(0)
+    model = HiFiGANGenerator(cfg, precision=a.precision).to(dev).eval()
+    model.remove_weight_norm()
+    mel = (torch.randn(1, 80, T2, generator=torch.Generator().manual_seed(1234 + rank)) * 1.5 - 4.0).to(dev)
+    for _ in range(max(a.warmup, 1)):
+        y = model(mel)
+    assert y.shape == (1, 1, T2 * 256) and bool(torch.isfinite(y).all())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        model(mel)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    dt /= a.steps
+    # algorithmic FLOPs of the generator per frame (2 * cin * cout * taps per output sample of every layer)
+    fl, ch, length = 2 * 80 * 512 * 7, 512, 1
+    for u, k in zip(cfg["upsample_rates"], cfg["upsample_kernel_sizes"]):
+        fl += 2 * ch * (ch // 2) * k * length                    # transposed conv: k / u taps per output sample, length * u samples
+        ch, length = ch // 2, length * u
+        fl += sum(2 * ch * ch * kk * 6 for kk in cfg["resblock_kernel_sizes"]) * length
+    fl += 2 * ch * 7 * length
+    if rank == 0:
+        res = dict(metric="mel-frames/sec (HiFi-GAN V1 generator, one 800-frame utterance per step)", value=world * T2 / dt,
+                   unit="mel-frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt * 1e3, higher_is_better=True,
+                   scaling="weak", vs_baseline=None, dtype=a.precision if a.precision == "bf16" else "bf16x3 (split-bf16 MFMA, fp32-class)",
+                   data="synthetic", config={"workload": "HiFi-GAN V1 generator, mel [1, 80, 800] -> 204800 samples", "mel_len": T2,
+                                              "precision": a.precision, "parallelism": f"replicas x{world}"},
+                   rtf=dt / (T2 * 256 / 22050.0), tflops=fl * T2 / dt / 1e12, roofline=None)
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle import hifigan_oracle as HO                  # cpu_baseline leg: the oracle as the thing timed
+            P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            Pw = {}
+            for k, v in P.items():                                   # the oracle takes weight_g / weight_v pairs
+                if k.endswith(".weight"):
+                    Pw[k + "_v"] = v
+                    Pw[k + "_g"] = v.flatten(1).norm(dim=1).view(-1, 1, 1)
+                else:
+                    Pw[k] = v
+            torch.set_num_threads(min(os.cpu_count() or 1, 32))
+            Tc = 100
+            mc = mel[:, :, :Tc].cpu()
+            with torch.no_grad():
+                ref = HO.forward(Pw, mc)
+                t1 = time.perf_counter(); HO.forward(Pw, mc); tc = time.perf_counter() - t1
+                got = model(mel[:, :, :Tc].contiguous())
+            res["cpu_baseline"] = dict(value=Tc / tc, unit="mel-frames/s", cores=min(os.cpu_count() or 1, 32), kind="port",
+                                       sample=f"oracle generator fp32, one {Tc}-frame mel ({tc:.2f} s)",
+                                       hip_vs_oracle_audio_max_abs=float((got.cpu() - ref).abs().max()))
+        print(json.dumps(res), flush=True)
+
+
 def run_infer_lj(a, world, rank, dev):
     """BASELINE config 1 plumbing on the GPU: free-running inference() of the first 10 LJSpeech test
     utterances (what nntts/bin/inference.py:97 iterates), one at a time (B = 1, as the reference), plus
@@ -285,6 +350,8 @@ def main():
         return run_infer64(a, world, rank, dev)
     if a.workload == "logmel64":
         return run_logmel64(a, world, rank, dev)
+    if a.workload == "vocoder":
+        return run_vocoder(a, world, rank, dev)
     wl = WORKLOADS[a.workload]
     B, T1, T2 = wl["B"], wl["T1"], wl["T2"]
     if a.workload == "train32":

@@ -1,0 +1,256 @@
+"""HiFi-GAN V1 generator on the MI355X contraction kernel.
+
+Drop-in for `nntts.vocoders.hifigan_model.Generator` (nntts/vocoders/hifigan_model.py:95-150): same
+constructor argument (the config object / dict of HiFiGAN_LJ_V1/config.json), same parameter names and
+shapes (`state_dict` of the reference loads unchanged, weight_g / weight_v pairs), `forward(mel [B, 80, T])
+-> audio [B, 1, T * prod(upsample_rates)]`, `remove_weight_norm()`.  Inference only.
+
+Every Conv1d / ConvTranspose1d is one `efts_gemm` launch on channel-last rows (one row per sample):
+  * dilated k = 3 / 7 / 11 convolutions: `taps`, `dilation` of the kernel (the tap offset is a row offset into
+    the LDS window, exactly like the acoustic model's k5 convolutions);
+  * the residual blocks are pre-activation (`conv(leaky(x))`, :45-52): the PRODUCER of x writes the operand
+    plane of leaky(x) (`plane_act`), so no activation pass exists; `xt` between the two convolutions of a
+    pair only ever lives as that plane (no fp32 copy);
+  * ConvTranspose1d(stride u, kernel 2u, padding u/2) = a 2-tap convolution with u * cout output columns:
+    y[n] = x[q] w[r] + x[q-1] w[r+u] with n + u/2 = q u + r; the [T+1][u*cout] result IS the [u(T+1)][cout] row
+    space of the next stage (a pointer offset of u/2 rows);
+  * the multi-receptive-field mean and the LeakyReLU of the next layer's input: `efts_mean_act_rows`;
+  * conv_post + tanh: the kernel's tanh epilogue.
+There is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+from torch.nn.utils import remove_weight_norm, weight_norm
+
+from . import lib as L
+from . import ops as O
+from .ops import PackedWeight, Plane
+
+LRELU_SLOPE = 0.1
+_GUARD = 64            # zero rows in front of every row space: (taps - 1) / 2 * dilation <= 25
+
+
+def _cfg(h, key, default=None):
+    return h[key] if isinstance(h, dict) and key in h else getattr(h, key, default)
+
+
+class _ResBlock1(nn.Module):
+    """parameter container with the reference's names (hifigan_model.py:30-43); never called"""
+
+    def __init__(self, channels: int, kernel_size: int, dilation):
+        super().__init__()
+        pad = lambda d: (kernel_size * d - d) // 2
+        self.convs1 = nn.ModuleList([weight_norm(nn.Conv1d(channels, channels, kernel_size, 1, dilation=d, padding=pad(d)))
+                                     for d in dilation])
+        self.convs2 = nn.ModuleList([weight_norm(nn.Conv1d(channels, channels, kernel_size, 1, dilation=1, padding=pad(1)))
+                                     for _ in dilation])
+        self.kernel_size, self.dilation = kernel_size, tuple(dilation)
+
+
+class _Rows:
+    """fp32 [rows][c] stream + its operand plane, both with zero guard rows"""
+
+    def __init__(self, rows: int, c: int, split: int, dev, f32: bool = True, plane: bool = True):
+        self.rows, self.c = rows, c
+        alloc = _GUARD + O.roundup(rows, 128) + 256
+        self.f = torch.zeros(alloc, c, dtype=torch.float32, device=dev) if f32 else None
+        self.p = Plane(alloc, c, split, dev, guard_lo=_GUARD) if plane else None
+
+    @property
+    def fptr(self) -> int:
+        return self.f.data_ptr() + _GUARD * self.c * 4
+
+
+class HiFiGANGenerator(nn.Module):
+    def __init__(self, h, precision: str = "bf16x3"):
+        super().__init__()
+        if str(_cfg(h, "resblock", "1")) != "1":
+            raise NotImplementedError("only ResBlock1 (the HiFiGAN_LJ_V1 configuration) is implemented")
+        if precision not in ("bf16x3", "bf16"):
+            raise ValueError("precision must be 'bf16x3' or 'bf16'")
+        self.precision, self.split = precision, 2 if precision == "bf16x3" else 1
+        self.upsample_rates = tuple(_cfg(h, "upsample_rates"))
+        self.upsample_kernel_sizes = tuple(_cfg(h, "upsample_kernel_sizes"))
+        self.res_kernels = tuple(_cfg(h, "resblock_kernel_sizes"))
+        self.res_dilations = tuple(tuple(d) for d in _cfg(h, "resblock_dilation_sizes"))
+        c0 = int(_cfg(h, "upsample_initial_channel"))
+        self.num_mels = int(_cfg(h, "num_mels", 80))
+        for u, k in zip(self.upsample_rates, self.upsample_kernel_sizes):
+            if k != 2 * u or u % 2:
+                raise NotImplementedError("transposed convolutions are implemented for kernel = 2 * stride, even stride")
+        self.conv_pre = weight_norm(nn.Conv1d(self.num_mels, c0, 7, 1, padding=3))
+        self.ups = nn.ModuleList([weight_norm(nn.ConvTranspose1d(c0 // 2 ** i, c0 // 2 ** (i + 1), k, u, padding=(k - u) // 2))
+                                  for i, (u, k) in enumerate(zip(self.upsample_rates, self.upsample_kernel_sizes))])
+        self.resblocks = nn.ModuleList()
+        ch = c0
+        for i in range(len(self.ups)):
+            ch = c0 // 2 ** (i + 1)
+            for k, d in zip(self.res_kernels, self.res_dilations):
+                self.resblocks.append(_ResBlock1(ch, k, d))
+        self.conv_post = weight_norm(nn.Conv1d(ch, 1, 7, 1, padding=3))
+        self._packed: Optional[Dict[str, PackedWeight]] = None
+        self._bias: Dict[str, torch.Tensor] = {}
+        self._bufs: Dict[int, dict] = {}
+
+    # ------------------------------------------------------------------ reference API
+    def remove_weight_norm(self):
+        for m in [self.conv_pre, self.conv_post, *self.ups]:
+            remove_weight_norm(m)
+        for rb in self.resblocks:
+            for m in [*rb.convs1, *rb.convs2]:
+                remove_weight_norm(m)
+        self._packed = None
+
+    def load_state_dict(self, *a, **k):
+        self._packed = None
+        return super().load_state_dict(*a, **k)
+
+    # ------------------------------------------------------------------ weights -> operand planes (once)
+    @staticmethod
+    def _folded(m: nn.Module) -> torch.Tensor:
+        if hasattr(m, "weight_g"):
+            # weight_norm, dim 0 (Conv1d: per cout; ConvTranspose1d: per cin) -- the very op remove_weight_norm bakes in
+            return torch._weight_norm(m.weight_v.detach(), m.weight_g.detach(), 0)
+        return m.weight.detach()
+
+    def _pack(self, dev) -> Dict[str, PackedWeight]:
+        if self._packed is not None:
+            return self._packed
+        pk: Dict[str, PackedWeight] = {}
+        with O.stream_scope():
+            def conv(name, m):
+                w = self._folded(m).float().contiguous()
+                pk[name] = PackedWeight(w.shape[0], w.shape[1], w.shape[2], self.split, dev)
+                pk[name].pack(w)
+                self._bias[name] = m.bias.detach().float().contiguous()
+
+            conv("conv_pre", self.conv_pre)
+            conv("conv_post", self.conv_post)
+            for i, (m, u) in enumerate(zip(self.ups, self.upsample_rates)):
+                w = self._folded(m).float()                                  # [cin][cout][2u]
+                cin, cout, _ = w.shape
+                # B[tap][n = r * cout + co][ci]: tap 0 multiplies x[q-1] (w[.., r + u]), tap 1 multiplies x[q] (w[.., r]), tap 2 = 0
+                b = torch.zeros(u * cout, cin, 3, device=dev)
+                b[:, :, 0] = w[:, :, u:].permute(2, 1, 0).reshape(u * cout, cin)
+                b[:, :, 1] = w[:, :, :u].permute(2, 1, 0).reshape(u * cout, cin)
+                pk[f"ups.{i}"] = PackedWeight(u * cout, cin, 3, self.split, dev)
+                pk[f"ups.{i}"].pack(b.contiguous())
+                self._bias[f"ups.{i}"] = m.bias.detach().float().repeat(u).contiguous()
+            for n, rb in enumerate(self.resblocks):
+                for d in range(len(rb.dilation)):
+                    conv(f"rb{n}.c1.{d}", rb.convs1[d])
+                    conv(f"rb{n}.c2.{d}", rb.convs2[d])
+        self._packed = pk
+        return pk
+
+    # ------------------------------------------------------------------ buffers per mel length
+    def _workspace_for(self, T: int, dev) -> dict:
+        if T in self._bufs:
+            return self._bufs[T]
+        if len(self._bufs) > 2:
+            self._bufs.pop(next(iter(self._bufs)))
+        sp = self.split
+        b = {"mel": _Rows(T, self.num_mels, sp, dev, f32=False), "pre": _Rows(T, self.conv_pre.out_channels, sp, dev, f32=False)}
+        t = T
+        for i, (m, u) in enumerate(zip(self.ups, self.upsample_rates)):
+            cout = m.out_channels
+            L_i = t * u
+            b[f"up{i}"] = _Rows((t + 1) * u, cout, sp, dev, plane=False)     # the [t + 1][u * cout] GEMM result, seen as rows of cout
+            b[f"x{i}"] = _Rows(L_i, cout, sp, dev, f32=False)                # plane of leaky(x_i)
+            b[f"t{i}"] = _Rows(L_i, cout, sp, dev, f32=False)                # plane of leaky(xt)
+            b[f"r{i}"] = [[_Rows(L_i, cout, sp, dev) for _ in range(2)] for _ in self.res_kernels]   # ping-pong per residual block
+            b[f"s{i}"] = _Rows(L_i, cout, sp, dev, f32=False)                # plane of leaky(mean)
+            t = L_i
+        b["out"] = torch.zeros(t + 256, 1, dtype=torch.float32, device=dev)
+        self._bufs[T] = b
+        return b
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() != 3 or x.shape[1] != self.num_mels:
+            raise ValueError(f"expected mel [B, {self.num_mels}, T]")
+        if not x.is_cuda:
+            raise RuntimeError("HiFiGANGenerator runs on an MI355X device only (no CPU path)")
+        L.load()
+        L.require_device()
+        dev = x.device
+        pk = self._pack(dev)
+        B, _, T = x.shape
+        hop = 1
+        for u in self.upsample_rates:
+            hop *= u
+        audio = torch.empty(B, 1, T * hop, dtype=torch.float32, device=dev)
+        with O.stream_scope():
+            for bi in range(B):
+                self._one(pk, x[bi].t().contiguous().float(), audio[bi, 0], T, dev)
+        return audio
+
+    def _conv(self, pk, name, a: Plane, rows, taps, dil, *, out_f=None, ldo=0, out_p=None, plane_slope=None, resid=None, ldr=0,
+              act=L.ACT_NONE):
+        w = pk[name]
+        O.gemm(a=a, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=taps, m=rows, n=w.cout, bias=self._bias[name], act=act,
+               resid_ptr=resid, ldr=ldr, out_f32_ptr=out_f, ldo=ldo, out_plane=out_p, dilation=dil,
+               plane_act=plane_slope is not None, plane_slope=0.0 if plane_slope is None else plane_slope)
+
+    def _one(self, pk, mel_tc: torch.Tensor, out: torch.Tensor, T: int, dev) -> None:
+        b = self._workspace_for(T, dev)
+        lib = L.load()
+        sp = self.split
+        mel_p = b["mel"].p
+        L.check(lib.efts_pack_rows(mel_tc.data_ptr(), None, mel_p.ptr, mel_p.ld, 1, T, T, self.num_mels,
+                                   mel_p.nchunk * O.chunk_k(sp), sp, O._stream()), "efts_pack_rows")
+        # conv_pre (:118); its only consumer applies leaky first (:120) -> the plane of leaky(x), no fp32 copy
+        self._conv(pk, "conv_pre", mel_p, T, 7, 1, out_p=b["pre"].p, plane_slope=LRELU_SLOPE)
+        cur_p, t, n = b["pre"].p, T, 0
+        for i, u in enumerate(self.upsample_rates):
+            cout = self.ups[i].out_channels
+            L_i = t * u
+            up = b[f"up{i}"]
+            # ConvTranspose1d as a 2-tap convolution over the t + 1 input rows (row t is a zero guard row)
+            self._conv(pk, f"ups.{i}", cur_p, t + 1, 3, 1, out_f=up.fptr, ldo=u * cout)
+            x_f = up.fptr + (u // 2) * cout * 4                               # y[n] = row n + u/2 of the flattened result
+            x_p = b[f"x{i}"].p
+            # plane of leaky(x): x * (x > 0 ? 1 : slope), the identity-residual LeakyReLU mode of efts_act_bwd
+            L.check(lib.efts_act_bwd(x_f, x_f, None, None, LRELU_SLOPE, 3, None, x_p.ptr, x_p.ld, sp, None, L_i, cout, O._stream()),
+                    "efts_act_bwd")
+            finals: List[int] = []
+            for j, k in enumerate(self.res_kernels):
+                rb = self.resblocks[n]
+                r_f, r_p, pp = x_f, x_p, b[f"r{i}"][j]
+                for d_i, d in enumerate(rb.dilation):
+                    tp = b[f"t{i}"].p
+                    self._conv(pk, f"rb{n}.c1.{d_i}", r_p, L_i, k, d, out_p=tp, plane_slope=LRELU_SLOPE)            # :47-48 (+ :49)
+                    nxt = pp[d_i & 1]
+                    self._conv(pk, f"rb{n}.c2.{d_i}", tp, L_i, k, 1, out_f=nxt.fptr, ldo=cout, out_p=nxt.p,
+                               plane_slope=LRELU_SLOPE, resid=r_f, ldr=cout)                                       # :50-51
+                    r_f, r_p = nxt.fptr, nxt.p
+                finals.append(r_f)
+                n += 1
+            last = i == len(self.upsample_rates) - 1
+            s_p = b[f"s{i}"].p
+            L.check(lib.efts_mean_act_rows(finals[0], finals[1] if len(finals) > 1 else None, finals[2] if len(finals) > 2 else None,
+                                           cout, 1.0 / len(finals), 0.01 if last else LRELU_SLOPE, None, 0, s_p.ptr, s_p.ld, sp, L_i, cout,
+                                           O._stream()), "efts_mean_act_rows")                                     # :128 (+ :120 / :129)
+            cur_p, t = s_p, L_i
+        self._conv(pk, "conv_post", cur_p, t, 7, 1, out_f=b["out"].data_ptr(), ldo=1, act=L.ACT_TANH)              # :130-131
+        out.copy_(b["out"][:t, 0])
+
+
+def load_hifigan_generator(device, config_path: str, checkpoint_path: str, precision: str = "bf16x3") -> HiFiGANGenerator:
+    """The reference's loader (hifigan_model.py:18-28) with explicit paths: JSON config + a checkpoint whose
+    "generator" entry is the reference Generator's state_dict (the published `generator_v1` is not shipped with the
+    reference repository)."""
+    import json
+    with open(config_path) as f:
+        cfg = json.load(f)
+    gen = HiFiGANGenerator(cfg, precision=precision)
+    state = torch.load(checkpoint_path, map_location="cpu")
+    gen.load_state_dict(state["generator"] if "generator" in state else state)
+    gen = gen.to(device).eval()
+    gen.remove_weight_norm()
+    return gen

@@ -291,6 +291,18 @@ int efts_frame_pack(const float* audio, int64_t ld_audio, const int32_t* lengths
 int efts_logmel(const float* spec, int64_t ld_spec, const float* basis, const int32_t* ranges, const int32_t* frames,
                 float* out, int32_t B, int32_t T, int32_t Tp, int32_t n_bins, int32_t n_mels, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * HiFi-GAN generator (nntts/vocoders/hifigan_model.py:95-136): every Conv1d /
+ * ConvTranspose1d of it is an efts_gemm call (dilated taps 3 / 7 / 11, `plane_act` for the pre-activation
+ * residual blocks, a stride-u transposed convolution = a 2-tap convolution with u * cout output columns,
+ * EFTS_ACT_TANH for the output layer).  The one remaining elementwise step:
+ * efts_mean_act_rows: m = (a + b + c) * scale (b, c optional); out (optional) = m; plane (optional) =
+ *   operand plane of LeakyReLU(m, slope): the multi-receptive-field mean `xs / num_kernels` (:123-131)
+ *   and the activation its consumer applies to its input.  a, b, c: fp32 [rows][ld], c % 4 == 0.
+ * ---------------------------------------------------------------------------------- */
+int efts_mean_act_rows(const float* a, const float* b, const float* c3, int64_t ld, float scale, float slope, float* out,
+                       int64_t ldo, void* plane, int64_t ld_plane, int32_t split, int32_t rows, int32_t c, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
