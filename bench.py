@@ -309,11 +309,27 @@ def run_infer_lj(a, world, rank, dev):
     torch.cuda.synchronize()
     dtb = (time.perf_counter() - t0) / a.steps
     audio = frames * 256 / 22050.0
+    # end to end, as nntts/bin/inference.py:105-111 times it: acoustic model + HiFi-GAN generator per utterance
+    from efficient_tts_amd.vocoder import HiFiGANGenerator
+    voc = HiFiGANGenerator(dict(resblock="1", upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=512,
+                                resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], num_mels=80),
+                           precision=a.precision).to(dev).eval()
+    voc.remove_weight_norm()
+    for x in dids:
+        voc(model.inference(x)[0].transpose(1, 2).contiguous())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        for x in dids:
+            voc(model.inference(x)[0].transpose(1, 2).contiguous())
+    torch.cuda.synchronize()
+    dte = (time.perf_counter() - t0) / a.steps
     res = dict(metric="mel-frames/sec (EFTS-CNN free-running inference, 10 LJSpeech test utterances, B=1 each)", value=frames / dt1,
                unit="mel-frames/s", n_gpus=1, steps=a.steps, warmup=a.warmup, ms_per_step=dt1 * 1e3, higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype=a.precision, data="LJSpeech test phoneme ids (reference filelist), random-init weights with the duration head biased to ~6 frames per phoneme",
                config=dict(workload="inference() x 10 utterances, B=1", frames=frames, precision=a.precision),
-               rtf=dt1 / audio, batched=dict(value=frames / dtb, ms=dtb * 1e3, rtf=dtb / audio, note="same 10 utterances as one ragged batch (inference_batch)"))
+               rtf=dt1 / audio, batched=dict(value=frames / dtb, ms=dtb * 1e3, rtf=dtb / audio, note="same 10 utterances as one ragged batch (inference_batch)"),
+               end_to_end=dict(ms=dte * 1e3, rtf=dte / audio, note="inference() + HiFi-GAN V1 generator per utterance (random-init vocoder weights): what nntts/bin/inference.py:105-111 calls RTF"))
     if not a.no_cpu_baseline:
         from oracle import efts_oracle as O           # cpu_baseline leg: the oracle as the thing timed
         torch.set_num_threads(min(os.cpu_count() or 1, 16))
