@@ -105,3 +105,40 @@ def test_cli_trains_saves_and_resumes(tmp_path):
     assert main(["--outdir", str(out2), "--config", str(cfg), "--verbose", "0", "--resume", str(ck3)]) == 0
     sd2 = torch.load(out2 / "checkpoint-6steps.pkl", map_location="cpu")
     assert sd2["steps"] == 6 and not (out2 / "checkpoint-3steps.pkl").exists()
+
+
+@pytest.mark.gpu
+def test_inference_cli_writes_wavs(tmp_path):
+    """python -m efficient_tts_amd.bin.inference with the reference's arguments (nntts/bin/inference.py:128-176): wav files
+    of T2 * 256 samples per utterance, the batched mode gives the same audio, --no_vocoder writes the mels."""
+    from scipy.io.wavfile import read
+    from efficient_tts_amd import EfficientTTSCNN
+    from efficient_tts_amd.bin.inference import main
+    exp = tmp_path / "exp"
+    exp.mkdir()
+    phones = ["_"] + [f"P{i}" for i in range(1, 76)]
+    (tmp_path / "phn.txt").write_text("\n".join(phones) + "\n")
+    rng = np.random.default_rng(1)
+    lines = [f"DUMMY/utt{n}.wav|" + " ".join(phones[int(i)] for i in rng.integers(1, 76, size=k)) for n, k in enumerate((9, 14, 11))]
+    (tmp_path / "test.txt").write_text("\n".join(lines) + "\n")
+    params = dict(num_symbols=76, dropout_rate=0.0, use_masking=True, use_weighted_masking=False, sigma=0.01)
+    with open(exp / "config.yml", "w") as f:
+        yaml.dump(dict(model_name="EfficientTTSCNN", model_params=params,
+                       dataset_params=dict(use_phnseq=True, phnset_path=str(tmp_path / "phn.txt"))), f)
+    torch.manual_seed(0)
+    m = EfficientTTSCNN(**params)
+    with torch.no_grad():
+        m.duration_predictor.linear.bias.fill_(1.5)              # a few frames per phoneme with random weights
+    torch.save({"model": m.state_dict(), "steps": 7}, exp / "checkpoint-7steps.pkl")
+    base = ["--checkpoint", str(exp / "checkpoint-7steps.pkl"), "--test_fid_scp", str(tmp_path / "test.txt"), "--verbose", "0"]
+    torch.manual_seed(0)
+    assert main(base + ["--outdir", str(tmp_path / "w1")]) == 0
+    torch.manual_seed(0)                                           # same random vocoder weights for the batched run
+    assert main(base + ["--outdir", str(tmp_path / "w3"), "--batch_size", "3"]) == 0
+    assert main(base + ["--outdir", str(tmp_path / "mel"), "--no_vocoder"]) == 0
+    for n in range(3):
+        sr, a = read(str(tmp_path / "w1" / f"utt{n}_7steps.wav"))
+        _, b = read(str(tmp_path / "w3" / f"utt{n}_7steps.wav"))
+        mel = np.load(tmp_path / "mel" / f"utt{n}_7steps.npy")
+        assert sr == 22050 and a.dtype == np.int16 and a.shape == (mel.shape[0] * 256,) and mel.shape[1] == 80
+        assert a.shape == b.shape and np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 2
