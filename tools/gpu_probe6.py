@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from efficient_tts_amd import lib as L, ops as P
 dev = torch.device("cuda:0"); L.load(); L.require_device()
-B, T, C, split = 64, 800, 512, int(os.environ.get("PSPLIT", "1"))
+B, T, C, split = int(os.environ.get("PB", "64")), 800, 512, int(os.environ.get("PSPLIT", "1"))
 rs = P.Rows(B, T)
 a = P.Plane.for_rows(rs, C, split, dev)
 x = torch.randn(B, T, C, device=dev)
