@@ -1188,10 +1188,13 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     dim3 grid(nt_all < cap ? nt_all : cap, a->batch, nb2);
 
     // outputs of at most 64 columns (the 64- and 32-channel stages of the vocoder): column tile 64 / 32
-    if (a->n <= 64 && a->batch == 1 && nb2 == 1 && (a->taps == 3 || a->taps == 7 || a->taps == 11) && !getenv("EFTS_NO_NARROW")) {
+    // ... and launches whose 128-column tiling would leave most CUs without a workgroup (the 256-channel stage of the
+    // vocoder at one utterance: 110 workgroups): 64-column tiles double the workgroup count
+    const bool few = (long)k.mtiles * k.ntiles < efts_num_cus() && a->n > 64;
+    if ((a->n <= 64 || few) && a->batch == 1 && nb2 == 1 && (a->taps == 3 || a->taps == 7 || a->taps == 11) && !getenv("EFTS_NO_NARROW")) {
         GemmKernelArgs kn = k;
-        kn.ntiles = 1;
-        dim3 gn(k.mtiles, 1, 1);
+        kn.ntiles = a->n <= 32 ? 1 : (a->n + 63) / 64;
+        dim3 gn(k.mtiles * kn.ntiles, 1, 1);
         bool done;
         if (a->n <= 32) done = a->split == 1 ? launch_narrow_taps<1, 32>(a->taps, gn, st, kn) : launch_narrow_taps<2, 32>(a->taps, gn, st, kn);
         else done = a->split == 1 ? launch_narrow_taps<1, 64>(a->taps, gn, st, kn) : launch_narrow_taps<2, 64>(a->taps, gn, st, kn);
