@@ -1113,7 +1113,9 @@ static void launch_narrow(dim3 grid, hipStream_t st, const GemmKernelArgs& k) {
 template <int S, int B>
 static bool launch_narrow_taps(int taps, dim3 grid, hipStream_t st, const GemmKernelArgs& k) {
     switch (taps) {
+        case 1: launch_narrow<1, S, B>(grid, st, k); return true;
         case 3: launch_narrow<3, S, B>(grid, st, k); return true;
+        case 5: launch_narrow<5, S, B>(grid, st, k); return true;
         case 7: launch_narrow<7, S, B>(grid, st, k); return true;
         case 11: launch_narrow<11, S, B>(grid, st, k); return true;
         default: return false;
@@ -1188,13 +1190,17 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     dim3 grid(nt_all < cap ? nt_all : cap, a->batch, nb2);
 
     // outputs of at most 64 columns (the 64- and 32-channel stages of the vocoder): column tile 64 / 32
-    // ... and launches whose 128-column tiling would leave most CUs without a workgroup (the 256-channel stage of the
-    // vocoder at one utterance: 110 workgroups): 64-column tiles double the workgroup count
-    const bool few = (long)k.mtiles * k.ntiles < efts_num_cus() && a->n > 64;
-    if ((a->n <= 64 || few) && a->batch == 1 && nb2 == 1 && (a->taps == 3 || a->taps == 7 || a->taps == 11) && !getenv("EFTS_NO_NARROW")) {
+    // ... and launches whose 128-column tiling cannot give every CU its two resident workgroups (the text side of
+    // the acoustic model: 64 x 130 rows = 272 workgroups; the 256-channel stage of the vocoder at one utterance:
+    // 110): such a launch is bound by the per-workgroup step latency, and 64-column tiles double the number of
+    // workgroups that overlap.  EFTS_NARROW_FEW = the threshold in workgroups per CU (default 1, 0 disables; 2 measured slower for the 272-workgroup text side).
+    int few_per_cu = 1;
+    { const char* e = getenv("EFTS_NARROW_FEW"); if (e) few_per_cu = atoi(e); }
+    const bool few = (long)k.mtiles * k.ntiles * a->batch < (long)few_per_cu * efts_num_cus() && a->n > 64;
+    if ((a->n <= 64 || few) && nb2 == 1 && !getenv("EFTS_NO_NARROW")) {
         GemmKernelArgs kn = k;
         kn.ntiles = a->n <= 32 ? 1 : (a->n + 63) / 64;
-        dim3 gn(k.mtiles * kn.ntiles, 1, 1);
+        dim3 gn(k.mtiles * kn.ntiles, a->batch, 1);
         bool done;
         if (a->n <= 32) done = a->split == 1 ? launch_narrow_taps<1, 32>(a->taps, gn, st, kn) : launch_narrow_taps<2, 32>(a->taps, gn, st, kn);
         else done = a->split == 1 ? launch_narrow_taps<1, 64>(a->taps, gn, st, kn) : launch_narrow_taps<2, 64>(a->taps, gn, st, kn);

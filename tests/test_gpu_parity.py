@@ -227,6 +227,35 @@ def test_odd_shapes_and_ragged_lengths_vs_oracle(model, B, T1, T2, tl, sl):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_narrow_tiles_equal_gemm_kernel(golden_dir, precision, monkeypatch):
+    """64-column tiles (narrow_kernel, taken by launches too small to give every CU two workgroups -- every
+    launch at this size) against the 128-column gemm_kernel: the same K order per output element, so the results
+    must agree to the last bits.  EFTS_NARROW_FEW is read per launch: 0 disables the rule."""
+    g = np.load(os.path.join(golden_dir, "fwd_full.npz"))
+    args = [torch.from_numpy(g[k]).cuda() for k in ("text", "text_lengths", "speech", "speech_lengths")]
+    from efficient_tts_amd import EfficientTTSCNN
+    m = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, sigma=0.01, precision=precision)
+    m.load_state_dict(O.fill_params())
+    m = m.cuda().eval()
+    outs = {}
+    for flag in ("0", "2"):
+        monkeypatch.setenv("EFTS_NARROW_FEW", flag)
+        with torch.no_grad():
+            o = m(*args)
+        torch.cuda.synchronize()
+        outs[flag] = (float(o[0]), o[4].clone(), o[3].clone())
+    monkeypatch.delenv("EFTS_NARROW_FEW")
+    assert (outs["0"][1] - outs["2"][1]).abs().max().item() <= 1e-6
+    assert (outs["0"][2] - outs["2"][2]).abs().max().item() <= 1e-6
+    assert abs(outs["0"][0] - outs["2"][0]) <= 1e-6 * abs(outs["0"][0])
+    if precision == "bf16x3":
+        stride = int(g["mel_pred_stride"])
+        assert np.abs(outs["0"][1].cpu().numpy()[:, ::stride] - g["mel_pred"]).max() <= 1e-3
+
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
 def test_conv5_kernel_equals_gemm_kernel(golden_dir, precision, monkeypatch):
     """The 256-row k5 kernel (conv5_kernel, used for large launches) against the 124-row gemm_kernel on the same
     batch: identical summation order per output element, so the results must agree to the last bits; plus the
