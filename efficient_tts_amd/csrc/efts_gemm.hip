@@ -35,6 +35,17 @@
 
 #include "efts_internal.h"
 
+// cache-policy bits of the epilogue's buffer accesses (bit 0 sc0, bit 1 nt, bit 4 sc1); experiments only
+#ifndef EFTS_AUX_LD
+#define EFTS_AUX_LD 0
+#endif
+#ifndef EFTS_AUX_STF
+#define EFTS_AUX_STF 0
+#endif
+#ifndef EFTS_AUX_STP
+#define EFTS_AUX_STP 0
+#endif
+
 namespace efts {
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
@@ -325,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
         const unsigned vr = trow * (unsigned)p.ldr * 4 + col * 4, sr = RPP * (unsigned)p.ldr * 4;
 #pragma unroll
         for (int ps = 0; ps < NPS; ++ps) {
-            rres[ps] = __builtin_amdgcn_raw_buffer_load_b128(rr, vr, ps * sr, 0);
+            rres[ps] = __builtin_amdgcn_raw_buffer_load_b128(rr, vr, ps * sr, EFTS_AUX_LD);
             rmv[ps] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rk, trow * 4, ps * RPP * 4, 0));
         }
     }
@@ -379,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
             v.z = (v.z + __uint_as_float(x.z)) * rm; v.w = (v.w + __uint_as_float(x.w)) * rm;
             if (of) {
                 const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-                __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo, ps * so, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo, ps * so, EFTS_AUX_STF);
             }
             if (ob) {
                 if (p.plane_act) {
@@ -388,11 +399,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
                 }
                 float r0, r1, r2, r3;
                 const u32x2 hi = {pack_bf16x2(v.x, v.y, &r0, &r1), pack_bf16x2(v.z, v.w, &r2, &r3)};
-                __builtin_amdgcn_raw_buffer_store_b64(hi, rb, vb, ps * sb, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(hi, rb, vb, ps * sb, EFTS_AUX_STP);
                 if (p.out_split == 2) {
                     float d0, d1;
                     const u32x2 lo = {pack_bf16x2(r0, r1, &d0, &d1), pack_bf16x2(r2, r3, &d0, &d1)};
-                    __builtin_amdgcn_raw_buffer_store_b64(lo, rb, vb + 64, ps * sb, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(lo, rb, vb + 64, ps * sb, EFTS_AUX_STP);
                 }
             }
         }
@@ -691,7 +702,7 @@ __global__ __launch_bounds__(256, 2) void narrow_kernel(GemmKernelArgs p) {
         const unsigned vr = trow * (unsigned)p.ldr * 4 + col * 4, sr = RPP * (unsigned)p.ldr * 4;
 #pragma unroll
         for (int ps = 0; ps < NPS; ++ps) {
-            rres[ps] = __builtin_amdgcn_raw_buffer_load_b128(rr, vr, ps * sr, 0);
+            rres[ps] = __builtin_amdgcn_raw_buffer_load_b128(rr, vr, ps * sr, EFTS_AUX_LD);
             rmv[ps] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rk, trow * 4, ps * RPP * 4, 0));
         }
     }
@@ -745,7 +756,7 @@ __global__ __launch_bounds__(256, 2) void narrow_kernel(GemmKernelArgs p) {
             v.z = (v.z + __uint_as_float(x.z)) * rm; v.w = (v.w + __uint_as_float(x.w)) * rm;
             if (of) {
                 const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-                __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo, ps * so, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo, ps * so, EFTS_AUX_STF);
             }
             if (ob) {
                 if (p.plane_act) {
@@ -754,11 +765,11 @@ __global__ __launch_bounds__(256, 2) void narrow_kernel(GemmKernelArgs p) {
                 }
                 float r0, r1, r2, r3;
                 const u32x2 hi = {pack_bf16x2(v.x, v.y, &r0, &r1), pack_bf16x2(v.z, v.w, &r2, &r3)};
-                __builtin_amdgcn_raw_buffer_store_b64(hi, rb, vb, ps * sb, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(hi, rb, vb, ps * sb, EFTS_AUX_STP);
                 if (p.out_split == 2) {
                     float d0, d1;
                     const u32x2 lo = {pack_bf16x2(r0, r1, &d0, &d1), pack_bf16x2(r2, r3, &d0, &d1)};
-                    __builtin_amdgcn_raw_buffer_store_b64(lo, rb, vb + 64, ps * sb, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(lo, rb, vb + 64, ps * sb, EFTS_AUX_STP);
                 }
             }
         }
@@ -993,7 +1004,7 @@ __global__ __launch_bounds__(256, 2) void conv5_kernel(GemmKernelArgs p) {
     // sweep ps of pass ep covers tile rows row_of(ep, ps) + (0..7)
     auto row_of = [&](int ep, int ps) { return ps * RPP + 64 * ep + (ps >= 8 ? 64 : 0); };
     auto request = [&](int ep, int ps) {
-        rres[ps % NRING] = __builtin_amdgcn_raw_buffer_load_b128(rr, vr, row_of(ep, ps) * (unsigned)p.ldr * 4, 0);
+        rres[ps % NRING] = __builtin_amdgcn_raw_buffer_load_b128(rr, vr, row_of(ep, ps) * (unsigned)p.ldr * 4, EFTS_AUX_LD);
         rmv[ps % NRING] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rk, trow * 4, row_of(ep, ps) * 4, 0));
     };
     compute(ws, TAPS - 1);
@@ -1043,16 +1054,16 @@ __global__ __launch_bounds__(256, 2) void conv5_kernel(GemmKernelArgs p) {
                 v.z = (v.z + __uint_as_float(x.z)) * rm; v.w = (v.w + __uint_as_float(x.w)) * rm;
                 if (of) {
                     const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-                    __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo, row_of(ep, ps) * (unsigned)p.ldo * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo, row_of(ep, ps) * (unsigned)p.ldo * 4, EFTS_AUX_STF);
                 }
                 if (ob) {
                     float r0, r1, r2, r3;
                     const u32x2 hi = {pack_bf16x2(v.x, v.y, &r0, &r1), pack_bf16x2(v.z, v.w, &r2, &r3)};
-                    __builtin_amdgcn_raw_buffer_store_b64(hi, rb, vb, row_of(ep, ps) * (unsigned)p.ldob, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(hi, rb, vb, row_of(ep, ps) * (unsigned)p.ldob, EFTS_AUX_STP);
                     if (p.out_split == 2) {
                         float d0, d1;
                         const u32x2 lo = {pack_bf16x2(r0, r1, &d0, &d1), pack_bf16x2(r2, r3, &d0, &d1)};
-                        __builtin_amdgcn_raw_buffer_store_b64(lo, rb, vb + 64, row_of(ep, ps) * (unsigned)p.ldob, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(lo, rb, vb + 64, row_of(ep, ps) * (unsigned)p.ldob, EFTS_AUX_STP);
                     }
                 }
             }
