@@ -183,6 +183,8 @@ class EfficientTTSCNN(torch.nn.Module):
         self.dropout_seed = 0x5EED          # base seed of the duration predictor's dropout masks (train mode)
         self._packed: Dict[str, PackedWeight] = {}
         self._packed_sig = None
+        self._packed_gen = 0                # bumped by every repack: what derived caches (TrainEngine) compare
+        self._folded_gen = -1               # the repack that last wrote the training engine's folded fp32 copies
         self._ws: Dict[Tuple, _Workspace] = {}
 
     # ------------------------------------------------------------------ weight norm (efficient_tts.py:400-418)
@@ -209,9 +211,12 @@ class EfficientTTSCNN(torch.nn.Module):
             out.append((f"dur.{i}", seq[0]))
         return out
 
-    def _weights(self) -> Dict[str, PackedWeight]:
+    def _weights(self, folded: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, PackedWeight]:
         """B operand planes of every Conv1d/Linear; repacked (weight-norm fold fused) whenever
-        a parameter changed (optimizer step, load_state_dict, .to())."""
+        a parameter changed (optimizer step, load_state_dict, .to()).  `folded` (training engine): per conv name,
+        an fp32 [cout][cin][taps] tensor that receives the folded weight g * v / ||v|| during the same pass.
+        `_packed_sig` cannot see in-place updates made by the fused optimizer kernel (no version bump), which is
+        why EftsAdam resets it and why consumers of derived data compare `_packed_gen`, never the signature."""
         sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if sig == self._packed_sig:
             return self._packed
@@ -222,7 +227,8 @@ class EfficientTTSCNN(torch.nn.Module):
             if name not in pk or pk[name].buf.device != dev:
                 pk[name] = PackedWeight(conv.out_channels, conv.in_channels, taps, self.split, dev)
             if hasattr(conv, "weight_g"):
-                pk[name].pack(conv.weight_v.detach().contiguous(), conv.weight_g.detach().contiguous())
+                pk[name].pack(conv.weight_v.detach().contiguous(), conv.weight_g.detach().contiguous(),
+                              None if folded is None else folded.get(name))
             else:
                 pk[name].pack(conv.weight.detach().contiguous())
         lin_split = {"key": self.split, "value": self.split, "prenet": self.split, "head": self.split}
@@ -233,6 +239,9 @@ class EfficientTTSCNN(torch.nn.Module):
                 pk[name] = PackedWeight(lin.out_features, lin.in_features, 1, lin_split[name], dev)
             pk[name].pack(lin.weight.detach().contiguous())
         self._packed_sig = sig
+        self._packed_gen += 1
+        if folded is not None:
+            self._folded_gen = self._packed_gen
         return pk
 
     def _side_stream(self, device) -> "torch.cuda.Stream":

@@ -106,31 +106,34 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ weights for the backward
     def _prepare_weights(self):
-        """forward planes (model._weights), folded fp32 weights and transposed/flipped dgrad planes"""
+        """forward planes (model._weights), folded fp32 weights and transposed/flipped dgrad planes.  Everything
+        derived here follows `model._packed_gen`, the repack counter: the fused optimizer updates parameters in
+        place without a version bump, so the signature of the parameters cannot be used to detect a change."""
         m = self.m
-        pk = m._weights()
-        sig = m._packed_sig
-        if sig == self._sig:
-            return pk
         dev = self.dev
         for name, conv in m._conv_modules():
-            taps = conv.kernel_size[0]
             if name not in self.folded:
+                taps = conv.kernel_size[0]
                 self.folded[name] = torch.empty(conv.out_channels, conv.in_channels, taps, device=dev)
                 self.wt[name] = PackedWeight(conv.in_channels, conv.out_channels, taps, m.split, dev)
-            if hasattr(conv, "weight_g"):
-                pk[name].pack(conv.weight_v.detach().contiguous(), conv.weight_g.detach().contiguous(), self.folded[name])
-                wsrc = self.folded[name]
-            else:
-                wsrc = conv.weight.detach().contiguous()
+        folded = self.folded                    # written for the weight-normed convolutions only
+        pk = m._weights(folded)
+        if m._folded_gen != m._packed_gen:
+            m._packed_sig = None                # the last repack (an eval forward) did not write the folded copies
+            pk = m._weights(folded)
+        gen = m._packed_gen
+        if gen == self._sig:
+            return pk
+        for name, conv in m._conv_modules():
+            wsrc = self.folded[name] if hasattr(conv, "weight_g") else conv.weight.detach().contiguous()
             L.check(_lib().efts_pack_weight_t(wsrc.data_ptr(), self.wt[name].ptr, self.wt[name].ld, conv.out_channels,
-                                              conv.in_channels, taps, m.split, O._stream()), "efts_pack_weight_t")
+                                              conv.in_channels, conv.kernel_size[0], m.split, O._stream()), "efts_pack_weight_t")
         for name, lin in (("key", m.text_encoder_key), ("value", m.text_encoder_value), ("head", m.mel_output_layer)):
             if name not in self.wt:
                 self.wt[name] = PackedWeight(lin.in_features, lin.out_features, 1, m.split, dev)
             L.check(_lib().efts_pack_weight_t(lin.weight.detach().contiguous().data_ptr(), self.wt[name].ptr, self.wt[name].ld,
                                               lin.out_features, lin.in_features, 1, m.split, O._stream()), "efts_pack_weight_t")
-        self._sig = sig
+        self._sig = gen
         return pk
 
     # ------------------------------------------------------------------ small wrappers
