@@ -570,10 +570,132 @@ __global__ __launch_bounds__(256) void pack_weight_t_kernel(const float* __restr
     }
 }
 
+// ---- grouped weight preparation: every item (same shape) in one launch per plane kind.  A training step repacks
+// ~20 weights twice (forward plane + folded fp32 copy, transposed dgrad plane); as separate 8-11 us launches that
+// was 0.4 ms of a 5 ms step, almost all of it launch latency.
+struct PackItem { const float* w; const float* g; float* wout; char* plane; char* plane_t; };
+
+__global__ __launch_bounds__(256) void pack_weight_group_kernel(const PackItem* __restrict__ items, long ldb, int cout, int cin,
+                                                                int taps, int kp, int split) {
+    __shared__ float sh[4];
+    const PackItem it = items[blockIdx.y];
+    const int co = blockIdx.x;
+    const float* wr = it.w + (long)co * cin * taps;
+    float scale = 1.f;
+    if (it.g) {
+        float ss = 0.f;
+        for (int i = threadIdx.x; i < cin * taps; i += 256) ss += wr[i] * wr[i];
+        ss = block_sum256t(ss, sh);
+        scale = it.g[co] / sqrtf(ss);
+    }
+    if (it.wout)
+        for (int i = threadIdx.x; i < cin * taps; i += 256) it.wout[(long)co * cin * taps + i] = wr[i] * scale;
+    if (!it.plane) return;
+    for (int q = threadIdx.x; q < (kp >> 2) * taps; q += 256) {
+        const int k = q / (kp >> 2), c4 = (q - k * (kp >> 2)) << 2;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (c4 + u < cin) ? wr[(long)(c4 + u) * taps + k] * scale : 0.f;
+        plane_store4(it.plane + ((long)k * cout + co) * ldb, c4, v[0], v[1], v[2], v[3], split);
+    }
+}
+
+// transposed planes of the group; reads the folded copy when the item has one (written by the kernel above)
+__global__ __launch_bounds__(256) void pack_weight_t_group_kernel(const PackItem* __restrict__ items, long ldb, int cout, int cin,
+                                                                  int taps, int kp, int split) {
+    const PackItem it = items[blockIdx.y];
+    if (!it.plane_t) return;
+    const float* w = (it.g && it.wout) ? it.wout : it.w;
+    const int ci = blockIdx.x;
+    for (int q = threadIdx.x; q < (kp >> 2) * taps; q += 256) {
+        const int k = q / (kp >> 2), c4 = (q - k * (kp >> 2)) << 2;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (c4 + u < cout) ? w[((long)(c4 + u) * cin + ci) * taps + k] : 0.f;
+        plane_store4(it.plane_t + ((long)(taps - 1 - k) * cin + ci) * ldb, c4, v[0], v[1], v[2], v[3], split);
+    }
+}
+
+// ---- fast path (cout % 64 == 0, cin % 64 == 0, taps <= 5): weight-norm scales first, then one pass over the
+// weights in [32 co][64 ci][taps] tiles through LDS that writes BOTH planes (and the folded copy if asked for)
+// with full-sector accesses.  14 k5 layers: 82 + 199 us with the row kernels above -> see DESIGN.md.
+__global__ __launch_bounds__(256) void weight_scale_kernel(const PackItem* __restrict__ items, float* __restrict__ scale, int cout,
+                                                           int row_len) {
+    __shared__ float sh[4];
+    const PackItem it = items[blockIdx.y];
+    const int co = blockIdx.x;
+    float sc = 1.f;
+    if (it.g) {
+        const float* wr = it.w + (long)co * row_len;
+        float ss = 0.f;
+        for (int i = threadIdx.x; i < row_len; i += 256) ss += wr[i] * wr[i];
+        ss = block_sum256t(ss, sh);            // same reduction order as pack_weight_kernel: identical scales
+        sc = it.g[co] / sqrtf(ss);
+    }
+    if (threadIdx.x == 0) scale[(long)blockIdx.y * cout + co] = sc;
+}
+
+constexpr int PT_CO = 32, PT_CI = 64, PT_MAXT = 5;
+__global__ __launch_bounds__(256) void pack_weight_tile_kernel(const PackItem* __restrict__ items, const float* __restrict__ scale,
+                                                               long ldb, long ldb_t, int cout, int cin, int taps, int split) {
+    __shared__ float tile[PT_CO][PT_CI * PT_MAXT + 1];
+    __shared__ float sc[PT_CO];
+    const PackItem it = items[blockIdx.z];
+    const int co0 = blockIdx.x * PT_CO, ci0 = blockIdx.y * PT_CI;
+    const int seg = PT_CI * taps;              // contiguous floats per co row of this tile
+    if (threadIdx.x < PT_CO) sc[threadIdx.x] = scale[(long)blockIdx.z * cout + co0 + threadIdx.x];
+    for (int i = threadIdx.x; i < PT_CO * seg; i += 256) {
+        const int c = i / seg, r = i - c * seg;
+        tile[c][r] = it.w[((long)(co0 + c) * cin + ci0) * taps + r];
+    }
+    __syncthreads();
+    if (it.wout)
+        for (int i = threadIdx.x; i < PT_CO * seg; i += 256) {
+            const int c = i / seg, r = i - c * seg;
+            it.wout[((long)(co0 + c) * cin + ci0) * taps + r] = tile[c][r] * sc[c];
+        }
+    if (it.plane)                               // [k][co][Kp(ci)]: 16 threads per 64-ci row piece
+        for (int i = threadIdx.x; i < taps * PT_CO * (PT_CI / 4); i += 256) {
+            const int q = i & 15, c = (i >> 4) & (PT_CO - 1), k = i >> 9;
+            const float s = sc[c];
+            const float* t = &tile[c][(4 * q) * taps + k];
+            plane_store4(it.plane + ((long)k * cout + co0 + c) * ldb, ci0 + 4 * q, t[0] * s, t[taps] * s, t[2 * taps] * s, t[3 * taps] * s, split);
+        }
+    if (it.plane_t)                             // [taps-1-k][ci][Kp(co)]: 8 threads per 32-co row piece
+        for (int i = threadIdx.x; i < taps * PT_CI * (PT_CO / 4); i += 256) {
+            const int q = i & 7, c = (i >> 3) & (PT_CI - 1), k = i >> 9;
+            const int r = c * taps + k;
+            plane_store4(it.plane_t + ((long)(taps - 1 - k) * cin + ci0 + c) * ldb_t, co0 + 4 * q, tile[4 * q][r] * sc[4 * q],
+                         tile[4 * q + 1][r] * sc[4 * q + 1], tile[4 * q + 2][r] * sc[4 * q + 2], tile[4 * q + 3][r] * sc[4 * q + 3], split);
+        }
+}
+
 }  // namespace efts
 
 using namespace efts;
 #define ST ((hipStream_t)stream)
+
+extern "C" int efts_pack_weights_grouped(const efts_pack_item* items, int32_t n_items, float* scale_ws, int64_t ldb, int64_t ldb_t,
+                                         int32_t cout, int32_t cin, int32_t taps, int32_t split, int32_t with_t, void* stream) {
+    static_assert(sizeof(PackItem) == sizeof(efts_pack_item), "efts_pack_item layout");
+    if (!items || n_items <= 0) return efts_fail(EFTS_EINVAL, "efts_pack_weights_grouped: no items");
+    if (!(split == 1 || split == 2) || cout <= 0 || cin <= 0 || taps <= 0) return efts_fail(EFTS_ESHAPE, "efts_pack_weights_grouped: bad shape/split");
+    const int kp = split == 1 ? (cin + 63) & ~63 : (cin + 31) & ~31;
+    const int kpt = split == 1 ? (cout + 63) & ~63 : (cout + 31) & ~31;
+    if (ldb < (split == 1 ? kp * 2 : kp * 4) || (ldb & 15)) return efts_fail(EFTS_EALIGN, "efts_pack_weights_grouped: ldb too small or not 16-byte aligned");
+    if (with_t && (ldb_t < (split == 1 ? kpt * 2 : kpt * 4) || (ldb_t & 15)))
+        return efts_fail(EFTS_EALIGN, "efts_pack_weights_grouped: ldb_t too small or not 16-byte aligned");
+    if (scale_ws && cout % 64 == 0 && cin % PT_CI == 0 && taps <= PT_MAXT && !getenv("EFTS_PACK_ROWS")) {
+        hipLaunchKernelGGL(weight_scale_kernel, dim3(cout, n_items), dim3(256), 0, ST, (const PackItem*)items, scale_ws, cout, cin * taps);
+        hipLaunchKernelGGL(pack_weight_tile_kernel, dim3(cout / PT_CO, cin / PT_CI, n_items), dim3(256), 0, ST, (const PackItem*)items,
+                           (const float*)scale_ws, (long)ldb, (long)ldb_t, cout, cin, taps, split);
+        return efts_check_launch("efts_pack_weights_grouped");
+    }
+    hipLaunchKernelGGL(pack_weight_group_kernel, dim3(cout, n_items), dim3(256), 0, ST, (const PackItem*)items, (long)ldb, cout, cin, taps, kp, split);
+    if (with_t)
+        hipLaunchKernelGGL(pack_weight_t_group_kernel, dim3(cin, n_items), dim3(256), 0, ST, (const PackItem*)items, (long)ldb_t, cout, cin, taps, kpt, split);
+    return efts_check_launch("efts_pack_weights_grouped");
+}
 
 extern "C" int efts_pack_weight_t(const float* w, void* plane, int64_t ldb, int32_t cout, int32_t cin, int32_t taps, int32_t split, void* stream) {
     if (!w || !plane) return efts_fail(EFTS_EINVAL, "efts_pack_weight_t: null pointer");

@@ -59,6 +59,7 @@ _SIGS = {
     "efts_masked_losses": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     # training step
     "efts_pack_weight_t": (i32, [vp, vp, i64, i32, i32, i32, i32, vp]),
+    "efts_pack_weights_grouped": (i32, [vp, i32, vp, i64, i64, i32, i32, i32, i32, i32, vp]),
     "efts_loss_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "efts_act_bwd": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, i64, i32, vp, i32, i32, vp]),
     "efts_pack_t": (i32, [vp, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, vp]),

@@ -211,10 +211,13 @@ class EfficientTTSCNN(torch.nn.Module):
             out.append((f"dur.{i}", seq[0]))
         return out
 
-    def _weights(self, folded: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, PackedWeight]:
+    def _weights(self, folded: Optional[Dict[str, torch.Tensor]] = None,
+                 wt: Optional[Dict[str, PackedWeight]] = None) -> Dict[str, PackedWeight]:
         """B operand planes of every Conv1d/Linear; repacked (weight-norm fold fused) whenever
-        a parameter changed (optimizer step, load_state_dict, .to()).  `folded` (training engine): per conv name,
-        an fp32 [cout][cin][taps] tensor that receives the folded weight g * v / ||v|| during the same pass.
+        a parameter changed (optimizer step, load_state_dict, .to()).  Training engine extras, produced by the same
+        launches: `folded[name]` (fp32 [cout][cin][taps]) receives the folded weight g * v / ||v|| of a weight-normed
+        conv, `wt[name]` the transposed + tap-flipped dgrad plane.  Equally shaped weights go through ONE grouped
+        call (`efts_pack_weights_grouped`, a device-side item table) instead of a launch each.
         `_packed_sig` cannot see in-place updates made by the fused optimizer kernel (no version bump), which is
         why EftsAdam resets it and why consumers of derived data compare `_packed_gen`, never the signature."""
         sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -222,26 +225,48 @@ class EfficientTTSCNN(torch.nn.Module):
             return self._packed
         dev = self.text_embedding_table.weight.device
         pk = self._packed
-        for name, conv in self._conv_modules():
-            taps = conv.kernel_size[0]
+        folded = folded or {}
+        wt = wt or {}
+        mods = [(name, conv, conv.kernel_size[0]) for name, conv in self._conv_modules()]
+        mods += [(name, lin, 1) for name, lin in (("key", self.text_encoder_key), ("value", self.text_encoder_value),
+                                                    ("prenet", self.mel_prenet[0]), ("head", self.mel_output_layer))]
+        groups: Dict[Tuple, list] = {}
+        for name, mod, taps in mods:
+            cout, cin = mod.weight_v.shape[:2] if hasattr(mod, "weight_g") else mod.weight.shape[:2]
             if name not in pk or pk[name].buf.device != dev:
-                pk[name] = PackedWeight(conv.out_channels, conv.in_channels, taps, self.split, dev)
-            if hasattr(conv, "weight_g"):
-                pk[name].pack(conv.weight_v.detach().contiguous(), conv.weight_g.detach().contiguous(),
-                              None if folded is None else folded.get(name))
-            else:
-                pk[name].pack(conv.weight.detach().contiguous())
-        lin_split = {"key": self.split, "value": self.split, "prenet": self.split, "head": self.split}
-        lins = {"key": self.text_encoder_key, "value": self.text_encoder_value, "prenet": self.mel_prenet[0],
-                "head": self.mel_output_layer}
-        for name, lin in lins.items():
-            if name not in pk or pk[name].buf.device != dev:
-                pk[name] = PackedWeight(lin.out_features, lin.in_features, 1, lin_split[name], dev)
-            pk[name].pack(lin.weight.detach().contiguous())
+                pk[name] = PackedWeight(cout, cin, taps, self.split, dev)
+            groups.setdefault((cout, cin, taps, name in wt), []).append((name, mod))
+        lib = L.load()
+        table_rows, launches = [], []
+        for (cout, cin, taps, with_t), members in groups.items():
+            first = len(table_rows)
+            tiled = cout % 64 == 0 and cin % 64 == 0 and taps <= 5     # the library's one-pass path: no folded copy needed
+            for name, mod in members:
+                if hasattr(mod, "weight_g"):
+                    w, g = mod.weight_v.detach(), mod.weight_g.detach()
+                    fo = None if tiled else folded.get(name)
+                    if with_t and not tiled and fo is None:
+                        raise L.EftsError(f"{name}: the row pack kernels need a folded fp32 copy for the dgrad plane")
+                else:
+                    w, g, fo = mod.weight.detach(), None, None
+                assert w.is_contiguous()
+                table_rows.append((w.data_ptr(), 0 if g is None else g.data_ptr(), 0 if fo is None else fo.data_ptr(),
+                                   pk[name].ptr, wt[name].ptr if with_t else 0))
+            ref = pk[members[0][0]]
+            launches.append((first, len(members), ref.ld, wt[members[0][0]].ld if with_t else 0, cout, cin, taps, int(with_t)))
+        key = tuple(table_rows)
+        if getattr(self, "_pack_table_key", None) != key:              # pointers are stable across steps: built once
+            object.__setattr__(self, "_pack_table", torch.tensor(table_rows, dtype=torch.int64, device=dev))
+            object.__setattr__(self, "_pack_scale", torch.empty(max(n * co for _, n, _, _, co, _, _, _ in launches), device=dev))
+            object.__setattr__(self, "_pack_table_key", key)
+        base = self._pack_table.data_ptr()
+        for first, n, ld, ld_t, cout, cin, taps, with_t in launches:
+            L.check(lib.efts_pack_weights_grouped(base + first * 40, n, self._pack_scale.data_ptr(), ld, ld_t, cout, cin, taps,
+                                                  self.split, with_t, O._stream()), "efts_pack_weights_grouped")
         self._packed_sig = sig
         self._packed_gen += 1
-        if folded is not None:
-            self._folded_gen = self._packed_gen
+        if wt:
+            self._folded_gen = self._packed_gen      # this repack also wrote the training engine's derived copies
         return pk
 
     def _side_stream(self, device) -> "torch.cuda.Stream":

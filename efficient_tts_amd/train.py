@@ -106,34 +106,25 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ weights for the backward
     def _prepare_weights(self):
-        """forward planes (model._weights), folded fp32 weights and transposed/flipped dgrad planes.  Everything
-        derived here follows `model._packed_gen`, the repack counter: the fused optimizer updates parameters in
-        place without a version bump, so the signature of the parameters cannot be used to detect a change."""
+        """forward planes, folded fp32 weights and transposed/flipped dgrad planes, all from `model._weights` (a handful
+        of grouped launches).  The derived copies follow `model._packed_gen` / `_folded_gen`, the repack counters: the
+        fused optimizer updates parameters in place without a version bump, so the signature of the parameters cannot
+        be used to detect a change, and an eval forward in between repacks without writing the copies kept here."""
         m = self.m
         dev = self.dev
         for name, conv in m._conv_modules():
-            if name not in self.folded:
+            if name not in self.wt:
                 taps = conv.kernel_size[0]
-                self.folded[name] = torch.empty(conv.out_channels, conv.in_channels, taps, device=dev)
+                if hasattr(conv, "weight_g") and (conv.out_channels % 64 or conv.in_channels % 64 or taps > 5):
+                    self.folded[name] = torch.empty(conv.out_channels, conv.in_channels, taps, device=dev)   # row-kernel shapes only
                 self.wt[name] = PackedWeight(conv.in_channels, conv.out_channels, taps, m.split, dev)
-        folded = self.folded                    # written for the weight-normed convolutions only
-        pk = m._weights(folded)
-        if m._folded_gen != m._packed_gen:
-            m._packed_sig = None                # the last repack (an eval forward) did not write the folded copies
-            pk = m._weights(folded)
-        gen = m._packed_gen
-        if gen == self._sig:
-            return pk
-        for name, conv in m._conv_modules():
-            wsrc = self.folded[name] if hasattr(conv, "weight_g") else conv.weight.detach().contiguous()
-            L.check(_lib().efts_pack_weight_t(wsrc.data_ptr(), self.wt[name].ptr, self.wt[name].ld, conv.out_channels,
-                                              conv.in_channels, conv.kernel_size[0], m.split, O._stream()), "efts_pack_weight_t")
         for name, lin in (("key", m.text_encoder_key), ("value", m.text_encoder_value), ("head", m.mel_output_layer)):
             if name not in self.wt:
                 self.wt[name] = PackedWeight(lin.in_features, lin.out_features, 1, m.split, dev)
-            L.check(_lib().efts_pack_weight_t(lin.weight.detach().contiguous().data_ptr(), self.wt[name].ptr, self.wt[name].ld,
-                                              lin.out_features, lin.in_features, 1, m.split, O._stream()), "efts_pack_weight_t")
-        self._sig = gen
+        pk = m._weights(self.folded, self.wt)
+        if m._folded_gen != m._packed_gen:
+            m._packed_sig = None                # the last repack (an eval forward) did not write the copies kept here
+            pk = m._weights(self.folded, self.wt)
         return pk
 
     # ------------------------------------------------------------------ small wrappers

@@ -211,6 +211,22 @@ int efts_masked_losses(const float* mel_pred, int64_t ldm, const float* speech, 
 /* folded weight w[cout][cin][taps] -> dgrad B plane [taps][cin rows][K = cout], taps flipped */
 int efts_pack_weight_t(const float* w, void* plane, int64_t ldb, int32_t cout, int32_t cin, int32_t taps,
                        int32_t split, void* stream);
+/* Weight preparation of a whole group of equally shaped Conv1d / Linear weights in one call (2 launches): per item
+ * efts_pack_weight (plane and/or w_f32_out; either may be NULL) and, with with_t != 0, efts_pack_weight_t into plane_t
+ * (NULL = skip the item) from the folded weight.  `items` is an array in DEVICE memory.  scale_ws: n_items * cout
+ * floats of device scratch (weight-norm scales); with it, shapes with cout % 64 == 0, cin % 64 == 0, taps <= 5 take
+ * the tiled path (one pass over the weights writes both planes); NULL or other shapes: row kernels, which need
+ * w_f32_out for a weight-normed item that has a plane_t.  The reference does this work implicitly per layer and
+ * step: the weight_norm hook (efts_modules.py:92-99) in every forward, the transposed operand inside cuDNN's dgrad. */
+typedef struct efts_pack_item {
+    const float* w;        /* [cout][cin][taps] fp32: weight_v, or the plain weight when g == NULL */
+    const float* g;        /* weight-norm gain [cout] or NULL */
+    float* w_f32_out;      /* folded fp32 copy [cout][cin][taps] or NULL */
+    void* plane;           /* forward B plane [taps][cout][Kp(cin)], row stride ldb, or NULL */
+    void* plane_t;         /* transposed + tap-flipped dgrad plane [taps][cin][Kp(cout)], row stride ldb_t, or NULL */
+} efts_pack_item;
+int efts_pack_weights_grouped(const efts_pack_item* items, int32_t n_items, float* scale_ws, int64_t ldb, int64_t ldb_t,
+                              int32_t cout, int32_t cin, int32_t taps, int32_t split, int32_t with_t, void* stream);
 /* d loss / d mel_pred (fp32 [B*T2p][odim] and/or operand plane) and d loss / d dur_pred [B*T1p]
  * of FastSpeechLoss(use_masking) (fastspeech_loss.py:54-67); gscale: device scalar or NULL (1). */
 int efts_loss_bwd(const float* mel_pred, int64_t ldm, const float* speech, const int32_t* mel_len,
