@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #ifndef EFTS_LNB_ROWS
 #define EFTS_LNB_ROWS 8
 #endif
-constexpr int LNB_ROWS = EFTS_LNB_ROWS;    // rows per block: the duration predictor only has B*T1 (~4k) rows, 32 per block left half the CUs idle
+constexpr int LNB_ROWS = EFTS_LNB_ROWS;    // default rows per block (EFTS_LNB_ROWS env overrides): the duration predictor only has B*T1 (~4k) rows
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps,
                                                             const float* __restrict__ dy_in, const float* __restrict__ ddur,
@@ -239,18 +239,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             float* __restrict__ dz, char* __restrict__ plane, long ldp, int split,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             float* __restrict__ dbias, float* __restrict__ dw, float* __restrict__ db,
-                                                            int rows, int c, float drop_p, unsigned drop_seed) {
-    extern __shared__ float acc_s[];                   // [4][c]: dgamma, dbeta, dbias, dw  (block partials)
+                                                            int rows, int c, float drop_p, unsigned drop_seed, int ROWS) {
+    extern __shared__ float acc_s[];                   // [4 waves][4][c]: dgamma, dbeta, dbias, dw partials of each wave
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 4 * c; i += 256) acc_s[i] = 0.f;
-    __syncthreads();
+    // per-lane accumulators of the channels this lane owns in every row (u * 256 + lane * 4 + e): the column sums
+    // stay in registers across the wave's rows; LDS only combines the 4 waves, global atomics only the blocks
+    float ag[8][4], ab[8][4], ac[8][4], aw[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ag[u][e] = ab[u][e] = ac[u][e] = aw[u][e] = 0.f;
     const int nv = c >> 8;
     const bool drop = drop_p > 0.f;
     const unsigned thresh = drop ? (unsigned)(drop_p * 4294967296.0) : 0u, seed_h = hash_u32(drop_seed);
     const float inv_keep = drop ? 1.f / (1.f - drop_p) : 1.f;
     float db_loc = 0.f;
     // each wave walks rows blockIdx.x*ROWS + wv, +4, ...
-    constexpr int ROWS = LNB_ROWS;
     for (int rr = wv; rr < ROWS; rr += 4) {
         const int row = blockIdx.x * ROWS + rr;
         if (row >= rows) break;
@@ -311,22 +315,35 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                     const float h = (xs[e] - mean) * rstd;
                     const float dx = rstd * (dys[e] * gms[e] - s1 - h * s2);
                     o[e] = (xs[e] > 0.f ? dx : 0.f) * rm;
-                    atomicAdd(&acc_s[0 * c + c4 + e], dys[e] * h);
-                    atomicAdd(&acc_s[1 * c + c4 + e], dys[e]);
-                    atomicAdd(&acc_s[2 * c + c4 + e], o[e]);
-                    if (ddur) atomicAdd(&acc_s[3 * c + c4 + e], dd * (h * gms[e] + bts[e]) * dms[e]);
+                    ag[u][e] += dys[e] * h;
+                    ab[u][e] += dys[e];
+                    ac[u][e] += o[e];
+                    if (ddur) aw[u][e] += dd * (h * gms[e] + bts[e]) * dms[e];
                 }
                 if (dz) *(float4*)(dz + (long)row * c + c4) = make_float4(o[0], o[1], o[2], o[3]);
                 if (plane) plane_store4(plane + (long)row * ldp, c4, o[0], o[1], o[2], o[3], split);
             }
         if (lane == 0) db_loc += dd;
     }
+    float* mine = acc_s + (long)wv * 4 * c;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (u < nv) {
+            const int c4 = u * 256 + lane * 4;
+            *(float4*)(mine + c4) = make_float4(ag[u][0], ag[u][1], ag[u][2], ag[u][3]);
+            *(float4*)(mine + c + c4) = make_float4(ab[u][0], ab[u][1], ab[u][2], ab[u][3]);
+            *(float4*)(mine + 2 * c + c4) = make_float4(ac[u][0], ac[u][1], ac[u][2], ac[u][3]);
+            *(float4*)(mine + 3 * c + c4) = make_float4(aw[u][0], aw[u][1], aw[u][2], aw[u][3]);
+        }
     __syncthreads();
     for (int i = threadIdx.x; i < c; i += 256) {
-        atomicAdd(dgamma + i, acc_s[i]);
-        atomicAdd(dbeta + i, acc_s[c + i]);
-        if (dbias) atomicAdd(dbias + i, acc_s[2 * c + i]);
-        if (dw) atomicAdd(dw + i, acc_s[3 * c + i]);
+        float t[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = acc_s[q * c + i] + acc_s[4 * c + q * c + i] + acc_s[8 * c + q * c + i] + acc_s[12 * c + q * c + i];
+        atomicAdd(dgamma + i, t[0]);
+        atomicAdd(dbeta + i, t[1]);
+        if (dbias) atomicAdd(dbias + i, t[2]);
+        if (dw) atomicAdd(dw + i, t[3]);
     }
     if (db && lane == 0 && db_loc != 0.f) atomicAdd(db, db_loc);
 }
@@ -751,8 +768,11 @@ extern "C" int efts_layernorm_bwd(const float* x, const float* gamma, const floa
                                   uint32_t drop_seed, void* stream) {
     if (!x || !gamma || !beta || (!dy && !ddur) || (ddur && !w) || !dgamma || !dbeta) return efts_fail(EFTS_EINVAL, "efts_layernorm_bwd: null pointer");
     if (c % 256 || c > 2048) return efts_fail(EFTS_ESHAPE, "efts_layernorm_bwd: c must be a multiple of 256, <= 2048");
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + LNB_ROWS - 1) / LNB_ROWS), dim3(256), (size_t)4 * c * sizeof(float), ST, x, gamma, beta, eps, dy, ddur, w,
-                       rowmask, dz, (char*)plane, (long)ld_plane, split, dgamma, dbeta, dbias, dw, db, rows, c, drop_p, drop_seed);
+    int rpb = LNB_ROWS;                        // rows per block
+    { const char* e = getenv("EFTS_LNB_ROWS"); if (e && atoi(e) >= 4) rpb = atoi(e) & ~3; }
+    if (c > 768) (void)hipFuncSetAttribute((const void*)layernorm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * c * (int)sizeof(float));
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), (size_t)16 * c * sizeof(float), ST, x, gamma, beta, eps, dy, ddur, w,
+                       rowmask, dz, (char*)plane, (long)ld_plane, split, dgamma, dbeta, dbias, dw, db, rows, c, drop_p, drop_seed, rpb);
     return efts_check_launch("efts_layernorm_bwd");
 }
 
