@@ -95,6 +95,7 @@ class TrainEngine:
         self.folded: Dict[str, torch.Tensor] = {}
         self.wt: Dict[str, PackedWeight] = {}
         self._sig = None
+        self._ws_tag = ""                       # "s" while work is being enqueued on the side stream
         self.bucket_hook: Optional[Callable[[int], None]] = None
         self.join_reduce: Optional[Callable[[], None]] = None
 
@@ -142,11 +143,12 @@ class TrainEngine:
         S = max(1, min(32, (_WGRAD_WGS + tiles * taps - 1) // (tiles * taps), nch_total))    # ~_WGRAD_WGS workgroups per launch
         nch = (nch_total + S - 1) // S
         kpad = O.roundup(S * nch * ck, 64)
-        zt = ws.get(("zt", cout, kpad, split), lambda: _TPlane(cout, kpad, split, self.dev))
+        tag = self._ws_tag                       # the side stream owns its own scratch (both streams run wgrads at once)
+        zt = ws.get(("zt", tag, cout, kpad, split), lambda: _TPlane(cout, kpad, split, self.dev))
         L.check(_lib().efts_pack_t(dz_ptr, cout, zt.ptr, zt.ld, 0, split, rows, cout, 0, 1, kpad, O._stream()), "efts_pack_t")
-        part = ws.get(("part", taps, S, cout, cin), lambda: torch.empty(taps, S, cout, cin, device=self.dev))
+        part = ws.get(("part", tag, taps, S, cout, cin), lambda: torch.empty(taps, S, cout, cin, device=self.dev))
         pad = (taps - 1) // 2
-        xts = ws.get(("xt", cin, kpad, split, taps), lambda: _TPlaneStack(cin, kpad, split, taps, self.dev))
+        xts = ws.get(("xt", tag, cin, kpad, split, taps), lambda: _TPlaneStack(cin, kpad, split, taps, self.dev))
         L.check(_lib().efts_pack_t(x_ptr, ldx, xts.ptr, xts.ld, xts.plane_bytes, split, rows, cin, -pad, taps, kpad, O._stream()),
                 "efts_pack_t")
         O.gemm(a=zt, b_ptr=xts.ptr, ldb=xts.ld, m=cout, n=cin, batch=S, nchunk=nch, a_batch_stride=nch * 128, b_batch_stride=nch * 128,
@@ -158,7 +160,7 @@ class TrainEngine:
     def _wgrad_tn(self, ws, dz_p: Plane, x_p: Plane, cout, cin, rows, v, g, out_dw, out_dg):
         """k5 wgrad straight from the row-major bf16 planes (csrc/efts_wgrad.hip): no transposed copies"""
         S = _WGRAD_TN_SPLITS
-        part = ws.get(("part", 5, S, cout, cin), lambda: torch.empty(5, S, cout, cin, device=self.dev))
+        part = ws.get(("part", self._ws_tag, 5, S, cout, cin), lambda: torch.empty(5, S, cout, cin, device=self.dev))
         L.check(_lib().efts_wgrad_tn(dz_p.ptr, dz_p.ld, x_p.ptr, x_p.ld, part.data_ptr(), rows, cout, cin, 5, S, dz_p.split, O._stream()),
                 "efts_wgrad_tn")
         L.check(_lib().efts_wgrad_reduce(part.data_ptr(), S, _ptr(v), _ptr(g), out_dw.data_ptr(), _ptr(out_dg), cout, cin, 5,
@@ -236,17 +238,52 @@ class TrainEngine:
         O.row_masks(ml, rs2, gap2, len2)
         self.flat.zero_()
 
+        # Two HIP streams.  The text-length work (embedding, text encoder, K/V, duration predictor and all of their
+        # backward) runs on ~B*T1 = 4k rows: launches of 70-270 workgroups that leave most of the chip idle.  None of it
+        # depends on the mel-length work except through K/V (forward) and dK/dV/d(dur) (backward), so it goes to a side
+        # stream and fills the idle CUs / tail rounds of the mel-length kernels; events mark the few hand-over points.
+        main = torch.cuda.current_stream(dev)
+        side = m._side_stream(dev)
+        side.wait_stream(main)
+        dp = m.duration_predictor
+        ln0, ln1 = dp.conv[0][2], dp.conv[1][2]
+        # Dropout(0.1) of the duration predictor is active in train() mode like the reference's
+        # (duration_predictor.py:61; the model never forwards its own dropout_rate to it)
+        drop_p = float(dp.conv[0][3].p) if m.training else 0.0
+        self.drop_calls = getattr(self, "drop_calls", 0) + 1
+        seed0, seed1 = (m.dropout_seed + 2 * self.drop_calls) & 0xFFFFFFFF, (m.dropout_seed + 2 * self.drop_calls + 1) & 0xFFFFFFFF
+
         # ============================ forward (efficient_tts.py:144-227), activations kept
-        emb_f, emb_p = ws.f32("Temb_f", rs1, C), ws.plane("Temb_p", rs1, C, split)
-        O.embed(text, m.text_embedding_table.weight.detach(), emb_f, emb_p, rs1)
-        te_f, te_p, te_saved = self._stack_fwd(ws, "te", "text_encoder", pk, rs1, emb_f, emb_p, gap1.data_ptr(), split)
-        key_f, key_p = ws.f32("Tkey_f", rs1, C), ws.plane("Tkey_p", rs1, C, 2)
-        val_f, val_p = ws.f32("Tval_f", rs1, C), ws.plane("Tval_p", rs1, C, split)
-        wk, wv = pk["key"], pk["value"]
-        O.gemm(a=te_p, b_ptr=wk.ptr, ldb=wk.ld, m=rs1.rows, n=C, bias=m.text_encoder_key.bias, rowmask_ptr=len1.data_ptr(),
-               out_f32_ptr=key_f.ptr, ldo=C, out_plane=key_p)
-        O.gemm(a=te_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=m.text_encoder_value.bias, rowmask_ptr=len1.data_ptr(),
-               out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p)
+        with O.on_stream(side):
+            self._ws_tag = "s"
+            emb_f, emb_p = ws.f32("Temb_f", rs1, C), ws.plane("Temb_p", rs1, C, split)
+            O.embed(text, m.text_embedding_table.weight.detach(), emb_f, emb_p, rs1)
+            te_f, te_p, te_saved = self._stack_fwd(ws, "te", "text_encoder", pk, rs1, emb_f, emb_p, gap1.data_ptr(), split)
+            key_f, key_p = ws.f32("Tkey_f", rs1, C), ws.plane("Tkey_p", rs1, C, 2)
+            val_f, val_p = ws.f32("Tval_f", rs1, C), ws.plane("Tval_p", rs1, C, split)
+            wk, wv = pk["key"], pk["value"]
+            O.gemm(a=te_p, b_ptr=wk.ptr, ldb=wk.ld, m=rs1.rows, n=C, bias=m.text_encoder_key.bias, rowmask_ptr=len1.data_ptr(),
+                   out_f32_ptr=key_f.ptr, ldo=C, out_plane=key_p)
+            O.gemm(a=te_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=m.text_encoder_value.bias, rowmask_ptr=len1.data_ptr(),
+                   out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p)
+            ev_kv = torch.cuda.Event()
+            ev_kv.record(side)
+            # duration predictor (efficient_tts.py:219): needs V only
+            h1_f, l1_f, l1_p = ws.f32("Tdur_h1", rs1, C), ws.f32("Tdur_l1", rs1, C), ws.plane("Tdur_l1p", rs1, C, split)
+            h2_f = ws.f32("Tdur_h2", rs1, C)
+            dur = ws.tensor("Tdur_out", (rs1.rows,))
+            w0, w1 = pk["dur.0"], pk["dur.1"]
+            O.gemm(a=val_p, b_ptr=w0.ptr, ldb=w0.ld, b_tap_stride=w0.tap_stride, taps=3, m=rs1.rows, n=C, act=L.ACT_RELU,
+                   bias=dp.conv[0][0].bias, out_f32_ptr=h1_f.ptr, ldo=C)
+            O.layernorm_rows(h1_f.ptr, ln0.weight.detach(), ln0.bias.detach(), ln0.eps, gap1.data_ptr(), l1_f.ptr, l1_p, rs1.rows, C,
+                             drop_p, seed0)
+            O.gemm(a=l1_p, b_ptr=w1.ptr, ldb=w1.ld, b_tap_stride=w1.tap_stride, taps=3, m=rs1.rows, n=C, act=L.ACT_RELU,
+                   bias=dp.conv[1][0].bias, out_f32_ptr=h2_f.ptr, ldo=C)
+            O.layernorm_dot(h2_f.ptr, ln1.weight.detach(), ln1.bias.detach(), ln1.eps, dp.linear.weight.detach(),
+                            dp.linear.bias.detach(), len1.data_ptr(), 0, float(dp.offset), dur, rs1.rows, C, drop_p, seed1)
+            ev_dur = torch.cuda.Event()
+            ev_dur.record(side)
+            self._ws_tag = ""
 
         mel_in_f, mel_in = ws.f32("Tmel_in_f", rs2, odim), ws.plane("Tmel_in", rs2, odim, split)
         O.pack_rows(speech, mel_in_f, mel_in, rs2)
@@ -256,6 +293,7 @@ class TrainEngine:
                rowmask_ptr=gap2.data_ptr(), out_f32_ptr=pre_f.ptr, ldo=C, out_plane=pre_p)
         q_f, q_p, me_saved = self._stack_fwd(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2)
 
+        main.wait_event(ev_kv)                                      # K, V from the side stream
         scale = O.INV_SQRT(C)
         scores = ws.tensor("Tscores", (B, T2, T1))
         O.gemm(a=q_p, b_ptr=key_p.ptr, ldb=key_p.ld, m=T2, n=T1, batch=B, a_batch_stride=rs2.Tp * q_p.ld,
@@ -281,26 +319,7 @@ class TrainEngine:
         O.gemm(a=d_p, b_ptr=wh.ptr, ldb=wh.ld, m=rs2.rows, n=odim, bias=m.mel_output_layer.bias, rowmask_ptr=len2.data_ptr(),
                out_f32_ptr=mel.ptr, ldo=odim)
 
-        dp = m.duration_predictor
-        h1_f, l1_f, l1_p = ws.f32("Tdur_h1", rs1, C), ws.f32("Tdur_l1", rs1, C), ws.plane("Tdur_l1p", rs1, C, split)
-        h2_f = ws.f32("Tdur_h2", rs1, C)
-        dur = ws.tensor("Tdur_out", (rs1.rows,))
-        w0, w1 = pk["dur.0"], pk["dur.1"]
-        ln0, ln1 = dp.conv[0][2], dp.conv[1][2]
-        O.gemm(a=val_p, b_ptr=w0.ptr, ldb=w0.ld, b_tap_stride=w0.tap_stride, taps=3, m=rs1.rows, n=C, act=L.ACT_RELU,
-               bias=dp.conv[0][0].bias, out_f32_ptr=h1_f.ptr, ldo=C)
-        # Dropout(0.1) of the duration predictor is active in train() mode like the reference's
-        # (duration_predictor.py:61; the model never forwards its own dropout_rate to it)
-        drop_p = float(dp.conv[0][3].p) if m.training else 0.0
-        self.drop_calls = getattr(self, "drop_calls", 0) + 1
-        seed0, seed1 = (m.dropout_seed + 2 * self.drop_calls) & 0xFFFFFFFF, (m.dropout_seed + 2 * self.drop_calls + 1) & 0xFFFFFFFF
-        O.layernorm_rows(h1_f.ptr, ln0.weight.detach(), ln0.bias.detach(), ln0.eps, gap1.data_ptr(), l1_f.ptr, l1_p, rs1.rows, C,
-                         drop_p, seed0)
-        O.gemm(a=l1_p, b_ptr=w1.ptr, ldb=w1.ld, b_tap_stride=w1.tap_stride, taps=3, m=rs1.rows, n=C, act=L.ACT_RELU,
-               bias=dp.conv[1][0].bias, out_f32_ptr=h2_f.ptr, ldo=C)
-        O.layernorm_dot(h2_f.ptr, ln1.weight.detach(), ln1.bias.detach(), ln1.eps, dp.linear.weight.detach(),
-                        dp.linear.bias.detach(), len1.data_ptr(), 0, float(dp.offset), dur, rs1.rows, C, drop_p, seed1)
-
+        main.wait_event(ev_dur)                                     # predicted durations from the side stream
         out3 = torch.empty(3, dtype=torch.float32, device=dev)
         O.masked_losses(mel.ptr, odim, speech, ml, dur, lde, tl, out3, ws.tensor("loss_ws", (1024,)), B, T1, rs1.Tp, T2, rs2.Tp, odim)
 
@@ -312,6 +331,38 @@ class TrainEngine:
         L.check(_lib().efts_loss_bwd(mel.ptr, odim, speech.data_ptr(), ml.data_ptr(), dur.data_ptr(), lde.data_ptr(), tl.data_ptr(),
                                      _ptr(gscale), dmel_f.ptr, None, 0, split, ddur.data_ptr(), B, T1, rs1.Tp, T2, rs2.Tp, odim,
                                      O._stream()), "efts_loss_bwd")
+        ev_loss = torch.cuda.Event()
+        ev_loss.record(main)
+        side.wait_event(ev_loss)                                    # d(dur) is ready
+        with O.on_stream(side):
+            self._ws_tag = "s"
+            # ---- duration predictor (input text_value is NOT detached: efficient_tts.py:219)
+            def gname(i, k):
+                return f"duration_predictor.conv.{i}.{k}"
+            dz2_f, dz2_p = ws.f32("Bdur_dz2", rs1, C), ws.plane("Bdur_dz2p", rs1, C, split)
+            L.check(_lib().efts_layernorm_bwd(h2_f.ptr, ln1.weight.data_ptr(), ln1.bias.data_ptr(), ln1.eps, None, ddur.data_ptr(),
+                                              dp.linear.weight.data_ptr(), None, dz2_f.ptr, dz2_p.ptr, dz2_p.ld, split,
+                                              g[gname(1, "2.weight")].data_ptr(), g[gname(1, "2.bias")].data_ptr(),
+                                              g[gname(1, "0.bias")].data_ptr(), g["duration_predictor.linear.weight"].data_ptr(),
+                                              g["duration_predictor.linear.bias"].data_ptr(), rs1.rows, C, drop_p, seed1, O._stream()),
+                    "efts_layernorm_bwd")
+            self._wgrad(ws, dz2_f.ptr, C, l1_f.ptr, C, C, 3, rs1.rows, None, None, g[gname(1, "0.weight")], None)
+            G1 = ws.f32("Bdur_G1", rs1, C)
+            wt = self.wt["dur.1"]
+            O.gemm(a=dz2_p, b_ptr=wt.ptr, ldb=wt.ld, b_tap_stride=wt.tap_stride, taps=3, m=rs1.rows, n=C, out_f32_ptr=G1.ptr, ldo=C)
+            dz1_f, dz1_p = ws.f32("Bdur_dz1", rs1, C), ws.plane("Bdur_dz1p", rs1, C, split)
+            L.check(_lib().efts_layernorm_bwd(h1_f.ptr, ln0.weight.data_ptr(), ln0.bias.data_ptr(), ln0.eps, G1.ptr, None, None,
+                                              gap1.data_ptr(), dz1_f.ptr, dz1_p.ptr, dz1_p.ld, split,
+                                              g[gname(0, "2.weight")].data_ptr(), g[gname(0, "2.bias")].data_ptr(),
+                                              g[gname(0, "0.bias")].data_ptr(), None, None, rs1.rows, C, drop_p, seed0, O._stream()),
+                    "efts_layernorm_bwd")
+            self._wgrad(ws, dz1_f.ptr, C, val_f.ptr, C, C, 3, rs1.rows, None, None, g[gname(0, "0.weight")], None)
+            dV_dur = ws.f32("BdV_dur", rs1, C)
+            wt = self.wt["dur.0"]
+            O.gemm(a=dz1_p, b_ptr=wt.ptr, ldb=wt.ld, b_tap_stride=wt.tap_stride, taps=3, m=rs1.rows, n=C, out_f32_ptr=dV_dur.ptr, ldo=C)
+            ev_durb = torch.cuda.Event()
+            ev_durb.record(side)
+            self._ws_tag = ""
         # mel head (Linear 512->80, masked): bias grad + operand plane, wgrad, dgrad
         self._act_bwd(dmel_f.ptr, None, None, None, 0, None, dmel_p, g["mel_output_layer.bias"], rs2.rows, odim)
         self._wgrad(ws, dmel_f.ptr, odim, d_f.ptr, C, C, 1, rs2.rows, None, None, g["mel_output_layer.weight"], None)
@@ -323,31 +374,6 @@ class TrainEngine:
         dH = self._stack_bwd(ws, "dec", "decoder", rs2, G, dec_saved, gap2.data_ptr(), len2.data_ptr(), dH_p)
         if self.bucket_hook:
             self.bucket_hook(0)
-
-        # ---- duration predictor (input text_value is NOT detached: efficient_tts.py:219)
-        def gname(i, k):
-            return f"duration_predictor.conv.{i}.{k}"
-        dz2_f, dz2_p = ws.f32("Bdur_dz2", rs1, C), ws.plane("Bdur_dz2p", rs1, C, split)
-        L.check(_lib().efts_layernorm_bwd(h2_f.ptr, ln1.weight.data_ptr(), ln1.bias.data_ptr(), ln1.eps, None, ddur.data_ptr(),
-                                          dp.linear.weight.data_ptr(), None, dz2_f.ptr, dz2_p.ptr, dz2_p.ld, split,
-                                          g[gname(1, "2.weight")].data_ptr(), g[gname(1, "2.bias")].data_ptr(),
-                                          g[gname(1, "0.bias")].data_ptr(), g["duration_predictor.linear.weight"].data_ptr(),
-                                          g["duration_predictor.linear.bias"].data_ptr(), rs1.rows, C, drop_p, seed1, O._stream()),
-                "efts_layernorm_bwd")
-        self._wgrad(ws, dz2_f.ptr, C, l1_f.ptr, C, C, 3, rs1.rows, None, None, g[gname(1, "0.weight")], None)
-        G1 = ws.f32("Bdur_G1", rs1, C)
-        wt = self.wt["dur.1"]
-        O.gemm(a=dz2_p, b_ptr=wt.ptr, ldb=wt.ld, b_tap_stride=wt.tap_stride, taps=3, m=rs1.rows, n=C, out_f32_ptr=G1.ptr, ldo=C)
-        dz1_f, dz1_p = ws.f32("Bdur_dz1", rs1, C), ws.plane("Bdur_dz1p", rs1, C, split)
-        L.check(_lib().efts_layernorm_bwd(h1_f.ptr, ln0.weight.data_ptr(), ln0.bias.data_ptr(), ln0.eps, G1.ptr, None, None,
-                                          gap1.data_ptr(), dz1_f.ptr, dz1_p.ptr, dz1_p.ld, split,
-                                          g[gname(0, "2.weight")].data_ptr(), g[gname(0, "2.bias")].data_ptr(),
-                                          g[gname(0, "0.bias")].data_ptr(), None, None, rs1.rows, C, drop_p, seed0, O._stream()),
-                "efts_layernorm_bwd")
-        self._wgrad(ws, dz1_f.ptr, C, val_f.ptr, C, C, 3, rs1.rows, None, None, g[gname(0, "0.weight")], None)
-        dV_dur = ws.f32("BdV_dur", rs1, C)
-        wt = self.wt["dur.0"]
-        O.gemm(a=dz1_p, b_ptr=wt.ptr, ldb=wt.ld, b_tap_stride=wt.tap_stride, taps=3, m=rs1.rows, n=C, out_f32_ptr=dV_dur.ptr, ldo=C)
 
         # ---- expand bmm backward: d alpha' [B,T1,T2] and dV
         val_p2 = ws.plane("Bval_p2", rs1, C, 2)
@@ -361,6 +387,7 @@ class TrainEngine:
         O.pack_vt(dH, dHt, B, T2, rs2.Tp, C)
         GV = ws.f32("BGV", rs1, C)
         GV_p = ws.plane("BGV_p", rs1, C, split)
+        main.wait_event(ev_durb)                                    # dV of the duration predictor (and its gradients: bucket 1)
         O.gemm(a=ra1_p, b_ptr=dHt.ptr, ldb=dHt.ld, m=T1, n=C, batch=B, a_batch_stride=rs1.Tp * ra1_p.ld, b_batch_stride=C * dHt.ld,
                resid_ptr=dV_dur.ptr, ldr=C, resid_batch_stride=rs1.Tp * C, rowmask_ptr=len1.data_ptr(), rowmask_batch_stride=rs1.Tp,
                out_f32_ptr=GV.ptr, ldo=C, out_batch_stride=rs1.Tp * C, out_plane=GV_p, outb_batch_stride=rs1.Tp * GV_p.ld)
@@ -393,6 +420,28 @@ class TrainEngine:
                rowmask_ptr=len1.data_ptr(), rowmask_batch_stride=rs1.Tp, out_f32_ptr=GK.ptr, ldo=C, out_batch_stride=rs1.Tp * C,
                out_plane=GK_p, outb_batch_stride=rs1.Tp * GK_p.ld)
 
+        ev_gk = torch.cuda.Event()
+        ev_gk.record(main)
+        side.wait_event(ev_gk)                                      # dK, dV are ready
+        with O.on_stream(side):
+            self._ws_tag = "s"
+            # ---- value / key Linears -> text encoder -> embedding
+            L.check(_lib().efts_act_bwd(GV.ptr, None, None, None, 0.0, 0, ws.f32("Bscratch1", rs1, C).ptr, None, 0, 1,
+                                        g["text_encoder_value.bias"].data_ptr(), rs1.rows, C, O._stream()), "efts_act_bwd")
+            L.check(_lib().efts_act_bwd(GK.ptr, None, None, None, 0.0, 0, ws.f32("Bscratch1", rs1, C).ptr, None, 0, 1,
+                                        g["text_encoder_key.bias"].data_ptr(), rs1.rows, C, O._stream()), "efts_act_bwd")
+            self._wgrad(ws, GV.ptr, C, te_f.ptr, C, C, 1, rs1.rows, None, None, g["text_encoder_value.weight"], None)
+            self._wgrad(ws, GK.ptr, C, te_f.ptr, C, C, 1, rs1.rows, None, None, g["text_encoder_key.weight"], None)
+            Gt0, Gt = ws.f32("Bte_G0", rs1, C), ws.f32("Bte_G1x", rs1, C)
+            wtv, wtk = self.wt["value"], self.wt["key"]
+            O.gemm(a=GV_p, b_ptr=wtv.ptr, ldb=wtv.ld, m=rs1.rows, n=C, rowmask_ptr=gap1.data_ptr(), out_f32_ptr=Gt0.ptr, ldo=C)
+            O.gemm(a=GK_p, b_ptr=wtk.ptr, ldb=wtk.ld, m=rs1.rows, n=C, resid_ptr=Gt0.ptr, ldr=C, rowmask_ptr=gap1.data_ptr(),
+                   out_f32_ptr=Gt.ptr, ldo=C)
+            Ge = self._stack_bwd(ws, "te", "text_encoder", rs1, Gt, te_saved, gap1.data_ptr(), gap1.data_ptr(), None)
+            L.check(_lib().efts_embed_bwd(text.data_ptr(), Ge.ptr, g["text_embedding_table.weight"].data_ptr(), B, T1, rs1.Tp, C,
+                                          m.num_symbols, O._stream()), "efts_embed_bwd")
+            self._ws_tag = ""
+
         # ---- mel encoder + prenet
         Gm = self._stack_bwd(ws, "me", "mel_encoder", rs2, GQ, me_saved, gap2.data_ptr(), gap2.data_ptr(), None)
         dzp_f = ws.f32("Bpre_dz", rs2, C)
@@ -401,21 +450,7 @@ class TrainEngine:
         if self.bucket_hook:
             self.bucket_hook(1)
 
-        # ---- value / key Linears -> text encoder -> embedding
-        L.check(_lib().efts_act_bwd(GV.ptr, None, None, None, 0.0, 0, ws.f32("Bscratch1", rs1, C).ptr, None, 0, 1,
-                                    g["text_encoder_value.bias"].data_ptr(), rs1.rows, C, O._stream()), "efts_act_bwd")
-        L.check(_lib().efts_act_bwd(GK.ptr, None, None, None, 0.0, 0, ws.f32("Bscratch1", rs1, C).ptr, None, 0, 1,
-                                    g["text_encoder_key.bias"].data_ptr(), rs1.rows, C, O._stream()), "efts_act_bwd")
-        self._wgrad(ws, GV.ptr, C, te_f.ptr, C, C, 1, rs1.rows, None, None, g["text_encoder_value.weight"], None)
-        self._wgrad(ws, GK.ptr, C, te_f.ptr, C, C, 1, rs1.rows, None, None, g["text_encoder_key.weight"], None)
-        Gt0, Gt = ws.f32("Bte_G0", rs1, C), ws.f32("Bte_G1x", rs1, C)
-        wtv, wtk = self.wt["value"], self.wt["key"]
-        O.gemm(a=GV_p, b_ptr=wtv.ptr, ldb=wtv.ld, m=rs1.rows, n=C, rowmask_ptr=gap1.data_ptr(), out_f32_ptr=Gt0.ptr, ldo=C)
-        O.gemm(a=GK_p, b_ptr=wtk.ptr, ldb=wtk.ld, m=rs1.rows, n=C, resid_ptr=Gt0.ptr, ldr=C, rowmask_ptr=gap1.data_ptr(),
-               out_f32_ptr=Gt.ptr, ldo=C)
-        Ge = self._stack_bwd(ws, "te", "text_encoder", rs1, Gt, te_saved, gap1.data_ptr(), gap1.data_ptr(), None)
-        L.check(_lib().efts_embed_bwd(text.data_ptr(), Ge.ptr, g["text_embedding_table.weight"].data_ptr(), B, T1, rs1.Tp, C,
-                                      m.num_symbols, O._stream()), "efts_embed_bwd")
+        main.wait_stream(side)                                      # text-side gradients (bucket 2) and everything else enqueued there
         if self.bucket_hook:
             self.bucket_hook(2)
 
