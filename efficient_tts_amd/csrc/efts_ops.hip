@@ -235,47 +235,68 @@ __global__ void dur_target_kernel(const float* __restrict__ e, const int* __rest
     lde[idx] = v;
 }
 
-// one thread per (b, j) column: softmax over the T1 keys of -sigma (q_j - e_i)^2
-__global__ __launch_bounds__(128) void reconst_alpha_kernel(const float* __restrict__ e, const int* __restrict__ tlen,
+// softmax over the T1 keys of -sigma (q_j - e_i)^2 for 64 columns j per block; the keys are split over the block's 4
+// waves (max and sum combined through LDS), the split-2 plane rows leave through a [64 j][32 i] LDS tile so that every
+// 128-byte K chunk of a row is written by 4 adjacent threads (one thread per column with three T1-long dependent loops
+// and 8-byte stores scattered over 64 rows: 35 us at B=64)
+__global__ __launch_bounds__(256) void reconst_alpha_kernel(const float* __restrict__ e, const int* __restrict__ tlen,
                                                             const int* __restrict__ mlen, float sigma,
                                                             float* __restrict__ alpha, char* __restrict__ plane,
                                                             long ldp, int T1, int T2, int T2p) {
     extern __shared__ float es[];   // e[b, :]
+    __shared__ float red[4][64];
+    __shared__ float tile[64][33];
     const int b = blockIdx.y;
-    for (int i = threadIdx.x; i < T1; i += blockDim.x) es[i] = e[(long)b * T1 + i];
+    for (int i = threadIdx.x; i < T1; i += 256) es[i] = e[(long)b * T1 + i];
     __syncthreads();
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= T2) return;
+    const int jj = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jj;
     const int tl = tlen ? min(tlen[b], T1) : T1;
-    const bool live = mlen ? (j < mlen[b]) : true;
+    const bool live = (j < T2) && (mlen ? (j < mlen[b]) : true);
     const float q = live ? (float)j : 0.f;
     float mx = -INFINITY;
-    for (int i = 0; i < tl; ++i) {
+    for (int i = w; i < tl; i += 4) {
         const float d = q - es[i];
         mx = fmaxf(mx, -sigma * d * d);
     }
+    red[w][jj] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][jj], red[1][jj]), fmaxf(red[2][jj], red[3][jj]));
+    __syncthreads();
     float se = 0.f;
-    for (int i = 0; i < tl; ++i) {
+    for (int i = w; i < tl; i += 4) {
         const float d = q - es[i];
         se += __expf(-sigma * d * d - mx);
     }
+    red[w][jj] = se;
+    __syncthreads();
+    se = red[0][jj] + red[1][jj] + red[2][jj] + red[3][jj];
     const float inv = (live && tl > 0) ? 1.f / se : 0.f;
     const int kp = (T1 + 31) & ~31;
-    char* prow = plane ? plane + ((long)b * T2p + j) * ldp : nullptr;
-    for (int i0 = 0; i0 < kp; i0 += 4) {
-        float v[4];
+    const int prow_l = threadIdx.x >> 2, pq = threadIdx.x & 3;          // plane pass: row (column j) and 8-key piece
+    const int pj = blockIdx.x * 64 + prow_l;
+    for (int i0 = 0; i0 < kp; i0 += 32) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u;
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + w * 8 + u;
             float a = 0.f;
             if (i < tl) {
                 const float d = q - es[i];
                 a = __expf(-sigma * d * d - mx) * inv;
             }
-            v[u] = a;
-            if (alpha && i < T1) alpha[((long)b * T1 + i) * T2 + j] = a;
+            if (alpha && i < T1 && j < T2) alpha[((long)b * T1 + i) * T2 + j] = a;
+            tile[jj][w * 8 + u] = a;
         }
-        if (prow) plane_store4(prow, i0, v[0], v[1], v[2], v[3], 2);
+        if (plane) {
+            __syncthreads();
+            if (pj < T2) {
+                char* prow = plane + ((long)b * T2p + pj) * ldp;
+                const float* t = &tile[prow_l][pq * 8];
+                plane_store4(prow, i0 + pq * 8, t[0], t[1], t[2], t[3], 2);
+                plane_store4(prow, i0 + pq * 8 + 4, t[4], t[5], t[6], t[7], 2);
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -527,7 +548,7 @@ extern "C" int efts_reconst_alpha(const float* e, const int32_t* text_len, const
     if (!e || (!alpha_out && !plane)) return efts_fail(EFTS_EINVAL, "efts_reconst_alpha: null pointer");
     if (T1 <= 0 || T2 <= 0 || T2p < T2 || T1 > 8192) return efts_fail(EFTS_ESHAPE, "efts_reconst_alpha: bad shape");
     if (plane && ld_plane < (int64_t)((T1 + 31) / 32) * 128) return efts_fail(EFTS_ESHAPE, "efts_reconst_alpha: ld_plane too small");
-    hipLaunchKernelGGL(reconst_alpha_kernel, dim3((T2 + 127) / 128, B), dim3(128), T1 * sizeof(float), ST, e, text_len, mel_len, sigma,
+    hipLaunchKernelGGL(reconst_alpha_kernel, dim3((T2 + 63) / 64, B), dim3(256), T1 * sizeof(float), ST, e, text_len, mel_len, sigma,
                        alpha_out, (char*)plane, (long)ld_plane, T1, T2, T2p);
     return efts_check_launch("efts_reconst_alpha");
 }
