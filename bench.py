@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
-    ap.add_argument("--workload", default="fwd64", choices=["fwd64", "fwd16_long", "train32", "infer_lj", "infer64", "logmel64", "vocoder"])
+    ap.add_argument("--workload", default="fwd64", choices=["fwd64", "fwd16_long", "train32", "infer_lj", "infer64", "logmel64", "vocoder", "vocoder8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="1 (default): replay the step from a captured hipGraph -- ~75 launches per forward are host-bound in eager mode (3.0 vs 2.6 ms); the roofline events then come from 3 eager steps right after the timed region. 0: eager, events inside the timed region")
     return ap.parse_args()
@@ -207,19 +207,20 @@ def run_logmel64(a, world, rank, dev):
 
 def run_vocoder(a, world, rank, dev):
     """Row f-4: HiFi-GAN V1 generator (nntts/vocoders/hifigan_model.py, HiFiGAN_LJ_V1 config, random-init weights),
-    one 800-frame mel -> 204 800 samples (9.3 s of audio) per step."""
+    one 800-frame mel -> 204 800 samples (9.3 s of audio) per step; `vocoder8`: a batch of 8 such utterances per step."""
     from efficient_tts_amd.vocoder import HiFiGANGenerator
     import torch.distributed as dist
     cfg = dict(resblock="1", upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=512,
                resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], num_mels=80)
     T2 = 800
+    NB = 8 if a.workload == "vocoder8" else 1
     torch.manual_seed(0)
     model = HiFiGANGenerator(cfg, precision=a.precision).to(dev).eval()
     model.remove_weight_norm()
-    mel = (torch.randn(1, 80, T2, generator=torch.Generator().manual_seed(1234 + rank)) * 1.5 - 4.0).to(dev)
+    mel = (torch.randn(NB, 80, T2, generator=torch.Generator().manual_seed(1234 + rank)) * 1.5 - 4.0).to(dev)
     for _ in range(max(a.warmup, 1)):
         y = model(mel)
-    assert y.shape == (1, 1, T2 * 256) and bool(torch.isfinite(y).all())
+    assert y.shape == (NB, 1, T2 * 256) and bool(torch.isfinite(y).all())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -241,12 +242,12 @@ def run_vocoder(a, world, rank, dev):
         fl += sum(2 * ch * ch * kk * 6 for kk in cfg["resblock_kernel_sizes"]) * length
     fl += 2 * ch * 7 * length
     if rank == 0:
-        res = dict(metric="mel-frames/sec (HiFi-GAN V1 generator, one 800-frame utterance per step)", value=world * T2 / dt,
+        res = dict(metric=f"mel-frames/sec (HiFi-GAN V1 generator, {NB} x 800-frame utterance per step)", value=world * NB * T2 / dt,
                    unit="mel-frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt * 1e3, higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype=a.precision if a.precision == "bf16" else "bf16x3 (split-bf16 MFMA, fp32-class)",
-                   data="synthetic", config={"workload": "HiFi-GAN V1 generator, mel [1, 80, 800] -> 204800 samples", "mel_len": T2,
+                   data="synthetic", config={"workload": f"HiFi-GAN V1 generator, mel [{NB}, 80, 800] -> {NB} x 204800 samples", "mel_len": T2,
                                               "precision": a.precision, "parallelism": f"replicas x{world}"},
-                   rtf=dt / (T2 * 256 / 22050.0), tflops=fl * T2 / dt / 1e12, roofline=None)
+                   rtf=dt / (NB * T2 * 256 / 22050.0), tflops=fl * NB * T2 / dt / 1e12, roofline=None)
         if world == 1 and not a.no_cpu_baseline:
             from oracle import hifigan_oracle as HO                  # cpu_baseline leg: the oracle as the thing timed
             P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
@@ -259,11 +260,11 @@ def run_vocoder(a, world, rank, dev):
                     Pw[k] = v
             torch.set_num_threads(min(os.cpu_count() or 1, 32))
             Tc = 100
-            mc = mel[:, :, :Tc].cpu()
+            mc = mel[:1, :, :Tc].cpu()
             with torch.no_grad():
                 ref = HO.forward(Pw, mc)
                 t1 = time.perf_counter(); HO.forward(Pw, mc); tc = time.perf_counter() - t1
-                got = model(mel[:, :, :Tc].contiguous())
+                got = model(mel[:1, :, :Tc].contiguous())
             res["cpu_baseline"] = dict(value=Tc / tc, unit="mel-frames/s", cores=min(os.cpu_count() or 1, 32), kind="port",
                                        sample=f"oracle generator fp32, one {Tc}-frame mel ({tc:.2f} s)",
                                        hip_vs_oracle_audio_max_abs=float((got.cpu() - ref).abs().max()))
@@ -366,7 +367,7 @@ def main():
         return run_infer64(a, world, rank, dev)
     if a.workload == "logmel64":
         return run_logmel64(a, world, rank, dev)
-    if a.workload == "vocoder":
+    if a.workload in ("vocoder", "vocoder8"):
         return run_vocoder(a, world, rank, dev)
     wl = WORKLOADS[a.workload]
     B, T1, T2 = wl["B"], wl["T1"], wl["T2"]

@@ -121,7 +121,13 @@ def run_tts(args) -> float:
                     ids[n, :len(t)] = t
                 mel, mel_lens, _ = model.inference_batch(ids.to(device), lens.to(device))
                 mels = [mel[n, :int(mel_lens[n])] for n in range(len(chunk))]
-            outs = [vocoder(m.t()[None].contiguous())[0, 0] for m in mels] if vocoder is not None else mels
+            if vocoder is None:
+                outs = mels
+            elif len(chunk) == 1:
+                outs = [vocoder(mels[0].t()[None].contiguous())[0, 0]]
+            else:                                       # one batched generator pass; every item equals its single-utterance result
+                audio = vocoder(mel.transpose(1, 2).contiguous(), mel_lens)
+                outs = [audio[n, 0, :int(mel_lens[n]) * 256] for n in range(len(chunk))]
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - start
         seconds = sum(m.shape[0] for m in mels) * 256 / SAMPLING_RATE

@@ -16,6 +16,11 @@ Every Conv1d / ConvTranspose1d is one `efts_gemm` launch on channel-last rows (o
     space of the next stage (a pointer offset of u/2 rows);
   * the multi-receptive-field mean and the LeakyReLU of the next layer's input: `efts_mean_act_rows`;
   * conv_post + tanh: the kernel's tanh epilogue.
+Batches: the B utterances share one row space per stage, item b at rows b * P .. b * P + T_b * up with a pitch of
+P = (T + 4) * up rows (the 4 spare mel frames become >= 32 zero rows from the first stage on: more than the largest
+halo, (11 - 1) / 2 * 5 = 25).  Every launch carries the per-row validity mask of its stage, so rows past an item's own
+length stay zero exactly as the zero padding of a single-utterance run does; `forward(mel, lengths)` therefore equals
+B separate calls on the unpadded items.
 There is no CPU path.
 """
 from __future__ import annotations
@@ -32,6 +37,7 @@ from .ops import PackedWeight, Plane
 
 LRELU_SLOPE = 0.1
 _GUARD = 64            # zero rows in front of every row space: (taps - 1) / 2 * dilation <= 25
+_GAP_FRAMES = 4        # spare mel frames between the items of a batch: >= 32 zero rows at every upsampled stage
 
 
 def _cfg(h, key, default=None):
@@ -93,6 +99,7 @@ class HiFiGANGenerator(nn.Module):
                 self.resblocks.append(_ResBlock1(ch, k, d))
         self.conv_post = weight_norm(nn.Conv1d(ch, 1, 7, 1, padding=3))
         self._packed: Optional[Dict[str, PackedWeight]] = None
+        self._packed_dev = None
         self._bias: Dict[str, torch.Tensor] = {}
         self._bufs: Dict[int, dict] = {}
 
@@ -118,8 +125,10 @@ class HiFiGANGenerator(nn.Module):
         return m.weight.detach()
 
     def _pack(self, dev) -> Dict[str, PackedWeight]:
-        if self._packed is not None:
+        if self._packed is not None and self._packed_dev == dev:
             return self._packed
+        self._bufs.clear()                      # workspaces of another device are of no use either
+        self._packed_dev = dev
         pk: Dict[str, PackedWeight] = {}
         with O.stream_scope():
             def conv(name, m):
@@ -148,30 +157,37 @@ class HiFiGANGenerator(nn.Module):
         return pk
 
     # ------------------------------------------------------------------ buffers per mel length
-    def _workspace_for(self, T: int, dev) -> dict:
-        if T in self._bufs:
-            return self._bufs[T]
+    def _workspace_for(self, B: int, T: int, dev) -> dict:
+        key = (B, T)
+        if key in self._bufs:
+            return self._bufs[key]
         if len(self._bufs) > 2:
             self._bufs.pop(next(iter(self._bufs)))
         sp = self.split
-        b = {"mel": _Rows(T, self.num_mels, sp, dev, f32=False), "pre": _Rows(T, self.conv_pre.out_channels, sp, dev, f32=False)}
-        t = T
+        pitch = T + _GAP_FRAMES                                                # rows per item at mel rate
+        rows = B * pitch
+        b = {"pitch": pitch, "mel": _Rows(rows, self.num_mels, sp, dev, f32=False),
+             "pre": _Rows(rows, self.conv_pre.out_channels, sp, dev, f32=False), "mask": []}
         for i, (m, u) in enumerate(zip(self.ups, self.upsample_rates)):
             cout = m.out_channels
-            L_i = t * u
-            b[f"up{i}"] = _Rows((t + 1) * u, cout, sp, dev, plane=False)     # the [t + 1][u * cout] GEMM result, seen as rows of cout
-            b[f"x{i}"] = _Rows(L_i, cout, sp, dev, f32=False)                # plane of leaky(x_i)
-            b[f"t{i}"] = _Rows(L_i, cout, sp, dev, f32=False)                # plane of leaky(xt)
-            b[f"r{i}"] = [[_Rows(L_i, cout, sp, dev) for _ in range(2)] for _ in self.res_kernels]   # ping-pong per residual block
-            b[f"s{i}"] = _Rows(L_i, cout, sp, dev, f32=False)                # plane of leaky(mean)
-            t = L_i
-        b["out"] = torch.zeros(t + 256, 1, dtype=torch.float32, device=dev)
-        self._bufs[T] = b
+            n_i = rows * u
+            b[f"up{i}"] = _Rows((rows + 1) * u, cout, sp, dev, plane=False)  # the [rows + 1][u * cout] GEMM result, seen as rows of cout
+            b[f"x{i}"] = _Rows(n_i, cout, sp, dev, f32=False)                # plane of leaky(x_i)
+            b[f"t{i}"] = _Rows(n_i, cout, sp, dev, f32=False)                # plane of leaky(xt)
+            b[f"r{i}"] = [[_Rows(n_i, cout, sp, dev) for _ in range(2)] for _ in self.res_kernels]   # ping-pong per residual block
+            b[f"s{i}"] = _Rows(n_i, cout, sp, dev, f32=False)                # plane of leaky(mean)
+            b["mask"].append(torch.zeros(n_i + 1, dtype=torch.float32, device=dev))
+            rows = n_i
+        b["mask_mel"] = torch.zeros(B * pitch + 1, dtype=torch.float32, device=dev)
+        b["out"] = torch.zeros(rows + 256, 1, dtype=torch.float32, device=dev)
+        self._bufs[key] = b
         return b
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """mel [B, num_mels, T] -> audio [B, 1, T * hop].  `lengths` (frames per item, optional): every item is
+        synthesised exactly as if it had been passed alone without its padding; samples past lengths[b] * hop are 0."""
         if x.dim() != 3 or x.shape[1] != self.num_mels:
             raise ValueError(f"expected mel [B, {self.num_mels}, T]")
         if not x.is_cuda:
@@ -184,39 +200,57 @@ class HiFiGANGenerator(nn.Module):
         hop = 1
         for u in self.upsample_rates:
             hop *= u
-        audio = torch.empty(B, 1, T * hop, dtype=torch.float32, device=dev)
+        if lengths is None:
+            lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+        else:
+            lens = lengths.to(device=dev, dtype=torch.int32).clamp(0, T)
+        audio = torch.zeros(B, 1, T * hop, dtype=torch.float32, device=dev)
+        mel = x.transpose(1, 2).float()
+        if lengths is not None:                 # what the padding frames hold must not reach conv_pre's halo
+            mel = mel * (torch.arange(T, device=dev)[None, :] < lens[:, None])[:, :, None]
         with O.stream_scope():
-            for bi in range(B):
-                self._one(pk, x[bi].t().contiguous().float(), audio[bi, 0], T, dev)
+            self._run(pk, mel.contiguous(), lens, audio, B, T, hop, dev)
         return audio
 
-    def _conv(self, pk, name, a: Plane, rows, taps, dil, *, out_f=None, ldo=0, out_p=None, plane_slope=None, resid=None, ldr=0,
-              act=L.ACT_NONE):
+    def _conv(self, pk, name, a: Plane, rows, taps, dil, *, mask=None, out_f=None, ldo=0, out_p=None, plane_slope=None, resid=None,
+              ldr=0, act=L.ACT_NONE):
         w = pk[name]
         O.gemm(a=a, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=taps, m=rows, n=w.cout, bias=self._bias[name], act=act,
-               resid_ptr=resid, ldr=ldr, out_f32_ptr=out_f, ldo=ldo, out_plane=out_p, dilation=dil,
-               plane_act=plane_slope is not None, plane_slope=0.0 if plane_slope is None else plane_slope)
+               resid_ptr=resid, ldr=ldr, rowmask_ptr=None if mask is None else mask.data_ptr(), out_f32_ptr=out_f, ldo=ldo,
+               out_plane=out_p, dilation=dil, plane_act=plane_slope is not None, plane_slope=0.0 if plane_slope is None else plane_slope)
 
-    def _one(self, pk, mel_tc: torch.Tensor, out: torch.Tensor, T: int, dev) -> None:
-        b = self._workspace_for(T, dev)
+    def _run(self, pk, mel_btc: torch.Tensor, lens: torch.Tensor, audio: torch.Tensor, B: int, T: int, hop: int, dev) -> None:
+        b = self._workspace_for(B, T, dev)
         lib = L.load()
         sp = self.split
+        pitch = b["pitch"]
+        st = O._stream()
+
+        def masks(into: torch.Tensor, lengths_i32: torch.Tensor, t_max: int, t_pitch: int):
+            L.check(lib.efts_row_masks(lengths_i32.data_ptr(), None, into.data_ptr(), B, t_max, t_pitch, st), "efts_row_masks")
+
         mel_p = b["mel"].p
-        L.check(lib.efts_pack_rows(mel_tc.data_ptr(), None, mel_p.ptr, mel_p.ld, 1, T, T, self.num_mels,
-                                   mel_p.nchunk * O.chunk_k(sp), sp, O._stream()), "efts_pack_rows")
+        L.check(lib.efts_pack_rows(mel_btc.data_ptr(), None, mel_p.ptr, mel_p.ld, B, T, pitch, self.num_mels,
+                                   mel_p.nchunk * O.chunk_k(sp), sp, st), "efts_pack_rows")
+        masks(b["mask_mel"], lens, T, pitch)
         # conv_pre (:118); its only consumer applies leaky first (:120) -> the plane of leaky(x), no fp32 copy
-        self._conv(pk, "conv_pre", mel_p, T, 7, 1, out_p=b["pre"].p, plane_slope=LRELU_SLOPE)
-        cur_p, t, n = b["pre"].p, T, 0
+        rows = B * pitch
+        self._conv(pk, "conv_pre", mel_p, rows, 7, 1, mask=b["mask_mel"], out_p=b["pre"].p, plane_slope=LRELU_SLOPE)
+        cur_p, n, up_total = b["pre"].p, 0, 1
         for i, u in enumerate(self.upsample_rates):
             cout = self.ups[i].out_channels
-            L_i = t * u
+            up_total *= u
+            n_i = rows * u
+            mask = b["mask"][i]
+            masks(mask, lens * up_total, T * up_total, pitch * up_total)
             up = b[f"up{i}"]
-            # ConvTranspose1d as a 2-tap convolution over the t + 1 input rows (row t is a zero guard row)
-            self._conv(pk, f"ups.{i}", cur_p, t + 1, 3, 1, out_f=up.fptr, ldo=u * cout)
+            # ConvTranspose1d as a 2-tap convolution over the input rows + 1 (the row after the last one is a zero guard row)
+            self._conv(pk, f"ups.{i}", cur_p, rows + 1, 3, 1, out_f=up.fptr, ldo=u * cout)
             x_f = up.fptr + (u // 2) * cout * 4                               # y[n] = row n + u/2 of the flattened result
             x_p = b[f"x{i}"].p
-            # plane of leaky(x): x * (x > 0 ? 1 : slope), the identity-residual LeakyReLU mode of efts_act_bwd
-            L.check(lib.efts_act_bwd(x_f, x_f, None, None, LRELU_SLOPE, 3, None, x_p.ptr, x_p.ld, sp, None, L_i, cout, O._stream()),
+            # plane of leaky(x): x * (x > 0 ? 1 : slope), the identity-residual LeakyReLU mode of efts_act_bwd; the mask drops
+            # the transposed convolution's cropped border samples, which land in the zero rows between items
+            L.check(lib.efts_act_bwd(x_f, x_f, None, mask.data_ptr(), LRELU_SLOPE, 3, None, x_p.ptr, x_p.ld, sp, None, n_i, cout, st),
                     "efts_act_bwd")
             finals: List[int] = []
             for j, k in enumerate(self.res_kernels):
@@ -224,21 +258,21 @@ class HiFiGANGenerator(nn.Module):
                 r_f, r_p, pp = x_f, x_p, b[f"r{i}"][j]
                 for d_i, d in enumerate(rb.dilation):
                     tp = b[f"t{i}"].p
-                    self._conv(pk, f"rb{n}.c1.{d_i}", r_p, L_i, k, d, out_p=tp, plane_slope=LRELU_SLOPE)            # :47-48 (+ :49)
+                    self._conv(pk, f"rb{n}.c1.{d_i}", r_p, n_i, k, d, mask=mask, out_p=tp, plane_slope=LRELU_SLOPE)  # :47-48 (+ :49)
                     nxt = pp[d_i & 1]
-                    self._conv(pk, f"rb{n}.c2.{d_i}", tp, L_i, k, 1, out_f=nxt.fptr, ldo=cout, out_p=nxt.p,
-                               plane_slope=LRELU_SLOPE, resid=r_f, ldr=cout)                                       # :50-51
+                    self._conv(pk, f"rb{n}.c2.{d_i}", tp, n_i, k, 1, mask=mask, out_f=nxt.fptr, ldo=cout, out_p=nxt.p,
+                               plane_slope=LRELU_SLOPE, resid=r_f, ldr=cout)                                        # :50-51
                     r_f, r_p = nxt.fptr, nxt.p
                 finals.append(r_f)
                 n += 1
             last = i == len(self.upsample_rates) - 1
             s_p = b[f"s{i}"].p
             L.check(lib.efts_mean_act_rows(finals[0], finals[1] if len(finals) > 1 else None, finals[2] if len(finals) > 2 else None,
-                                           cout, 1.0 / len(finals), 0.01 if last else LRELU_SLOPE, None, 0, s_p.ptr, s_p.ld, sp, L_i, cout,
-                                           O._stream()), "efts_mean_act_rows")                                     # :128 (+ :120 / :129)
-            cur_p, t = s_p, L_i
-        self._conv(pk, "conv_post", cur_p, t, 7, 1, out_f=b["out"].data_ptr(), ldo=1, act=L.ACT_TANH)              # :130-131
-        out.copy_(b["out"][:t, 0])
+                                           cout, 1.0 / len(finals), 0.01 if last else LRELU_SLOPE, None, 0, s_p.ptr, s_p.ld, sp, n_i, cout,
+                                           st), "efts_mean_act_rows")                                              # :128 (+ :120 / :129)
+            cur_p, rows = s_p, n_i
+        self._conv(pk, "conv_post", cur_p, rows, 7, 1, mask=b["mask"][-1], out_f=b["out"].data_ptr(), ldo=1, act=L.ACT_TANH)   # :130-131
+        audio[:, 0].copy_(b["out"][:rows, 0].view(B, pitch * hop)[:, :T * hop])
 
 
 def load_hifigan_generator(device, config_path: str, checkpoint_path: str, precision: str = "bf16x3") -> HiFiGANGenerator:

@@ -60,3 +60,25 @@ def test_generator_matches_reference_golden(precision, tol):
     m.remove_weight_norm()
     y3 = m(mel[:1])
     assert (y3 - y2[:1]).abs().max().item() <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_ragged_batch_equals_single_utterances(precision):
+    """`forward(mel, lengths)`: the items of a padded batch share one row space (zero rows between them, a validity mask
+    per stage); each must come out exactly as if it had been synthesised alone without its padding, and be silent past
+    its own length -- whatever the padding frames contain."""
+    from efficient_tts_amd.vocoder import HiFiGANGenerator
+    m = HiFiGANGenerator(CFG, precision=precision)
+    m.load_state_dict(HO.fill_params())
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(7)
+    lens = [37, 12, 50, 1]
+    T = max(lens)
+    mel = torch.randn(len(lens), 80, T, generator=g)              # padding frames are NOT zero: they must not matter
+    y = m(mel.cuda(), torch.tensor(lens))
+    assert y.shape == (len(lens), 1, T * 256)
+    for b, n in enumerate(lens):
+        alone = m(mel[b:b + 1, :, :n].contiguous().cuda())
+        assert torch.equal(y[b, :, :n * 256], alone[0]), (precision, b)
+        assert float(y[b, :, n * 256:].abs().max()) == 0.0 if n < T else True
