@@ -186,18 +186,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
             vow[q] = (unsigned)((r < b_max ? r : b_max) * (int)p.ldb + (sl << 4));
         }
     }
-    const char* a_base = A + (long)(m0 - p.pad * p.dil) * p.lda;     // window row 0 (may start in the guard rows)
-    const char* w_base = Bw + (long)n0 * p.ldb;
+    // debug bits 8 / 16 (timing experiments): every workgroup stages the SAME weight tile / window (always L1-resident)
+    const bool alias_w = DBG && (dbg & 8), alias_a = DBG && (dbg & 16);
+    const char* a_base = A + (long)((alias_a ? 0 : m0) - p.pad * p.dil) * p.lda;     // window row 0 (may start in the guard rows)
+    const char* w_base = Bw + (long)(alias_w ? 0 : n0) * p.ldb;
     const unsigned lds_piece = lds0 + wave * 4096;            // this wave's first piece inside a tile
 
     auto issue_w = [&](int cn, int kn, int slot) {     // weights of step (chunk cn, tap kn) -> ring slot
+        if (alias_w) { cn = 0; kn = 0; }
         const char* sb = w_base + (long)kn * p.b_tap_stride + (long)cn * 128;
         const unsigned l = lds_piece + 2 * TILE_BYTES + slot * TILE_BYTES;
 #pragma unroll
         for (int q = 0; q < 4; ++q) dma16(l + q * 1024, vow[q], sb);
     };
     auto issue_a = [&](int cn) {     // A window of chunk cn -> window buffer cn & 1
-        const char* sb = a_base + (long)cn * 128;
+        const char* sb = a_base + (long)(alias_a ? 0 : cn) * 128;
         const unsigned l = lds_piece + (cn & 1) * TILE_BYTES;
 #pragma unroll
         for (int q = 0; q < 4; ++q) dma16(l + q * 1024, voa[q], sb);
@@ -1227,7 +1230,8 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
         long min_tiles = a->split == 1 ? C5_DEFAULT_MIN_TILES : 0x7fffffffL;
         { const char* e = getenv("EFTS_CONV5"); if (e) min_tiles = atol(e) > 0 ? atol(e) : 0x7fffffffL; }
         const int mt5 = (a->m + C5_BM - 1) / C5_BM;
-        if ((long)mt5 * k.ntiles * a->batch >= min_tiles) {
+        // the last 256-row window may reach mt5 * 252 + 2 - m rows past the matrix: only inside the 144 guard rows of the ABI
+        if ((long)mt5 * k.ntiles * a->batch >= min_tiles && (long)mt5 * C5_BM + 2 - a->m <= 144) {
             GemmKernelArgs k5 = k;
             k5.mtiles = mt5;
             dim3 g5(mt5 * k.ntiles, a->batch, 1);

@@ -1,0 +1,31 @@
+"""k5 conv at B=64, 124-row kernel, debug instantiation: EFTS_GEMM_DBG ablation bits from the command line"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from efficient_tts_amd import lib as L, ops as P
+dev = torch.device("cuda:0"); L.load(); L.require_device()
+B, T, C, split = 64, 800, 512, 1
+rs = P.Rows(B, T)
+a = P.Plane.for_rows(rs, C, split, dev)
+x = torch.randn(B, T, C, device=dev)
+xf = P.F32Rows(rs, C, dev); xf.view().copy_(x)
+P.pack_rows(x, None, a, rs)
+pw = P.PackedWeight(C, C, 5, split, dev); pw.pack((torch.randn(C, C, 5, device=dev) * 0.02).contiguous())
+bias = torch.randn(C, device=dev)
+gap = torch.zeros(rs.rows, device=dev); P.row_masks(torch.full((B,), T, dtype=torch.int32, device=dev), rs, gap, None)
+out = P.F32Rows(rs, C, dev); outp = P.Plane.for_rows(rs, C, split, dev)
+def run():
+    P.gemm(a=a, b_ptr=pw.ptr, ldb=pw.ld, b_tap_stride=pw.tap_stride, taps=5, m=rs.rows, n=C, act=L.ACT_LEAKY, slope=0.1, bias=bias,
+           resid_ptr=xf.ptr, ldr=C, rowmask_ptr=gap.data_ptr(), out_f32_ptr=out.ptr, ldo=C, out_plane=outp)
+def timeit(fn, iters=100):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+with P.stream_scope():
+    for bits in [int(v) for v in sys.argv[1:]]:
+        os.environ["EFTS_GEMM_DBG"] = str(bits)
+        print(f"DBG={bits:2d} (1 no epilogue mem, 2 no DMA, 4 no MFMA, 8 alias W, 16 alias A): {timeit(run):.1f} us", flush=True)
