@@ -325,12 +325,24 @@ def run_infer_lj(a, world, rank, dev):
             voc(model.inference(x)[0].transpose(1, 2).contiguous())
     torch.cuda.synchronize()
     dte = (time.perf_counter() - t0) / a.steps
+
+    def batched_e2e():                                   # the same 10 utterances: one ragged acoustic pass + one ragged vocoder pass
+        mel_b, mel_lens, _ = model.inference_batch(batch, lens)
+        return voc(mel_b.transpose(1, 2).contiguous(), mel_lens)
+    batched_e2e()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        batched_e2e()
+    torch.cuda.synchronize()
+    dteb = (time.perf_counter() - t0) / a.steps
     res = dict(metric="mel-frames/sec (EFTS-CNN free-running inference, 10 LJSpeech test utterances, B=1 each)", value=frames / dt1,
                unit="mel-frames/s", n_gpus=1, steps=a.steps, warmup=a.warmup, ms_per_step=dt1 * 1e3, higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype=a.precision, data="LJSpeech test phoneme ids (reference filelist), random-init weights with the duration head biased to ~6 frames per phoneme",
                config=dict(workload="inference() x 10 utterances, B=1", frames=frames, precision=a.precision),
                rtf=dt1 / audio, batched=dict(value=frames / dtb, ms=dtb * 1e3, rtf=dtb / audio, note="same 10 utterances as one ragged batch (inference_batch)"),
-               end_to_end=dict(ms=dte * 1e3, rtf=dte / audio, note="inference() + HiFi-GAN V1 generator per utterance (random-init vocoder weights): what nntts/bin/inference.py:105-111 calls RTF"))
+               end_to_end=dict(ms=dte * 1e3, rtf=dte / audio, note="inference() + HiFi-GAN V1 generator per utterance (random-init vocoder weights): what nntts/bin/inference.py:105-111 calls RTF"),
+               end_to_end_batched=dict(ms=dteb * 1e3, rtf=dteb / audio, note="the 10 utterances as one ragged batch through inference_batch() and the batched generator"))
     if not a.no_cpu_baseline:
         from oracle import efts_oracle as O           # cpu_baseline leg: the oracle as the thing timed
         torch.set_num_threads(min(os.cpu_count() or 1, 16))
