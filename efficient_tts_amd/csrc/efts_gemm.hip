@@ -1100,6 +1100,201 @@ __global__ __launch_bounds__(256, 2) void conv5_kernel(GemmKernelArgs p) {
   }   // tile loop
 }
 
+
+// =============================================================================================
+// resident32_kernel: convolutions with ONE K chunk (cin <= 64 bf16 / 32 bf16x3) and at most 32 output columns -- the
+// 32-channel stage of the vocoder, 1.6 M rows at a batch of 8.  There the ring kernels are all overhead: 124 rows per
+// workgroup, a window wait, one barrier per tap, an epilogue, for 44 MFMAs per wave.  Here a workgroup keeps a 256-row
+// window AND the weights of every tap in LDS (32 KiB + taps x 4 KiB <= 76 KiB: two workgroups per CU): everything is
+// requested up front, one wait, one barrier, then all taps back to back (wave = 64 rows x 32 columns) and the usual
+// staged epilogue.  Same K order per output element as gemm_kernel / narrow_kernel (bit-compatible).
+// =============================================================================================
+constexpr int R32_WIN = 256;
+
+template <int TAPS, int SPLIT>
+__global__ __launch_bounds__(256, 2) void resident32_kernel(GemmKernelArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem));
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int z = blockIdx.y;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int BM = p.bm;                                       // R32_WIN - (TAPS - 1) * dilation
+    const float* resid = p.resid ? p.resid + (long)z * p.r_bs : nullptr;
+    const float* rowmask = p.rowmask ? p.rowmask + (long)z * p.m_bs : nullptr;
+    float* of = p.out_f32 ? p.out_f32 + (long)z * p.o_bs : nullptr;
+    char* ob = p.out_bf16 ? p.out_bf16 + (long)z * p.ob_bs : nullptr;
+    const char* A = p.a + (long)z * p.a_bs;
+    const char* Bw = p.b + (long)z * p.b_bs;
+    const int mt = blockIdx.x / p.ntiles, nt = blockIdx.x - mt * p.ntiles;    // column tiles of 32 (n fastest: they share the window in L2)
+    const int m0 = mt * BM, n0 = nt * 32;
+    const int w0 = m0 - p.pad * p.dil;                         // first row of the window (may lie in the guard rows)
+    const int row_max = p.m + 143;                             // last row the ABI lets us read (144 zero guard rows)
+
+    // ---- request everything: 8 window pieces per wave, then this wave's piece (8 weight rows) of every tap
+    {
+        const char* a_base = A + (long)w0 * p.lda;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = (wave * 8 + q) * 8 + (lane >> 3);
+            const int sl = (lane & 7) ^ ((r >> 1) & 7);
+            const int rc = w0 + r > row_max ? row_max - w0 : r;   // rows past the guard read the last (zero) guard row
+            dma16(lds0 + (wave * 8 + q) * 1024, (unsigned)(rc * (int)p.lda + (sl << 4)), a_base);
+        }
+        const int r = wave * 8 + (lane >> 3);
+        const int sl = (lane & 7) ^ ((r >> 1) & 7);
+        const int b_max = p.n - 1 - n0;
+        const unsigned vw = (unsigned)((r < b_max ? r : b_max) * (int)p.ldb + (sl << 4));
+        const char* w_base = Bw + (long)n0 * p.ldb;
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) dma16(lds0 + R32_WIN * 128 + (k * 4 + wave) * 1024, vw, w_base + (long)k * p.b_tap_stride);
+    }
+    // epilogue operands of this thread (8 sweeps of 32 rows, 8 threads per 128-byte row): in flight under the DMA wait
+    constexpr int NPS = 8;
+    const int c4 = (tid & 7) << 2;
+    const int col = n0 + c4;
+    const bool vec = p.vec_ok && (col + 3 < p.n);
+    const bool pre = vec;
+    const unsigned trow = tid >> 3;
+    const int rows_in = p.m - m0 < R32_WIN ? p.m - m0 : R32_WIN;
+    const int rows_out = p.m - m0 < BM ? p.m - m0 : BM;
+    u32x4 rres[NPS];
+    float rmv[NPS];
+    if (pre) {
+        const __amdgpu_buffer_rsrc_t rr = make_rsrc(resid ? resid + (long)m0 * p.ldr : nullptr, resid ? (long)rows_in * p.ldr * 4 : 0);
+        const __amdgpu_buffer_rsrc_t rk = make_rsrc(rowmask ? rowmask + m0 : nullptr, rowmask ? (long)rows_in * 4 : 0);
+        const unsigned vr = trow * (unsigned)p.ldr * 4 + col * 4, sr = 32 * (unsigned)p.ldr * 4;
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+            rres[ps] = __builtin_amdgcn_raw_buffer_load_b128(rr, vr, ps * sr, EFTS_AUX_LD);
+            rmv[ps] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rk, trow * 4, ps * 32 * 4, 0));
+        }
+    }
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    {
+        const char* at = smem;
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) {
+            const char* wt = smem + R32_WIN * 128 + k * 4096;
+            const int arow = wave * 64 + lrow + k * p.dil;
+            if constexpr (SPLIT == 1) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int slot = kk * 2 + lhalf;
+                    const bf16x8 b = *(const bf16x8*)(wt + lds_off(lrow, slot));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const bf16x8 a = *(const bf16x8*)(at + lds_off(arow + i * 32, slot));
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int slot = kk * 2 + lhalf;
+                    const bf16x8 bh = *(const bf16x8*)(wt + lds_off(lrow, slot));
+                    const bf16x8 bl = *(const bf16x8*)(wt + lds_off(lrow, slot + 4));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const bf16x8 ah = *(const bf16x8*)(at + lds_off(arow + i * 32, slot));
+                        const bf16x8 al = *(const bf16x8*)(at + lds_off(arow + i * 32, slot + 4));
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    lds_barrier();                                             // every wave is done with the window: it becomes the staging tile
+
+    float* cs = (float*)smem;                                  // [256][32] fp32 = 32 KiB
+    {
+        const float bv = (p.bias && n0 + lrow < p.n) ? p.bias[n0 + lrow] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                float v = acc[i][r] * p.alpha + bv;
+                if (p.act == EFTS_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                else if (p.act == EFTS_ACT_RELU) v = v > 0.f ? v : 0.f;
+                else if (p.act == EFTS_ACT_TANH) v = tanhf(v);
+                cs[rl * 32 + lrow] = v;
+            }
+        }
+    }
+    lds_barrier();
+    if (pre) {
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc(of ? of + (long)m0 * p.ldo : nullptr, of ? (long)rows_out * p.ldo * 4 : 0);
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(ob ? ob + (long)m0 * p.ldob : nullptr, ob ? (long)rows_out * p.ldob : 0);
+        const unsigned vo = trow * (unsigned)p.ldo * 4 + col * 4, so = 32 * (unsigned)p.ldo * 4;
+        const unsigned vb = trow * (unsigned)p.ldob + (unsigned)plane_off_hi(col, p.out_split), sb = 32 * (unsigned)p.ldob;
+        const bool has_mask = rowmask != nullptr;
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+            const int rl = ps * 32 + trow;
+            float4 v = *(const float4*)(cs + rl * 32 + c4);
+            const u32x4 x = rres[ps];
+            const float rm = has_mask ? rmv[ps] : 1.f;
+            v.x = (v.x + __uint_as_float(x.x)) * rm; v.y = (v.y + __uint_as_float(x.y)) * rm;
+            v.z = (v.z + __uint_as_float(x.z)) * rm; v.w = (v.w + __uint_as_float(x.w)) * rm;
+            if (of) {
+                const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo, ps * so, EFTS_AUX_STF);
+            }
+            if (ob) {
+                if (p.plane_act) {
+                    v.x = v.x > 0.f ? v.x : v.x * p.plane_slope; v.y = v.y > 0.f ? v.y : v.y * p.plane_slope;
+                    v.z = v.z > 0.f ? v.z : v.z * p.plane_slope; v.w = v.w > 0.f ? v.w : v.w * p.plane_slope;
+                }
+                float r0, r1, r2, r3;
+                const u32x2 hi = {pack_bf16x2(v.x, v.y, &r0, &r1), pack_bf16x2(v.z, v.w, &r2, &r3)};
+                __builtin_amdgcn_raw_buffer_store_b64(hi, rb, vb, ps * sb, EFTS_AUX_STP);
+                if (p.out_split == 2) {
+                    float d0, d1;
+                    const u32x2 lo = {pack_bf16x2(r0, r1, &d0, &d1), pack_bf16x2(r2, r3, &d0, &d1)};
+                    __builtin_amdgcn_raw_buffer_store_b64(lo, rb, vb + 64, ps * sb, EFTS_AUX_STP);
+                }
+            }
+        }
+    } else if (col < p.n) {
+        for (int ps = 0; ps < NPS; ++ps) {
+            const int rl = ps * 32 + trow;
+            const int row = m0 + rl;
+            if (rl >= BM || row >= p.m) break;
+            const float4 v = *(const float4*)(cs + rl * 32 + c4);
+            const float rm = rowmask ? rowmask[row] : 1.f;
+            float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (col + u >= p.n) break;
+                float t = vv[u];
+                if (resid) t += resid[(long)row * p.ldr + col + u];
+                t *= rm;
+                if (of) of[(long)row * p.ldo + col + u] = t;
+                if (ob) {
+                    if (p.plane_act) t = t > 0.f ? t : t * p.plane_slope;
+                    const unsigned short hi = f32_to_bf16(t);
+                    char* d = ob + (long)row * p.ldob + plane_off_hi(col + u, p.out_split);
+                    *(unsigned short*)d = hi;
+                    if (p.out_split == 2) *(unsigned short*)(d + 64) = f32_to_bf16(t - bf16_to_f32(hi));
+                }
+            }
+        }
+    }
+}
+
 }  // namespace efts
 
 using namespace efts;
@@ -1124,6 +1319,26 @@ static void launch_narrow(dim3 grid, hipStream_t st, const GemmKernelArgs& k) {
     }
     hipLaunchKernelGGL((narrow_kernel<T, S, B>), grid, dim3(256), GEMM_LDS, st, k);
 }
+template <int T, int S>
+static void launch_resident32(dim3 grid, hipStream_t st, const GemmKernelArgs& k) {
+    static bool attr = false;
+    constexpr int lds = R32_WIN * 128 + T * 4096;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)resident32_kernel<T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((resident32_kernel<T, S>), grid, dim3(256), lds, st, k);
+}
+template <int S>
+static bool launch_resident32_taps(int taps, dim3 grid, hipStream_t st, const GemmKernelArgs& k) {
+    switch (taps) {
+        case 3: launch_resident32<3, S>(grid, st, k); return true;
+        case 7: launch_resident32<7, S>(grid, st, k); return true;
+        case 11: launch_resident32<11, S>(grid, st, k); return true;
+        default: return false;
+    }
+}
+
 template <int S, int B>
 static bool launch_narrow_taps(int taps, dim3 grid, hipStream_t st, const GemmKernelArgs& k) {
     switch (taps) {
@@ -1208,6 +1423,18 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     // the acoustic model: 64 x 130 rows = 272 workgroups; the 256-channel stage of the vocoder at one utterance:
     // 110): such a launch is bound by the per-workgroup step latency, and 64-column tiles double the number of
     // workgroups that overlap.  EFTS_NARROW_FEW = the threshold in workgroups per CU (default 1, 0 disables; 2 measured slower for the 272-workgroup text side).
+    // one K chunk and at most 64 columns over many rows (the 32- and 64-channel stages of the vocoder): window + all taps
+    // resident, 32-column tiles (64 columns = two workgroups per window: 2.11 -> 2.03 ms per utterance, 11.1 -> 10.5 ms per 8)
+    static const int resident_nmax = [] { const char* e = getenv("EFTS_RESIDENT_NMAX"); return e ? atoi(e) : 64; }();
+    if (a->n <= resident_nmax && a->nchunk == 1 && nb2 == 1 && (a->taps - 1) * dil <= 64 && a->m >= 8 * R32_WIN && !getenv("EFTS_NO_RESIDENT")) {
+        GemmKernelArgs kr = k;
+        kr.bm = R32_WIN - (a->taps - 1) * dil;
+        kr.mtiles = (a->m + kr.bm - 1) / kr.bm;
+        kr.ntiles = (a->n + 31) / 32;
+        dim3 gr(kr.mtiles * kr.ntiles, a->batch, 1);
+        const bool done = a->split == 1 ? launch_resident32_taps<1>(a->taps, gr, st, kr) : launch_resident32_taps<2>(a->taps, gr, st, kr);
+        if (done) return efts_check_launch("efts_gemm");
+    }
     int few_per_cu = 1;
     { const char* e = getenv("EFTS_NARROW_FEW"); if (e) few_per_cu = atoi(e); }
     const bool few = (long)k.mtiles * k.ntiles * a->batch < (long)few_per_cu * efts_num_cus() && a->n > 64;
