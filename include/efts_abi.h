@@ -103,7 +103,9 @@ typedef struct efts_gemm_args {
     int32_t batch2;    /* optional outer batch (grid.z), 0/1 = none; e.g. the taps of a wgrad */
     int64_t a_batch2_stride, b_batch2_stride, out_batch2_stride; /* bytes, bytes, elements */
     /* dilated convolutions (HiFi-GAN residual blocks, nntts/vocoders/hifigan_model.py:30-58): rows between taps,
-     * 0 / 1 = dense; (taps - 1) * dilation <= 64; taps may also be 7 or 11. */
+     * 0 / 1 = dense; (taps - 1) * dilation <= 64; taps may also be 7 or 11.  The A plane is read from
+     * (taps - 1) / 2 * dilation rows before row 0 to 144 rows after row m - 1: the caller's buffer must hold zero rows
+     * there (EFTS_GUARD_LO = 8 covers the dense taps of the acoustic model; the vocoder's row spaces carry 64). */
     int32_t dilation;
     /* 1: out_bf16 receives LeakyReLU(out, plane_slope) instead of out -- for consumers that apply the
      * activation to their INPUT (pre-activation residual blocks); out_f32 stays un-activated. */

@@ -78,7 +78,58 @@ def test_gemm_conv_vs_fp64(split, taps, cin, cout, B, T):
     assert float((recon - got).abs().max()) <= 2e-5 * scale
 
 
-# ------------------------------------------------------------------ whole forward vs golden + oracle
+@pytest.mark.parametrize("split", [2, 1])
+@pytest.mark.parametrize("taps,dil,c,T", [(3, 1, 32, 2600), (7, 3, 32, 2500), (11, 5, 32, 3000), (11, 1, 64, 2200), (7, 5, 24, 2100)])
+def test_resident_kernel_vs_fp64_and_ring_kernels(split, taps, dil, c, T, monkeypatch):
+    """One-K-chunk convolutions with <= 64 columns over many rows (the vocoder's narrow stages) take resident32_kernel
+    (window + every tap's weights resident in LDS).  Dilated taps, residual, row mask (a ragged second item), activated
+    output plane: against float64 and, bit for bit, against the ring kernels (EFTS_NO_RESIDENT, read per launch).
+    Row space of the vocoder (64 zero guard rows in front: the halo of a dilated k = 11 tap is 25 rows)."""
+    from efficient_tts_amd import lib as L, ops as P
+    from efficient_tts_amd.vocoder import _GUARD, _Rows
+    dev = _dev()
+    g = torch.Generator().manual_seed(taps * 100 + dil * 10 + c)
+    B, lens, gap = 2, [T, T - 777], 40
+    Tp = T + gap
+    rows = B * Tp
+    x = torch.randn(B, T, c, generator=g)
+    x[1, lens[1]:] = 0.0                                           # what a masked producer would have left there
+    w = torch.randn(c, c, taps, generator=g) * 0.2
+    bias = torch.randn(c, generator=g).to(dev)
+    res = torch.randn(B, Tp, c, generator=g)
+    lib = L.load()
+    a = _Rows(rows, c, split, dev, f32=False)
+    L.check(lib.efts_pack_rows(x.to(dev).contiguous().data_ptr(), None, a.p.ptr, a.p.ld, B, T, Tp, c, a.p.nchunk * P.chunk_k(split), split, None),
+            "efts_pack_rows")
+    pw = P.PackedWeight(c, c, taps, split, dev)
+    pw.pack(w.to(dev).contiguous())
+    resid = _Rows(rows, c, split, dev, plane=False)
+    resid.f[_GUARD:_GUARD + rows].copy_(res.reshape(rows, c).to(dev))
+    lenmask = torch.zeros(rows, device=dev)
+    L.check(lib.efts_row_masks(torch.tensor(lens, dtype=torch.int32, device=dev).data_ptr(), None, lenmask.data_ptr(), B, T, Tp, None), "efts_row_masks")
+    outs = {}
+    for flag in ("1", None):
+        if flag is None:
+            monkeypatch.delenv("EFTS_NO_RESIDENT", raising=False)
+        else:
+            monkeypatch.setenv("EFTS_NO_RESIDENT", flag)
+        out = _Rows(rows, c, split, dev)
+        P.gemm(a=a.p, b_ptr=pw.ptr, ldb=pw.ld, b_tap_stride=pw.tap_stride, taps=taps, m=rows, n=c, bias=bias, resid_ptr=resid.fptr, ldr=c,
+               rowmask_ptr=lenmask.data_ptr(), out_f32_ptr=out.fptr, ldo=c, out_plane=out.p, dilation=dil, plane_act=True, plane_slope=0.1)
+        torch.cuda.synchronize()
+        outs[flag] = (out.f.clone(), out.p.buf.clone())
+    assert torch.equal(outs[None][0], outs["1"][0]) and torch.equal(outs[None][1], outs["1"][1])
+    ref = torch.nn.functional.conv1d(x.double().transpose(1, 2), w.double(), bias.cpu().double(), padding=(taps - 1) // 2 * dil, dilation=dil)
+    ref = (res[:, :T].double() + ref.transpose(1, 2)).float()
+    ref[1, lens[1]:] = 0.0
+    full = outs[None][0].cpu()
+    got = full[_GUARD:_GUARD + rows].view(B, Tp, c)
+    scale = float(ref.abs().max())
+    assert float((got[:, :T] - ref).abs().max()) <= (2e-5 if split == 2 else 2e-2) * scale
+    assert float(got[:, T:].abs().max()) == 0.0                    # rows between the items: masked
+    assert float(full[:_GUARD].abs().max()) == 0.0 and float(full[_GUARD + rows:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("case", ["fwd_tiny", "fwd_small", "fwd_full", "fwd_long"])
 def test_forward_matches_reference_golden(golden_dir, model, case):
     g = _golden(golden_dir, case)
