@@ -64,6 +64,7 @@ class DistributedEFTS(torch.nn.Module):
             # identical initial parameters on every rank (DDP broadcasts rank 0's)
             for p in module.parameters():
                 dist.broadcast(p.data, src=0, group=group)
+            module._packed_sig = None           # in-place through .data: no version bump, so drop any packed operand planes
 
     @property
     def grad_scale(self) -> float:
