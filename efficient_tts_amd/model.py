@@ -422,7 +422,8 @@ class EfficientTTSCNN(torch.nn.Module):
         O.gemm(a=q_p, b_ptr=key_p.ptr, ldb=key_p.ld, m=T2, n=T1, batch=B, a_batch_stride=rs2.Tp * q_p.ld,
                b_batch_stride=rs1.Tp * key_p.ld, alpha=O.INV_SQRT(C), out_f32_ptr=scores.data_ptr(), ldo=T1,
                out_batch_stride=T2 * T1)
-        sidx, imv = ws.tensor("sidx", (B, T2)), ws.tensor("imv", (B, T2))
+        sidx = ws.tensor("sidx", (B, T2))
+        imv = torch.empty(B, T2, dtype=torch.float32, device=dev)              # returned to the caller: written in place, no copy
         alpha = ws.tensor("alpha", (B, T1, T2)) if keep else None
         O.attn_soft_index(scores, T1, tl, ml, sidx, alpha, B, T1, T2)             # :391-398, :168, :312
         O.imv_scan(sidx, tl, ml, imv, B, T2)                                      # :314-323
@@ -439,7 +440,7 @@ class EfficientTTSCNN(torch.nn.Module):
         O.masked_losses(mel.ptr, self.odim, speech, ml, dur, lde, tl, out3, ws.tensor("loss_ws", (1024,)), B, T1,
                         rs1.Tp, T2, rs2.Tp, self.odim)
         mel_pred = mel.view().clone()
-        ret = (out3[0], LazyStats(out3), imv.clone(), ralpha, mel_pred, speech)
+        ret = (out3[0], LazyStats(out3), imv, ralpha, mel_pred, speech)
         extra = dict(e=e, log_delta_e=lde, dur_pred=dur.view(B, rs1.Tp)[:, :T1], ws=ws) if keep else None
         return ret, extra
 
