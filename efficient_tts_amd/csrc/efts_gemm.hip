@@ -1495,17 +1495,6 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(GemmKernelArgs p) {
     }
 }
 
-
-// =============================================================================================
-// conv9_kernel (EFTS_CONV9=1): persistent version of the 8-wave loop with the epilogue of tile i running INSIDE the main
-// loop of tile i + 1.  One 512-thread workgroup per CU walks the tile list; tile = 256-row window (252 rows) x 128 columns,
-// 4 x 2 waves of 64 x 64, TWO accumulator sets (128 VGPRs): while set P accumulates tile i + 1, set 1 - P (tile i) is
-// dumped to a 64 KiB LDS staging tile one 128-row half at a time and swept out (residual + mask + fp32 + plane), one
-// 8-row sweep per K step.  Roles keep the counted vmcnt clean: waves 0-3 issue every LDS-DMA piece and no other global
-// access; waves 4-7 issue no DMA and do all the epilogue loads / stores; all 8 waves issue MFMAs.
-// LDS: 32 KiB window + 3 x 16 KiB weight ring + 64 KiB staging = 144 KiB.  bf16 planes, k5, n % 128 == 0, float4-able rows.
-// =============================================================================================
-
 }  // namespace efts
 
 using namespace efts;
