@@ -142,3 +142,39 @@ def test_inference_cli_writes_wavs(tmp_path):
         mel = np.load(tmp_path / "mel" / f"utt{n}_7steps.npy")
         assert sr == 22050 and a.dtype == np.int16 and a.shape == (mel.shape[0] * 256,) and mel.shape[1] == 80
         assert a.shape == b.shape and np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 2
+
+
+def test_inference_cli_parser_and_list_reader(tmp_path):
+    """Host side of the synthesis script (nntts/bin/inference.py:128-176, :88-101): arguments and the `wav|phonemes` list."""
+    from efficient_tts_amd.bin import inference as I
+    a = I.get_parser().parse_args(["--checkpoint", "exp/checkpoint-7steps.pkl", "--test_fid_scp", "t.txt", "--outdir", "o",
+                                   "--batch_size", "4", "--no_vocoder"])
+    assert a.checkpoint.endswith("7steps.pkl") and a.batch_size == 4 and a.no_vocoder and a.precision == "bf16x3" and a.config is None
+    lst = tmp_path / "t.txt"
+    lst.write_text("wavs/LJ001-0001.wav|HH AH0 L OW1\n\nwavs/LJ001-0002.wav|W ER1 L D|extra field\n")
+    phn2idx = {p: i for i, p in enumerate(["AH0", "D", "ER1", "HH", "L", "OW1", "W"])}
+    items = I._read_list(str(lst), phn2idx)
+    assert [u for u, _ in items] == ["LJ001-0001", "LJ001-0002"]
+    assert items[0][1].tolist() == [3, 0, 4, 5] and items[1][1].tolist() == [6, 2, 4, 1] and items[0][1].dtype == torch.long
+    with pytest.raises(KeyError):
+        I._read_list(str(lst), {"HH": 0})
+
+
+def test_trainer_intervals_and_meters():
+    """Host bookkeeping of the trainer (efficient_tts_trainer.py:147-149, :236-262): interval tests and running means."""
+    from efficient_tts_amd.trainer import EfficientTTSTrainer, _Meter
+    cfg = dict(outdir="/tmp", log_interval_steps=5, eval_interval_steps=0, save_interval_steps=10, train_max_steps=20, grad_norm=1.0)
+    t = EfficientTTSTrainer(steps=0, epochs=0, data_loader={}, sampler={}, model=torch.nn.Linear(2, 2), optimizer=None, scheduler=None, config=cfg)
+    hits = {k: [] for k in ("log_interval_steps", "eval_interval_steps", "save_interval_steps")}
+    for step in range(1, 21):
+        t.steps = step
+        for k in hits:
+            if t._due(k):
+                hits[k].append(step)
+    assert hits == {"log_interval_steps": [5, 10, 15, 20], "eval_interval_steps": [], "save_interval_steps": [10, 20]}
+    m = _Meter("train")
+    for v in (1.0, 3.0):
+        m.add({"loss": v, "mel_loss": v / 2, "duration_loss": v / 4})
+    assert m.means(2) == {"train/loss": 2.0, "train/mel_loss": 1.0, "train/dur_loss": 0.5}
+    m.reset()
+    assert m.means(0) == {"train/loss": 0.0, "train/mel_loss": 0.0, "train/dur_loss": 0.0}
