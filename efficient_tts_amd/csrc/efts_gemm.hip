@@ -46,25 +46,9 @@
 #define EFTS_AUX_STP 0
 #endif
 
+#include "efts_mma.h"
+
 namespace efts {
-
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-
-constexpr int BN = 128;                   // output columns per tile
-constexpr int WIN = 128;                  // window rows = MFMA rows per tile
-constexpr int TILE_BYTES = 128 * 128;     // one operand tile: 128 rows x 128 B
-constexpr int NST = 3;                    // weight ring stages
-constexpr int GEMM_LDS = 2 * TILE_BYTES + NST * TILE_BYTES;   // 81920 = 160 KiB / 2
-
-// Swizzled LDS byte offset of (row, 16-byte slot) inside a [rows][128 B] tile.  A ds_read_b128
-// lane group holds 16 different rows at one logical slot; rows r and r+2 share banks, so the
-// physical slot is XORed with (r >> 1) & 7 (conflict-free for every tap shift).
-__device__ __forceinline__ int lds_off(int row, int slot) {
-    return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
-}
 
 struct GemmKernelArgs {
     const char* a;
@@ -89,40 +73,6 @@ struct GemmKernelArgs {
     unsigned long long* prof;   // DBG instantiation: per-phase cycle sums
     int dbg;      // DBG instantiation (EFTS_GEMM_DBG): 1 = no epilogue memory traffic, 2 = no DMA, 4 = no MFMA
 };
-
-// One LDS-DMA piece = one wave instruction = 8 tile rows x 128 B.  Lane l lands at LDS
-// m0 + 16*l, i.e. tile row 8*piece + l/8, physical slot l%8; its source is sbase + voff.
-__device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, const char* sbase) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase)
-                 : "memory");
-}
-
-__device__ __forceinline__ void wait_vmcnt(int n) {   // n = LDS-DMA pieces allowed to stay in flight (multiple of 4)
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    }
-}
-
-// barrier that orders LDS traffic only: global loads / stores in flight stay in flight
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
-
-// raw buffer descriptor over `bytes` bytes at p: loads past the end return 0, stores past it are dropped
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long bytes) {
-    const unsigned n = bytes <= 0 ? 0u : (bytes > 0xffffffffL ? 0xffffffffu : (unsigned)bytes);
-    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, n, 0x00020000);
-}
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b, float* ra, float* rb) {
-    const unsigned short ha = f32_to_bf16(a), hb = f32_to_bf16(b);
-    *ra = a - bf16_to_f32(ha);
-    *rb = b - bf16_to_f32(hb);
-    return (unsigned)ha | ((unsigned)hb << 16);
-}
 
 template <int TAPS, int SPLIT, int DBG>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {

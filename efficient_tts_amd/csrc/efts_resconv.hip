@@ -1,0 +1,525 @@
+// efts_resconv.hip -- the residual k5 convolution layer of the EFTS-CNN stacks at mel length on gfx950 (CDNA4):
+//
+//   y[row, :] = ( x[row, :] + LeakyReLU( sum_{tap<5} x[row + tap - 2, :] . W[tap] + bias ) ) * rowmask[row]
+//
+// i.e. one `ResConv1d` layer of the reference (nntts/layers/efts_modules.py:48-51 forward, :32-35 the Conv1d,
+// :77-79 the stack loop) over the padded row space of include/efts_abi.h.
+//
+// Why a kernel of its own: at 64 x 800 frames this layer is 134 GFLOP and ~80 % of the forward.
+// The general contraction (efts_gemm.hip) runs two independent 4-wave workgroups per CU which collide on the matrix
+// pipe and pay their HBM-bound epilogues in lock-step.  Here:
+//   * ONE persistent 8-wave workgroup per CU, one barrier domain: 2 x 4 waves of (32*NI) x 64 outputs each on a
+//     (64*NI) x 256 tile, NI = 1..4 picked per tile.  A 256-column weight tile (32 KiB) feeds 8 waves, so the LDS-DMA
+//     line requests per MFMA are half those of a 128-column tile.
+//   * LDS = two 256-row windows (double-buffered: the next K chunk's window lands while the current one is read at its
+//     5 tap shifts) + a 3-stage ring of 32 KiB weight tiles = exactly 160 KiB.  All operands arrive by LDS-DMA issued
+//     from inline asm with counted s_waitcnt vmcnt(N); one s_barrier per (chunk, tap) step.
+//   * the residual stream travels as bf16 hi/lo planes (x = hi + lo, 16 mantissa bits) instead of an fp32 copy
+//     beside the bf16 operand plane: the epilogue reads 4 B and writes 4 B per element instead of 4 + 6..8 B.
+//   * the epilogue is wave-private (no barriers): each wave drops one 32 x 32 accumulator block at a time into its own
+//     4 KiB of LDS and sweeps it out as 16-byte row segments; the next tile's first operands are already in flight.
+//   * a STATIC tile schedule (host side, `rc_schedule`): every CU gets its share of rows as a short list of tiles of
+//     different heights, with two classes of workgroups whose epilogues (HBM bursts) fall at different times, and no
+//     partial last round.
+// Results are bit-identical to efts_gemm on the same operands (same per-element summation order: chunk, tap, k-slice).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "efts_mma.h"
+
+namespace efts {
+
+constexpr int RC_BN = 256;                                   // output columns per tile
+constexpr int RC_WIN_BYTES = 256 * 128;                      // one window buffer (256 rows x 128 B)
+constexpr int RC_W_BYTES = RC_BN * 128;                      // one weight tile
+constexpr int RC_RING = 2 * RC_WIN_BYTES;                    // LDS offset of the weight ring
+constexpr int RC_LDS = 2 * RC_WIN_BYTES + 3 * RC_W_BYTES;    // 163840 = all of a CU's LDS
+constexpr int RC_MAXCLS = 4, RC_MAXTILES = 8;
+
+struct RcSched {
+    int ncls;                                // workgroup group g belongs to class g % ncls
+    int rows[RC_MAXCLS];                     // output rows a group of this class owns
+    int ntile[RC_MAXCLS];
+    unsigned char ni[RC_MAXCLS][RC_MAXTILES];   // tile heights in units of 64 window rows (a tile yields 64 * ni - 4 rows)
+};
+
+struct RcArgs {
+    const char* a;          // operand plane of x (split 1: bf16 hi; split 2: [32 hi | 32 lo] chunks), row 0
+    const char* a_lo;       // split 1: lo plane of x (same layout) or null
+    const float* resid;     // fp32 x (takes precedence over the planes as the residual) or null
+    const char* w;
+    const float* bias;
+    const float* rowmask;
+    float* out_f32;
+    char* ob;
+    char* ob_lo;
+    long lda, ldw, w_tap_stride, ldr, ldo, ldob;
+    int m, nchunk, ntn;
+    float slope;
+    int out_split;
+    RcSched s;
+};
+
+__device__ __forceinline__ void rc_wait(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
+}
+
+struct RcCtx {
+    char* smem;
+    unsigned lds0;
+    int lane, wave, wm, wn, lrow, lhalf;
+    int n0;
+    unsigned vow[4];        // per-lane source offsets of this wave's 4 weight pieces (fixed per workgroup)
+    const char* w_base;
+    float bv[2];            // bias of this lane's two accumulator columns
+    int ws;                 // ring slot of the next step
+    int wpar;               // window buffer of the next tile's chunk 0
+};
+
+// window pieces of one tile: piece P = q * 8 + wave covers window rows 8P .. 8P+7 (lane l: row 8P + l/8, physical slot l%8);
+// rows past the guard band after the matrix are clamped (their outputs are never stored)
+template <int NI>
+__device__ __forceinline__ void rc_window_offsets(const RcArgs& p, const RcCtx& c, int m0, unsigned (&voa)[NI]) {
+    const int rmax = p.m + 143 - (m0 - 2);
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+        const int r = (q * 8 + c.wave) * 8 + (c.lane >> 3);
+        const int sl = (c.lane & 7) ^ ((r >> 1) & 7);
+        voa[q] = (unsigned)((r < rmax ? r : rmax) * (int)p.lda + (sl << 4));
+    }
+}
+
+// One (64 * NI) x 256 tile at output row m0: main loop over (chunk, tap) steps, then the fused epilogue.  On entry the
+// window of chunk 0 and the weights of steps 0 and 1 are in flight (or landed); before its epilogue the tile issues
+// the same for the next tile (rows m1, height ni1; ni1 == 0: none).
+template <int SPLIT, int NI>
+__device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int rows_out, int m1, int ni1) {
+    constexpr int TAPS = 5;
+    const int nsteps = p.nchunk * TAPS;
+    char* const smem = c.smem;
+    const int lane = c.lane, wave = c.wave, lrow = c.lrow, lhalf = c.lhalf, wm = c.wm, wn = c.wn;
+
+    unsigned voa[NI];
+    rc_window_offsets<NI>(p, c, m0, voa);
+    const char* a_base = p.a + (long)(m0 - 2) * p.lda;
+    auto issue_w = [&](int cn, int kn, int slot) {
+        const char* sb = c.w_base + (long)kn * p.w_tap_stride + (long)cn * 128;
+        const unsigned l = c.lds0 + RC_RING + slot * RC_W_BYTES + wave * 1024;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma16(l + q * 8192, c.vow[q], sb);
+    };
+    auto issue_a = [&](int cn, int buf) {
+        const char* sb = a_base + (long)cn * 128;
+        const unsigned l = c.lds0 + buf * RC_WIN_BYTES + wave * 1024;
+#pragma unroll
+        for (int q = 0; q < NI; ++q) dma16(l + q * 8192, voa[q], sb);
+    };
+
+    f32x16 acc[NI][2];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int wbuf, int slot, int k) {
+        const char* at = smem + wbuf * RC_WIN_BYTES;
+        const char* wt = smem + RC_RING + slot * RC_W_BYTES;
+        const int arow = wm * (32 * NI) + lrow + k;
+        const int brow = wn * 64 + lrow;
+        if constexpr (SPLIT == 1) {
+            bf16x8 af[2][NI], bfr[2][2];
+            auto ld = [&](int kk, int b) {
+                const int slot16 = kk * 2 + lhalf;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bfr[b][j] = *(const bf16x8*)(wt + lds_off(brow + j * 32, slot16));
+#pragma unroll
+                for (int i = 0; i < NI; ++i) af[b][i] = *(const bf16x8*)(at + lds_off(arow + i * 32, slot16));
+            };
+            ld(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (kk + 1 < 4) ld(kk + 1, (kk + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int slot16 = kk * 2 + lhalf;
+                bf16x8 bh[2], bl[2], ah[2], al[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bh[j] = *(const bf16x8*)(wt + lds_off(brow + j * 32, slot16));
+                    bl[j] = *(const bf16x8*)(wt + lds_off(brow + j * 32, slot16 + 4));
+                }
+                ah[0] = *(const bf16x8*)(at + lds_off(arow, slot16));
+                al[0] = *(const bf16x8*)(at + lds_off(arow, slot16 + 4));
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    if (i + 1 < NI) {
+                        ah[(i + 1) & 1] = *(const bf16x8*)(at + lds_off(arow + (i + 1) * 32, slot16));
+                        al[(i + 1) & 1] = *(const bf16x8*)(at + lds_off(arow + (i + 1) * 32, slot16 + 4));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i & 1], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bh[j], acc[i][j], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    };
+
+    // ---- the tile's first operands were requested earlier (kernel start / previous epilogue); nothing else is outstanding
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int ch = 0, k = 0, ws = c.ws, c2 = 0, k2 = 2;
+    for (int s = 0; s < nsteps; ++s) {
+        const bool do_w = s + 2 < nsteps;
+        const bool do_a = (k == 0) && (ch + 1 < p.nchunk);
+        if (do_w) issue_w(c2, k2, ws == 0 ? 2 : ws - 1);                 // weights two steps ahead, slot (ws + 2) % 3
+        if (do_a) issue_a(ch + 1, (c.wpar + ch + 1) & 1);                // next chunk's window into the idle buffer
+        compute((c.wpar + ch) & 1, ws, k);
+        // step end: the weights of step s+1 (issued one step ago) and anything older must have landed; LDS-DMA completes
+        // in issue order, so it is enough to bound what may still be in flight: this step's own requests
+        rc_wait((do_w ? 4 : 0) + (do_a ? NI : 0));
+        lds_barrier();
+        if (++k == TAPS) { k = 0; ++ch; }
+        if (++k2 == TAPS) { k2 = 0; ++c2; }
+        ws = (ws == 2) ? 0 : ws + 1;
+    }
+    c.ws = ws;
+    c.wpar = (c.wpar + p.nchunk) & 1;
+
+    // ---- next tile's window 0 and weights of steps 0 / 1: every buffer they touch was last read before the final barrier
+    if (ni1 > 0) {
+        const int rmax = p.m + 143 - (m1 - 2);
+        const char* sb = p.a + (long)(m1 - 2) * p.lda;
+        const unsigned l = c.lds0 + c.wpar * RC_WIN_BYTES + wave * 1024;
+        for (int q = 0; q < ni1; ++q) {
+            const int r = (q * 8 + wave) * 8 + (lane >> 3);
+            const int sl = (lane & 7) ^ ((r >> 1) & 7);
+            dma16(l + q * 8192, (unsigned)((r < rmax ? r : rmax) * (int)p.lda + (sl << 4)), sb);
+        }
+        issue_w(0, 0, ws);
+        issue_w(0, 1, ws == 2 ? 0 : ws + 1);
+    }
+
+    // ---- epilogue, wave-private: staging = this wave's 4 KiB of the ring slot the last step read
+    char* st = smem + RC_RING + (ws == 0 ? 2 : ws - 1) * RC_W_BYTES + wave * 4096;
+    const __amdgpu_buffer_rsrc_t r_a = make_rsrc(p.a + (long)m0 * p.lda, (long)rows_out * p.lda);
+    const __amdgpu_buffer_rsrc_t r_al = make_rsrc(p.a_lo ? p.a_lo + (long)m0 * p.lda : nullptr, p.a_lo ? (long)rows_out * p.lda : 0);
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(p.resid ? p.resid + (long)m0 * p.ldr : nullptr, p.resid ? (long)rows_out * p.ldr * 4 : 0);
+    const __amdgpu_buffer_rsrc_t r_m = make_rsrc(p.rowmask ? p.rowmask + m0 : nullptr, p.rowmask ? (long)rows_out * 4 : 0);
+    const __amdgpu_buffer_rsrc_t r_of = make_rsrc(p.out_f32 ? p.out_f32 + (long)m0 * p.ldo : nullptr, p.out_f32 ? (long)rows_out * p.ldo * 4 : 0);
+    const __amdgpu_buffer_rsrc_t r_ob = make_rsrc(p.ob ? p.ob + (long)m0 * p.ldob : nullptr, p.ob ? (long)rows_out * p.ldob : 0);
+    const __amdgpu_buffer_rsrc_t r_ol = make_rsrc(p.ob_lo ? p.ob_lo + (long)m0 * p.ldob : nullptr, p.ob_lo ? (long)rows_out * p.ldob : 0);
+    const bool res_f32 = p.resid != nullptr;
+    const bool has_mask = p.rowmask != nullptr;
+    const int srow = lane >> 2;                       // row of the 16-row sweep this lane handles
+    const int sc8 = (lane & 3) * 8;                   // first of its 8 columns inside the 32-column block
+
+    // Addressing: one per-lane byte offset per stream (this lane's row of the sweep, its 8 columns); the block row
+    // (i, it) and the block column j go into the scalar offset of the buffer instruction.
+    const unsigned lrow0 = wm * (32 * NI) + srow;                  // tile row of this lane in sweep (i = 0, it = 0)
+    const unsigned col0 = c.n0 + wn * 64 + sc8;                    // its first column in block j = 0
+    const unsigned vx = res_f32 ? lrow0 * (unsigned)p.ldr * 4 + col0 * 4
+                                : lrow0 * (unsigned)p.lda + (SPLIT == 1 ? col0 * 2 : (col0 >> 5) * 128 + (col0 & 31) * 2);
+    const unsigned sx_row = res_f32 ? (unsigned)p.ldr * 4 : (unsigned)p.lda;       // bytes per row
+    const unsigned sx_j = res_f32 ? 128u : (SPLIT == 1 ? 64u : 128u);              // bytes per 32-column block
+    const unsigned vm = lrow0 * 4;
+    const unsigned vof = lrow0 * (unsigned)p.ldo * 4 + col0 * 4, sof_row = (unsigned)p.ldo * 4;
+    const unsigned vob = lrow0 * (unsigned)p.ldob + (p.out_split == 1 ? col0 * 2 : (col0 >> 5) * 128 + (col0 & 31) * 2);
+    const unsigned sob_row = (unsigned)p.ldob, sob_j = p.out_split == 1 ? 64u : 128u;
+
+    // operands of pass (i, j), sweep it: 8 residual values (fp32, or bf16 hi + lo) and the row mask
+    u32x4 xa[2][2], xb[2][2];
+    float rmv[2][2];
+    auto request = [&](int i, int j, int b) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const unsigned so = (i * 32 + it * 16) * sx_row + j * sx_j;
+            if (res_f32) {
+                xa[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_x, vx, so, 0);
+                xb[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_x, vx + 16, so, 0);
+            } else if (SPLIT == 1) {
+                xa[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_a, vx, so, 0);
+                xb[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_al, vx, so, 0);      // null plane: zeros
+            } else {
+                xa[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_a, vx, so, 0);
+                xb[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_a, vx + 64, so, 0);
+            }
+            rmv[b][it] = has_mask ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_m, vm, (i * 32 + it * 16) * 4, 0)) : 1.f;
+        }
+    };
+    request(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int b = (i * 2 + j) & 1;
+            if (j == 0) request(i, 1, b ^ 1);
+            else if (i + 1 < NI) request(i + 1, 0, b ^ 1);
+            // accumulator block -> LDS.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+            // 16-byte slots of a row are XORed with (row >> 1) & 1: the row-major read-back is bank-conflict free
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                float v = acc[i][j][r] + c.bv[j];
+                v = v > 0.f ? v : v * p.slope;
+                *(float*)(st + rl * 128 + ((((lrow >> 2) ^ ((rl >> 1) & 1))) << 4) + (lrow & 3) * 4) = v;
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = it * 16 + srow;
+                const int sw = (row >> 1) & 1;
+                const float4 d0 = *(const float4*)(st + row * 128 + ((((lane & 3) * 2) ^ sw) << 4));
+                const float4 d1 = *(const float4*)(st + row * 128 + ((((lane & 3) * 2 + 1) ^ sw) << 4));
+                float x[8];
+                const u32x4 qa = xa[b][it], qb = xb[b][it];
+                if (res_f32) {
+                    x[0] = __uint_as_float(qa.x); x[1] = __uint_as_float(qa.y); x[2] = __uint_as_float(qa.z); x[3] = __uint_as_float(qa.w);
+                    x[4] = __uint_as_float(qb.x); x[5] = __uint_as_float(qb.y); x[6] = __uint_as_float(qb.z); x[7] = __uint_as_float(qb.w);
+                } else {
+                    const unsigned ha[4] = {qa.x, qa.y, qa.z, qa.w}, lo[4] = {qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        x[2 * u] = __uint_as_float(ha[u] << 16) + __uint_as_float(lo[u] << 16);
+                        x[2 * u + 1] = __uint_as_float(ha[u] & 0xffff0000u) + __uint_as_float(lo[u] & 0xffff0000u);
+                    }
+                }
+                const float rm = rmv[b][it];
+                float y[8] = {(x[0] + d0.x) * rm, (x[1] + d0.y) * rm, (x[2] + d0.z) * rm, (x[3] + d0.w) * rm,
+                              (x[4] + d1.x) * rm, (x[5] + d1.y) * rm, (x[6] + d1.z) * rm, (x[7] + d1.w) * rm};
+                const unsigned brow = i * 32 + it * 16;
+                if ((int)(lrow0 + brow) >= rows_out) continue;      // rows of the next tile / past the matrix (the descriptors clip them too)
+                if (p.out_f32) {
+                    const u32x4 o0 = {__float_as_uint(y[0]), __float_as_uint(y[1]), __float_as_uint(y[2]), __float_as_uint(y[3])};
+                    const u32x4 o1 = {__float_as_uint(y[4]), __float_as_uint(y[5]), __float_as_uint(y[6]), __float_as_uint(y[7])};
+                    __builtin_amdgcn_raw_buffer_store_b128(o0, r_of, vof, brow * sof_row + j * 128, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o1, r_of, vof + 16, brow * sof_row + j * 128, 0);
+                }
+                if (p.ob) {
+                    float rr[8];
+                    const u32x4 hi = {pack_bf16x2(y[0], y[1], &rr[0], &rr[1]), pack_bf16x2(y[2], y[3], &rr[2], &rr[3]),
+                                      pack_bf16x2(y[4], y[5], &rr[4], &rr[5]), pack_bf16x2(y[6], y[7], &rr[6], &rr[7])};
+                    float d0_, d1_;
+                    const u32x4 lo = {pack_bf16x2(rr[0], rr[1], &d0_, &d1_), pack_bf16x2(rr[2], rr[3], &d0_, &d1_),
+                                      pack_bf16x2(rr[4], rr[5], &d0_, &d1_), pack_bf16x2(rr[6], rr[7], &d0_, &d1_)};
+                    const unsigned so = brow * sob_row + j * sob_j;
+                    __builtin_amdgcn_raw_buffer_store_b128(hi, r_ob, vob, so, 0);
+                    if (p.out_split == 2) __builtin_amdgcn_raw_buffer_store_b128(lo, r_ob, vob + 64, so, 0);
+                    else if (p.ob_lo) __builtin_amdgcn_raw_buffer_store_b128(lo, r_ol, vob, so, 0);
+                }
+            }
+        }
+    }
+}
+
+template <int SPLIT>
+__global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    RcCtx c;
+    c.smem = smem;
+    c.lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem));
+    const int tid = threadIdx.x;
+    c.lane = tid & 63;
+    c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    c.wm = c.wave >> 2; c.wn = c.wave & 3;
+    c.lrow = c.lane & 31; c.lhalf = c.lane >> 5;
+
+    // XCD-aware order: block b runs on XCD b % 8; each XCD gets a contiguous range of (group, column tile) pairs, so the
+    // column tiles of a group (which read the same windows) share an L2
+    int v = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7;
+        const int xcd = v & 7, loc = v >> 3;
+        v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int g = v / p.ntn, nt = v - g * p.ntn;
+    c.n0 = nt * RC_BN;
+    const int cls = g % p.s.ncls;
+    int sum_rows = 0, pre = 0;
+    for (int i = 0; i < p.s.ncls; ++i) { if (i < cls) pre += p.s.rows[i]; sum_rows += p.s.rows[i]; }
+    int m0 = (g / p.s.ncls) * sum_rows + pre;
+    const int end = m0 + p.s.rows[cls] < p.m ? m0 + p.s.rows[cls] : p.m;
+    const int ntile = p.s.ntile[cls];
+    // height of tile t starting at row m: the scheduled one, cut to what is left of this group's rows
+    auto height = [&](int t, int m) -> int {
+        if (t >= ntile || m >= end) return 0;
+        const int ni = p.s.ni[cls][t], need = (end - m + 4 + 63) >> 6;
+        return ni < need ? ni : need;
+    };
+    int ni = height(0, m0);
+    if (ni == 0) return;
+
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = (q * 8 + c.wave) * 8 + (c.lane >> 3);
+        const int sl = (c.lane & 7) ^ ((r >> 1) & 7);
+        c.vow[q] = (unsigned)(r * (int)p.ldw + (sl << 4));
+    }
+    c.w_base = p.w + (long)c.n0 * p.ldw;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) c.bv[j] = p.bias ? p.bias[c.n0 + c.wn * 64 + j * 32 + c.lrow] : 0.f;
+    c.ws = 0; c.wpar = 0;
+
+    // first tile: window of chunk 0, weights of steps 0 and 1
+    {
+        const int rmax = p.m + 143 - (m0 - 2);
+        const char* sb = p.a + (long)(m0 - 2) * p.lda;
+        for (int q = 0; q < ni; ++q) {
+            const int r = (q * 8 + c.wave) * 8 + (c.lane >> 3);
+            const int sl = (c.lane & 7) ^ ((r >> 1) & 7);
+            dma16(c.lds0 + c.wave * 1024 + q * 8192, (unsigned)((r < rmax ? r : rmax) * (int)p.lda + (sl << 4)), sb);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                dma16(c.lds0 + RC_RING + s * RC_W_BYTES + c.wave * 1024 + q * 8192, c.vow[q], c.w_base + (long)s * p.w_tap_stride);
+    }
+    for (int t = 0; ni > 0; ++t) {
+        const int m1 = m0 + 64 * ni - 4;
+        const int ni1 = height(t + 1, m1);
+        const int rows_out = end - m0 < 64 * ni - 4 ? end - m0 : 64 * ni - 4;
+        switch (ni) {
+            case 1: rc_tile<SPLIT, 1>(p, c, m0, rows_out, m1, ni1); break;
+            case 2: rc_tile<SPLIT, 2>(p, c, m0, rows_out, m1, ni1); break;
+            case 3: rc_tile<SPLIT, 3>(p, c, m0, rows_out, m1, ni1); break;
+            default: rc_tile<SPLIT, 4>(p, c, m0, rows_out, m1, ni1); break;
+        }
+        m0 = m1;
+        ni = ni1;
+    }
+}
+
+}  // namespace efts
+
+using namespace efts;
+
+// ---------------------------------------------------------------------------------------------------------------
+// The static tile schedule.  `groups` workgroup groups (one workgroup per column tile each) share the m rows; a group's
+// rows are cut into tiles of 64 * ni - 4 rows, ni <= 4.  Two classes of groups alternate (g % 2): when the rows allow it
+// class 1 gets one 64-row unit less than class 0, so that its last epilogue -- an HBM burst no MFMA work of the same CU
+// can hide -- runs while class 0 still computes, and the epilogues in between fall at different times too.
+// ---------------------------------------------------------------------------------------------------------------
+static int rc_cover(int units) { return 64 * units - 4 * ((units + 3) / 4); }    // rows `units` 64-row units yield in ceil(units / 4) tiles
+
+static void rc_split(int units, bool descending, unsigned char* ni, int* ntile) {
+    const int t = (units + 3) / 4;
+    for (int i = 0; i < t; ++i) {
+        const int v = units / t + (i < units % t ? 1 : 0);      // as even as possible, larger first
+        ni[descending ? i : t - 1 - i] = (unsigned char)v;
+    }
+    *ntile = t;
+}
+
+static void rc_schedule(int m, int slots, RcSched* s, int* groups) {
+    // slots = workgroup groups that can run at once (CUs / column tiles)
+    int units = 1;
+    while (rc_cover(units) * (long)slots < m) ++units;           // every group `units` units: covers m
+    if (units > 4 * RC_MAXTILES) units = 4 * RC_MAXTILES;        // (beyond: more groups than slots, several rounds)
+    s->ncls = 2;
+    const bool uneven = units >= 2 && slots >= 2 && (long)(rc_cover(units) + rc_cover(units - 1)) * (slots / 2) >= m;
+    s->rows[0] = rc_cover(units);
+    rc_split(units, true, s->ni[0], &s->ntile[0]);
+    if (uneven) {
+        s->rows[1] = rc_cover(units - 1);
+        rc_split(units - 1, true, s->ni[1], &s->ntile[1]);
+    } else {
+        s->rows[1] = rc_cover(units);
+        rc_split(units, false, s->ni[1], &s->ntile[1]);
+    }
+    const long pair = s->rows[0] + s->rows[1];
+    long g = (m / pair) * 2;
+    const long rem = m - (m / pair) * pair;
+    if (rem > 0) g += rem > s->rows[0] ? 2 : 1;
+    *groups = (int)g;
+}
+
+// EFTS_RC_SCHED="4,3;3,3" (experiments): tile heights of class 0 ; class 1
+static bool rc_schedule_env(int m, RcSched* s, int* groups) {
+    const char* e = getenv("EFTS_RC_SCHED");
+    if (!e || !*e) return false;
+    s->ncls = 0;
+    int cls = 0, t = 0;
+    s->rows[0] = 0; s->ntile[0] = 0;
+    for (const char* q = e;; ++q) {
+        if (*q >= '1' && *q <= '4') {
+            if (t < RC_MAXTILES) { s->ni[cls][t++] = (unsigned char)(*q - '0'); s->rows[cls] += 64 * (*q - '0') - 4; s->ntile[cls] = t; }
+        } else if (*q == ';' || *q == 0) {
+            if (t > 0) ++cls;
+            t = 0;
+            if (*q == 0 || cls >= RC_MAXCLS) break;
+            s->rows[cls] = 0; s->ntile[cls] = 0;
+        }
+    }
+    if (cls == 0) return false;
+    s->ncls = cls;
+    long sum = 0;
+    for (int i = 0; i < cls; ++i) sum += s->rows[i];
+    long g = (m / sum) * cls;
+    long rem = m - (m / sum) * sum;
+    for (int i = 0; i < cls && rem > 0; ++i) { ++g; rem -= s->rows[i]; }
+    *groups = (int)g;
+    return true;
+}
+
+extern "C" int efts_resconv5(const efts_resconv5_args* a, void* stream) {
+    if (!a) return efts_fail(EFTS_EINVAL, "efts_resconv5: null args");
+    if (!(a->split == 1 || a->split == 2)) return efts_fail(EFTS_EINVAL, "efts_resconv5: split must be 1 or 2");
+    if (a->m <= 0 || a->n <= 0 || a->nchunk <= 0) return efts_fail(EFTS_ESHAPE, "efts_resconv5: m, n, nchunk must be positive");
+    if (a->n % RC_BN) return efts_fail(EFTS_ESHAPE, "efts_resconv5: n must be a multiple of 256");
+    if (!a->x || !a->w) return efts_fail(EFTS_EINVAL, "efts_resconv5: null operand");
+    if (!a->y && !a->y_f32) return efts_fail(EFTS_EINVAL, "efts_resconv5: no output");
+    if (((uintptr_t)a->x & 15) || ((uintptr_t)a->x_lo & 15) || ((uintptr_t)a->w & 15) || (a->ldx & 15) || (a->ldw & 15) || (a->w_tap_stride & 15) ||
+        ((uintptr_t)a->y & 15) || ((uintptr_t)a->y_lo & 15) || (a->ldy & 15) || ((uintptr_t)a->x_f32 & 15) || (a->ldr & 3) ||
+        ((uintptr_t)a->y_f32 & 15) || (a->ldo & 3))
+        return efts_fail(EFTS_EALIGN, "efts_resconv5: planes and fp32 streams must be 16-byte aligned (pointers and row strides)");
+    if (a->ldx < (int64_t)a->nchunk * 128 || a->ldw < (int64_t)a->nchunk * 128)
+        return efts_fail(EFTS_ESHAPE, "efts_resconv5: row stride smaller than nchunk*128 bytes");
+    if (a->ldx > (1 << 23) || a->ldw > (1 << 23)) return efts_fail(EFTS_ESHAPE, "efts_resconv5: row stride above 8 MiB");
+    if (a->y && !(a->y_split == 1 || a->y_split == 2)) return efts_fail(EFTS_EINVAL, "efts_resconv5: y_split must be 1 or 2");
+    if (a->split == 2 && a->x_lo) return efts_fail(EFTS_EINVAL, "efts_resconv5: x_lo is for split-1 planes (split 2 carries lo inside x)");
+    if (a->y_split == 2 && a->y_lo) return efts_fail(EFTS_EINVAL, "efts_resconv5: y_lo is for split-1 output planes");
+
+    RcArgs k;
+    k.a = (const char*)a->x; k.a_lo = (const char*)a->x_lo; k.resid = a->x_f32; k.w = (const char*)a->w;
+    k.bias = a->bias; k.rowmask = a->rowmask; k.out_f32 = a->y_f32; k.ob = (char*)a->y; k.ob_lo = (char*)a->y_lo;
+    k.lda = a->ldx; k.ldw = a->ldw; k.w_tap_stride = a->w_tap_stride; k.ldr = a->ldr; k.ldo = a->ldo; k.ldob = a->ldy;
+    k.m = a->m; k.nchunk = a->nchunk; k.ntn = a->n / RC_BN; k.slope = a->slope; k.out_split = a->y_split;
+    int groups = 0;
+    const int slots = efts_num_cus() / k.ntn > 0 ? efts_num_cus() / k.ntn : 1;
+    if (!rc_schedule_env(a->m, &k.s, &groups)) rc_schedule(a->m, slots, &k.s, &groups);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)resconv5_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
+        (void)hipFuncSetAttribute((const void*)resconv5_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
+        attr = true;
+    }
+    const dim3 grid(groups * k.ntn);
+    if (a->split == 1) hipLaunchKernelGGL(resconv5_kernel<1>, grid, dim3(512), RC_LDS, (hipStream_t)stream, k);
+    else hipLaunchKernelGGL(resconv5_kernel<2>, grid, dim3(512), RC_LDS, (hipStream_t)stream, k);
+    return efts_check_launch("efts_resconv5");
+}

@@ -38,11 +38,23 @@ class GemmArgs(C.Structure):
     ]
 
 
+class ResConv5Args(C.Structure):
+    """mirror of `struct efts_resconv5_args` (include/efts_abi.h)"""
+    _fields_ = [
+        ("x", vp), ("x_lo", vp), ("ldx", i64), ("x_f32", vp), ("ldr", i64),
+        ("w", vp), ("ldw", i64), ("w_tap_stride", i64),
+        ("split", i32), ("m", i32), ("n", i32), ("nchunk", i32),
+        ("bias", vp), ("slope", f32), ("rowmask", vp),
+        ("y_f32", vp), ("ldo", i64), ("y", vp), ("y_lo", vp), ("ldy", i64), ("y_split", i32),
+    ]
+
+
 _SIGS = {
     "efts_version": (i32, []),
     "efts_last_error": (C.c_char_p, []),
     "efts_device_check": (i32, []),
     "efts_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+    "efts_resconv5": (i32, [C.POINTER(ResConv5Args), vp]),
     "efts_pack_weight": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "efts_row_masks": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "efts_embed": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]),

@@ -147,6 +147,23 @@ def gemm(*, a: Plane, a_ptr: Optional[int] = None, b_ptr: int, ldb: int, b_tap_s
     L.check(L.load().efts_gemm(C.byref(g), _stream()), "efts_gemm")
 
 
+def resconv5(*, x: Plane, x_lo: Optional[Plane] = None, x_f32_ptr: Optional[int] = None, ldr: int = 0, w: "PackedWeight",
+             m: int, n: int, bias: Optional[torch.Tensor] = None, slope: float = 0.1, rowmask_ptr: Optional[int] = None,
+             y_f32_ptr: Optional[int] = None, ldo: int = 0, y: Optional[Plane] = None, y_lo: Optional[Plane] = None) -> None:
+    """one residual k5 convolution layer on hi/lo planes (efts_resconv5)"""
+    g = L.ResConv5Args()
+    g.x, g.x_lo, g.ldx = x.ptr, (None if x_lo is None else x_lo.ptr), x.ld
+    g.x_f32, g.ldr = x_f32_ptr, ldr
+    g.w, g.ldw, g.w_tap_stride = w.ptr, w.ld, w.tap_stride
+    g.split, g.m, g.n, g.nchunk = x.split, m, n, x.nchunk
+    g.bias, g.slope, g.rowmask = _p(bias), slope, rowmask_ptr
+    g.y_f32, g.ldo = y_f32_ptr, ldo
+    if y is not None:
+        g.y, g.ldy, g.y_split = y.ptr, y.ld, y.split
+        g.y_lo = None if y_lo is None else y_lo.ptr
+    L.check(L.load().efts_resconv5(C.byref(g), _stream()), "efts_resconv5")
+
+
 class PackedWeight:
     """B operand plane [taps][cout][ld] of one Conv1d / Linear weight."""
 

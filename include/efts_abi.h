@@ -116,6 +116,44 @@ typedef struct efts_gemm_args {
 int efts_gemm(const efts_gemm_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * One residual convolution layer of the EFTS-CNN stacks (ResConv1d.forward,
+ * nntts/layers/efts_modules.py:48-51 with the Conv1d k=5 of :32-35; the stack loop is :77-79):
+ *   y[row, :] = ( x[row, :] + LeakyReLU( conv1d_k5(x)[row, :] + bias, slope ) ) * rowmask[row]
+ * on a padded row space, for long row spaces (the mel-length stacks).  The contraction runs on the operand plane `x`
+ * (format `split`); the RESIDUAL x is taken, in this order, from x_f32 (fp32 [m][ldr]) if given, else from the
+ * planes as hi + lo: split 2 planes carry lo inside x; a split 1 plane may come with a separate lo plane x_lo of the
+ * same layout (NULL: the residual is the bf16 value itself).  Outputs, any combination: y (operand plane of format
+ * y_split; with y_split 1 an optional lo plane y_lo so that the next layer can rebuild its residual), y_f32.
+ * Bit-identical to efts_gemm(taps 5, LeakyReLU, resid, rowmask) on the same operands.
+ * n (= cout) must be a multiple of 256; x is read from 2 rows before row 0 to 144 rows after row m - 1 (the guard rows).
+ * ---------------------------------------------------------------------------------- */
+typedef struct efts_resconv5_args {
+    const void* x;      /* operand plane of the layer input, row 0 */
+    const void* x_lo;   /* split 1 only: bf16 remainder plane of x, or NULL */
+    int64_t ldx;        /* bytes, both planes */
+    const float* x_f32; /* fp32 residual stream or NULL */
+    int64_t ldr;        /* elements */
+    const void* w;      /* B operand plane [5][n][K] (efts_pack_weight) */
+    int64_t ldw;
+    int64_t w_tap_stride;
+    int32_t split;      /* format of x and w: 1 = bf16, 2 = bf16x3 */
+    int32_t m;          /* rows */
+    int32_t n;          /* output channels, % 256 == 0 */
+    int32_t nchunk;     /* 128-byte K chunks per row of x / w */
+    const float* bias;  /* [n] or NULL */
+    float slope;        /* LeakyReLU slope */
+    const float* rowmask; /* [m] or NULL */
+    float* y_f32;       /* fp32 [m][ldo] or NULL */
+    int64_t ldo;        /* elements */
+    void* y;            /* operand plane of the layer output or NULL */
+    void* y_lo;         /* y_split 1 only: remainder plane of y, or NULL */
+    int64_t ldy;        /* bytes, both planes */
+    int32_t y_split;    /* 1 or 2 */
+} efts_resconv5_args;
+
+int efts_resconv5(const efts_resconv5_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Parameter preparation.
  * efts_pack_weight: w[cout][cin][taps] fp32 (torch Conv1d / Linear layout) -> B operand plane
  * [taps][cout][Kp].  With g != NULL the weight-norm fold w = g * v / ||v|| (norm over cin*taps)
