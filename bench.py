@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
     ap.add_argument("--workload", default="fwd64", choices=["fwd64", "fwd16_long", "train32", "infer_lj", "infer64", "logmel64", "vocoder", "vocoder8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--side-stream", type=int, default=1, help="0: text-length work on the main stream (A/B)")
+    ap.add_argument("--resconv", type=int, default=1, help="0: residual stacks on efts_gemm + fp32 stream (A/B)")
     ap.add_argument("--graph", type=int, default=1, help="1 (default): replay the step from a captured hipGraph -- ~75 launches per forward are host-bound in eager mode (3.0 vs 2.6 ms); the roofline events then come from 3 eager steps right after the timed region. 0: eager, events inside the timed region")
     return ap.parse_args()
 
@@ -391,6 +393,7 @@ def main():
     model = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, use_weighted_masking=False,
                             sigma=0.01, precision=a.precision).to(dev).eval()
     text, tl, mel, sl = synth(B, T1, T2, 1234 + rank, dev)
+    model.side_stream, model.resconv = bool(a.side_stream), bool(a.resconv)
 
     def step():
         with torch.no_grad():
@@ -456,8 +459,7 @@ def main():
             traffic = json.load(open(tf)).get(f"{a.precision}:{a.workload}")
         except Exception:
             traffic = None
-    big = model.split == 1 and ((B * (T2 + 2) + 251) // 252) * 4 >= 400      # efts_gemm's own rule for the 256-row kernel
-    kname = "conv5_kernel<split=1> (256-row tiles)" if big else f"gemm_kernel<taps=5,split={model.split}> (124-row tiles)"
+    kname = f"resconv5_kernel<split={model.split}> (persistent, 256-column tiles)"
     roof = dict(bound="mfma", kernel=f"{kname}: k5 Conv1d 512->512, {B}x{T2} frames",
                 achieved=conv_flop / avg / 1e12, peak=PEAK_MFMA_BF16_TFLOPS, unit="TFLOP/s",
                 frac=conv_flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS, traffic=traffic,

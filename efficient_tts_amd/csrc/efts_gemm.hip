@@ -58,6 +58,7 @@ struct GemmKernelArgs {
     const float* rowmask;
     float* out_f32;
     char* out_bf16;
+    char* out_lo;               // out_split 1 only: separate plane for the bf16 remainder (generic gemm_kernel only)
     long lda, ldb, b_tap_stride, ldr, ldo, ldob;
     long a_bs, b_bs, r_bs, m_bs, o_bs, ob_bs;
     long a_bs2, b_bs2, o_bs2;   // outer batch (blockIdx.z)
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
     const float* rowmask = p.rowmask ? p.rowmask + (long)z * p.m_bs : nullptr;
     float* of = p.out_f32 ? p.out_f32 + (long)z * p.o_bs + (long)z2 * p.o_bs2 : nullptr;
     char* ob = p.out_bf16 ? p.out_bf16 + (long)z * p.ob_bs : nullptr;
+    char* obl = (DBG == 0 && p.out_lo) ? p.out_lo + (long)z * p.ob_bs : nullptr;
     const char* A = p.a + (long)z * p.a_bs + (long)z2 * p.a_bs2;
     const char* Bw = p.b + (long)z * p.b_bs + (long)z2 * p.b_bs2;
 
@@ -330,6 +332,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
     if (pre) {
         const __amdgpu_buffer_rsrc_t ro = make_rsrc(of ? of + (long)m0 * p.ldo : nullptr, of ? (long)rows_out * p.ldo * 4 : 0);
         const __amdgpu_buffer_rsrc_t rb = make_rsrc(ob ? ob + (long)m0 * p.ldob : nullptr, ob ? (long)rows_out * p.ldob : 0);
+        const __amdgpu_buffer_rsrc_t rbl = make_rsrc(obl ? obl + (long)m0 * p.ldob : nullptr, obl ? (long)rows_out * p.ldob : 0);
         const unsigned vo = trow * (unsigned)p.ldo * 4 + col * 4, so = RPP * (unsigned)p.ldo * 4;
         const unsigned vb = trow * (unsigned)p.ldob + (unsigned)plane_off_hi(col, p.out_split), sb = RPP * (unsigned)p.ldob;
         const bool has_mask = rowmask != nullptr;
@@ -357,6 +360,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
                     float d0, d1;
                     const u32x2 lo = {pack_bf16x2(r0, r1, &d0, &d1), pack_bf16x2(r2, r3, &d0, &d1)};
                     __builtin_amdgcn_raw_buffer_store_b64(lo, rb, vb + 64, ps * sb, EFTS_AUX_STP);
+                } else if (obl) {
+                    float d0, d1;
+                    const u32x2 lo = {pack_bf16x2(r0, r1, &d0, &d1), pack_bf16x2(r2, r3, &d0, &d1)};
+                    __builtin_amdgcn_raw_buffer_store_b64(lo, rbl, vb, ps * sb, EFTS_AUX_STP);
                 }
             }
         }
@@ -376,6 +383,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
                 v.x *= rm; v.y *= rm; v.z *= rm; v.w *= rm;
                 if (of) *(float4*)(of + (long)row * p.ldo + col) = v;
                 if (ob) plane_store4(ob + (long)row * p.ldob, col, v.x, v.y, v.z, v.w, p.out_split);
+                if (obl) {
+                    plane_store4(obl + (long)row * p.ldob, col, v.x - bf16_to_f32(f32_to_bf16(v.x)), v.y - bf16_to_f32(f32_to_bf16(v.y)),
+                                 v.z - bf16_to_f32(f32_to_bf16(v.z)), v.w - bf16_to_f32(f32_to_bf16(v.w)), 1);
+                }
             } else {
                 float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -391,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
                         char* d = ob + (long)row * p.ldob + plane_off_hi(col + u, p.out_split);
                         *(unsigned short*)d = hi;
                         if (p.out_split == 2) *(unsigned short*)(d + 64) = f32_to_bf16(t - bf16_to_f32(hi));
+                        else if (obl) *(unsigned short*)(obl + (long)row * p.ldob + (col + u) * 2) = f32_to_bf16(t - bf16_to_f32(hi));
                     }
                 }
             }
@@ -1548,7 +1560,9 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     GemmKernelArgs k;
     k.a = (const char*)a->a; k.b = (const char*)a->b;
     k.bias = a->bias; k.resid = a->resid; k.rowmask = a->rowmask;
-    k.out_f32 = a->out_f32; k.out_bf16 = (char*)a->out_bf16;
+    k.out_f32 = a->out_f32; k.out_bf16 = (char*)a->out_bf16; k.out_lo = (char*)a->out_bf16_lo;
+    if (a->out_bf16_lo && (!a->out_bf16 || a->out_split != 1 || a->plane_act || ((uintptr_t)a->out_bf16_lo & 7)))
+        return efts_fail(EFTS_EINVAL, "efts_gemm: out_bf16_lo goes with an un-activated split-1 out_bf16 plane (8-byte aligned)");
     k.lda = a->lda; k.ldb = a->ldb; k.b_tap_stride = a->b_tap_stride; k.ldr = a->ldr; k.ldo = a->ldo; k.ldob = a->ldob;
     k.a_bs = a->a_batch_stride; k.b_bs = a->b_batch_stride; k.r_bs = a->resid_batch_stride;
     k.m_bs = a->rowmask_batch_stride; k.o_bs = a->out_batch_stride; k.ob_bs = a->outb_batch_stride;
@@ -1582,7 +1596,8 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     // one K chunk and at most 64 columns over many rows (the 32- and 64-channel stages of the vocoder): window + all taps
     // resident, 32-column tiles (64 columns = two workgroups per window: 2.11 -> 2.03 ms per utterance, 11.1 -> 10.5 ms per 8)
     static const int resident_nmax = [] { const char* e = getenv("EFTS_RESIDENT_NMAX"); return e ? atoi(e) : 64; }();
-    if (a->n <= resident_nmax && a->nchunk == 1 && nb2 == 1 && (a->taps - 1) * dil <= 64 && a->m >= 8 * R32_WIN && !getenv("EFTS_NO_RESIDENT")) {
+    const bool generic_only = a->out_bf16_lo != nullptr;      // the remainder plane is written by gemm_kernel only
+    if (!generic_only && a->n <= resident_nmax && a->nchunk == 1 && nb2 == 1 && (a->taps - 1) * dil <= 64 && a->m >= 8 * R32_WIN && !getenv("EFTS_NO_RESIDENT")) {
         GemmKernelArgs kr = k;
         kr.bm = R32_WIN - (a->taps - 1) * dil;
         kr.mtiles = (a->m + kr.bm - 1) / kr.bm;
@@ -1594,7 +1609,7 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     int few_per_cu = 1;
     { const char* e = getenv("EFTS_NARROW_FEW"); if (e) few_per_cu = atoi(e); }
     const bool few = (long)k.mtiles * k.ntiles * a->batch < (long)few_per_cu * efts_num_cus() && a->n > 64;
-    if ((a->n <= 64 || few) && nb2 == 1 && !getenv("EFTS_NO_NARROW")) {
+    if (!generic_only && (a->n <= 64 || few) && nb2 == 1 && !getenv("EFTS_NO_NARROW")) {
         GemmKernelArgs kn = k;
         kn.ntiles = a->n <= 32 ? 1 : (a->n + 63) / 64;
         dim3 gn(k.mtiles * kn.ntiles, a->batch, 1);
@@ -1609,7 +1624,7 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
 
     // k5 convolutions with enough rows take the 256-row kernel: EFTS_CONV5 = minimum number of
     // (252-row tile x column tile x batch) workgroups, 0 disables it
-    if (a->taps == 5 && dil == 1 && !a->plane_act && a->act != EFTS_ACT_TANH && nb2 == 1 && !dbg && !prof) {
+    if (!generic_only && a->taps == 5 && dil == 1 && !a->plane_act && a->act != EFTS_ACT_TANH && nb2 == 1 && !dbg && !prof) {
         long min_tiles = a->split == 1 ? C5_DEFAULT_MIN_TILES : 0x7fffffffL;
         { const char* e = getenv("EFTS_CONV5"); if (e) min_tiles = atol(e) > 0 ? atol(e) : 0x7fffffffL; }
         const int mt5 = (a->m + C5_BM - 1) / C5_BM;

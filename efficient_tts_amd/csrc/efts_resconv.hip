@@ -29,6 +29,23 @@
 
 #include "efts_mma.h"
 
+// EFTS_LAB builds only: RC_EXP ablation bits (1 no LDS-DMA in the loop, 2 no counted waits, 4 no MFMA + fragment reads,
+// 8 no epilogue loads / stores, 16 no epilogue at all, 32 no step barriers)
+#ifndef RC_EXP
+#define RC_EXP 0
+#endif
+// tunables (A/B'd on the GPU): epilogue operand prefetch depth in passes; LDS-DMA issue staggered between
+// the two waves of a SIMD; s_setprio around the MFMA clusters
+#ifndef RC_PF
+#define RC_PF 1
+#endif
+#ifndef RC_STAGGER
+#define RC_STAGGER 0
+#endif
+#ifndef RC_PRIO
+#define RC_PRIO 0
+#endif
+
 namespace efts {
 
 constexpr int RC_BN = 256;                                   // output columns per tile
@@ -112,7 +129,8 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
     rc_window_offsets<NI>(p, c, m0, voa);
     const char* a_base = p.a + (long)(m0 - 2) * p.lda;
     auto issue_w = [&](int cn, int kn, int slot) {
-        const char* sb = c.w_base + (long)kn * p.w_tap_stride + (long)cn * 128;
+        const char* sb = (RC_EXP & 64) ? p.w + (((long)kn * p.nchunk + cn) * p.ntn + c.n0 / RC_BN) * RC_W_BYTES    // timing only: tile-contiguous weights
+                                       : c.w_base + (long)kn * p.w_tap_stride + (long)cn * 128;
         const unsigned l = c.lds0 + RC_RING + slot * RC_W_BYTES + wave * 1024;
 #pragma unroll
         for (int q = 0; q < 4; ++q) dma16(l + q * 8192, c.vow[q], sb);
@@ -132,7 +150,9 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto compute = [&](int wbuf, int slot, int k) {
+    // `mid`: called once in the middle of the step's MFMAs (the second wave of every SIMD issues its LDS-DMA there, so the
+    // two waves of a SIMD do not stall on DMA issue at the same moment)
+    auto compute = [&](int wbuf, int slot, int k, auto&& mid) {
         const char* at = smem + wbuf * RC_WIN_BYTES;
         const char* wt = smem + RC_RING + slot * RC_W_BYTES;
         const int arow = wm * (32 * NI) + lrow + k;
@@ -151,12 +171,15 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
             for (int kk = 0; kk < 4; ++kk) {
                 if (kk + 1 < 4) ld(kk + 1, (kk + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
+                if (RC_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j], 0, 0, 0);
+                if (RC_PRIO) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (kk == 1) { mid(); __builtin_amdgcn_sched_barrier(0); }
             }
         } else {
 #pragma unroll
@@ -185,6 +208,7 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (kk == 0) { mid(); __builtin_amdgcn_sched_barrier(0); }
             }
         }
     };
@@ -197,13 +221,18 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
     for (int s = 0; s < nsteps; ++s) {
         const bool do_w = s + 2 < nsteps;
         const bool do_a = (k == 0) && (ch + 1 < p.nchunk);
-        if (do_w) issue_w(c2, k2, ws == 0 ? 2 : ws - 1);                 // weights two steps ahead, slot (ws + 2) % 3
-        if (do_a) issue_a(ch + 1, (c.wpar + ch + 1) & 1);                // next chunk's window into the idle buffer
-        compute((c.wpar + ch) & 1, ws, k);
+        auto issue = [&]() {
+            if (do_w && !(RC_EXP & 1)) issue_w(c2, k2, ws == 0 ? 2 : ws - 1);             // weights two steps ahead, slot (ws + 2) % 3
+            if (do_a && !(RC_EXP & 1)) issue_a(ch + 1, (c.wpar + ch + 1) & 1);            // next chunk's window into the idle buffer
+        };
+        const bool late = RC_STAGGER && wm == 1;       // waves 4-7: the second wave of each SIMD
+        if (!late) issue();
+        if (!(RC_EXP & 4)) compute((c.wpar + ch) & 1, ws, k, [&]() { if (late) issue(); });
+        else if (late) issue();
         // step end: the weights of step s+1 (issued one step ago) and anything older must have landed; LDS-DMA completes
         // in issue order, so it is enough to bound what may still be in flight: this step's own requests
-        rc_wait((do_w ? 4 : 0) + (do_a ? NI : 0));
-        lds_barrier();
+        if (!(RC_EXP & 2)) rc_wait((do_w ? 4 : 0) + (do_a ? NI : 0));
+        if (!(RC_EXP & 32)) lds_barrier();
         if (++k == TAPS) { k = 0; ++ch; }
         if (++k2 == TAPS) { k2 = 0; ++c2; }
         ws = (ws == 2) ? 0 : ws + 1;
@@ -225,6 +254,13 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
         issue_w(0, 1, ws == 2 ? 0 : ws + 1);
     }
 
+    if (RC_EXP & 16) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
     // ---- epilogue, wave-private: staging = this wave's 4 KiB of the ring slot the last step read
     char* st = smem + RC_RING + (ws == 0 ? 2 : ws - 1) * RC_W_BYTES + wave * 4096;
     const __amdgpu_buffer_rsrc_t r_a = make_rsrc(p.a + (long)m0 * p.lda, (long)rows_out * p.lda);
@@ -235,7 +271,7 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
     const __amdgpu_buffer_rsrc_t r_ob = make_rsrc(p.ob ? p.ob + (long)m0 * p.ldob : nullptr, p.ob ? (long)rows_out * p.ldob : 0);
     const __amdgpu_buffer_rsrc_t r_ol = make_rsrc(p.ob_lo ? p.ob_lo + (long)m0 * p.ldob : nullptr, p.ob_lo ? (long)rows_out * p.ldob : 0);
     const bool res_f32 = p.resid != nullptr;
-    const bool has_mask = p.rowmask != nullptr;
+    const bool has_mask = p.rowmask != nullptr && !(RC_EXP & 8);
     const int srow = lane >> 2;                       // row of the 16-row sweep this lane handles
     const int sc8 = (lane & 3) * 8;                   // first of its 8 columns inside the 32-column block
 
@@ -253,13 +289,15 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
     const unsigned sob_row = (unsigned)p.ldob, sob_j = p.out_split == 1 ? 64u : 128u;
 
     // operands of pass (i, j), sweep it: 8 residual values (fp32, or bf16 hi + lo) and the row mask
-    u32x4 xa[2][2], xb[2][2];
-    float rmv[2][2];
+    constexpr int PF = RC_PF < NI * 2 ? RC_PF : NI * 2;      // passes in flight ahead of the one being written out
+    u32x4 xa[PF + 1][2], xb[PF + 1][2];
+    float rmv[PF + 1][2];
     auto request = [&](int i, int j, int b) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const unsigned so = (i * 32 + it * 16) * sx_row + j * sx_j;
-            if (res_f32) {
+            if (RC_EXP & 8) { xa[b][it] = u32x4{0, 0, 0, 0}; xb[b][it] = xa[b][it]; }
+            else if (res_f32) {
                 xa[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_x, vx, so, 0);
                 xb[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_x, vx + 16, so, 0);
             } else if (SPLIT == 1) {
@@ -272,14 +310,14 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
             rmv[b][it] = has_mask ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_m, vm, (i * 32 + it * 16) * 4, 0)) : 1.f;
         }
     };
-    request(0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < PF; ++q) request(q >> 1, q & 1, q % (PF + 1));
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int b = (i * 2 + j) & 1;
-            if (j == 0) request(i, 1, b ^ 1);
-            else if (i + 1 < NI) request(i + 1, 0, b ^ 1);
+            const int b = (i * 2 + j) % (PF + 1);
+            if (i * 2 + j + PF < NI * 2) request((i * 2 + j + PF) >> 1, (i * 2 + j + PF) & 1, (i * 2 + j + PF) % (PF + 1));
             // accumulator block -> LDS.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
             // 16-byte slots of a row are XORed with (row >> 1) & 1: the row-major read-back is bank-conflict free
 #pragma unroll
@@ -312,7 +350,8 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
                 float y[8] = {(x[0] + d0.x) * rm, (x[1] + d0.y) * rm, (x[2] + d0.z) * rm, (x[3] + d0.w) * rm,
                               (x[4] + d1.x) * rm, (x[5] + d1.y) * rm, (x[6] + d1.z) * rm, (x[7] + d1.w) * rm};
                 const unsigned brow = i * 32 + it * 16;
-                if ((int)(lrow0 + brow) >= rows_out) continue;      // rows of the next tile / past the matrix (the descriptors clip them too)
+                if ((int)(lrow0 + brow) >= rows_out) continue;
+                if (RC_EXP & 8) { asm volatile("" ::"v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7])); continue; }      // rows of the next tile / past the matrix (the descriptors clip them too)
                 if (p.out_f32) {
                     const u32x4 o0 = {__float_as_uint(y[0]), __float_as_uint(y[1]), __float_as_uint(y[2]), __float_as_uint(y[3])};
                     const u32x4 o1 = {__float_as_uint(y[4]), __float_as_uint(y[5]), __float_as_uint(y[6]), __float_as_uint(y[7])};
@@ -377,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
     for (int q = 0; q < 4; ++q) {
         const int r = (q * 8 + c.wave) * 8 + (c.lane >> 3);
         const int sl = (c.lane & 7) ^ ((r >> 1) & 7);
-        c.vow[q] = (unsigned)(r * (int)p.ldw + (sl << 4));
+        c.vow[q] = (RC_EXP & 64) ? (unsigned)(r * 128 + (sl << 4)) : (unsigned)(r * (int)p.ldw + (sl << 4));
     }
     c.w_base = p.w + (long)c.n0 * p.ldw;
 #pragma unroll

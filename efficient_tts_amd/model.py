@@ -180,6 +180,8 @@ class EfficientTTSCNN(torch.nn.Module):
         self.decoder = _ResConvBlock(n_decoder_layer, n_channels, k_size, a, ap, dropout_rate, use_weight_norm)
         self.mel_output_layer = torch.nn.Linear(n_channels, odim)
         self.duration_predictor = _DurationPredictor(n_channels, n_duration_layer, n_channels, offset=duration_offset)
+        self.side_stream = True             # text-length work on a second HIP stream beside the mel-length kernels
+        self.resconv = True                 # long row spaces: residual stacks on efts_resconv5 (False: efts_gemm + fp32 stream, A/B and tests)
         self.dropout_seed = 0x5EED          # base seed of the duration predictor's dropout masks (train mode)
         self._packed: Dict[str, PackedWeight] = {}
         self._packed_sig = None
@@ -270,6 +272,8 @@ class EfficientTTSCNN(torch.nn.Module):
         return pk
 
     def _side_stream(self, device) -> "torch.cuda.Stream":
+        if not self.side_stream:
+            return torch.cuda.current_stream(device)
         st = getattr(self, "_side", None)
         if st is None or st.device != device:
             st = torch.cuda.Stream(device=device)
@@ -284,11 +288,41 @@ class EfficientTTSCNN(torch.nn.Module):
         return self._ws[key]
 
     # ------------------------------------------------------------------ building blocks
-    def _res_stack(self, ws, tag, blk, pk, rs: Rows, x_f32: F32Rows, x_pl: Plane, gap_ptr, last_split: int,
-                   last_f32: bool):
+    # row spaces of at least this many rows run their residual stacks on efts_resconv5 (hi/lo planes, one persistent
+    # 8-wave workgroup per CU); shorter ones keep the fp32 stream + efts_gemm, whose 124-row tiles fill the chip better
+    RESCONV_MIN_ROWS = 16384
+
+    def _on_resconv(self, rs: Rows) -> bool:
+        return self.resconv and rs.rows >= self.RESCONV_MIN_ROWS and self.n_channels % 256 == 0
+
+    def _stream_in(self, ws, tag, rs: Rows):
+        """Buffers the producer of a residual stack's input writes: (fp32 stream or None, operand plane, lo plane or None).
+        A stack on efts_resconv5 reads its residual from the planes, so no fp32 copy is written at all."""
+        C = self.n_channels
+        pl = ws.plane(f"{tag}_p", rs, C, self.split)
+        if self._on_resconv(rs):
+            return None, pl, (ws.plane(f"{tag}_l", rs, C, 1) if self.split == 1 else None)
+        return ws.f32(f"{tag}_f", rs, C), pl, None
+
+    def _res_stack(self, ws, tag, blk, pk, rs: Rows, x_f32: Optional[F32Rows], x_pl: Plane, gap_ptr, last_split: int,
+                   last_f32: bool, x_lo: Optional[Plane] = None):
         """n x ( x + LeakyReLU(conv1d_k5(x)) ) on the row space (efts_modules.py:48-51,77-79)."""
         n = len(getattr(self, blk).layers)
         C = self.n_channels
+        if self._on_resconv(rs):
+            # The stream between the layers is a pair of bf16 planes (hi = the next layer's MFMA operand, lo = the
+            # remainder; split 2 planes carry both): 4 B read + 4 B written per element and layer instead of 4 + 6..8 B.
+            for i in range(n):
+                last = i == n - 1
+                o_split = last_split if last else self.split
+                y = ws.plane(f"{tag}_p{i & 1}", rs, C, o_split)
+                y_lo = ws.plane(f"{tag}_l{i & 1}", rs, C, 1) if (o_split == 1 and not last) else None
+                o_f32 = ws.f32(f"{tag}_f{i & 1}", rs, C) if (last and last_f32) else None
+                O.resconv5(x=x_pl, x_lo=x_lo, x_f32_ptr=x_f32.ptr if (i == 0 and x_f32 is not None) else None, ldr=C, w=pk[f"{blk}.{i}"],
+                           m=rs.rows, n=C, bias=getattr(self, blk).layers[i].conv[0].bias, slope=self.slope,
+                           rowmask_ptr=gap_ptr, y_f32_ptr=None if o_f32 is None else o_f32.ptr, ldo=C, y=y, y_lo=y_lo)
+                x_pl, x_lo = y, y_lo
+            return o_f32, x_pl
         for i in range(n):
             last = i == n - 1
             w = pk[f"{blk}.{i}"]
@@ -347,13 +381,12 @@ class EfficientTTSCNN(torch.nn.Module):
         C = self.n_channels
         vt = ws.raw_plane("vt", B * C, T1, 2)
         O.pack_vt(val_f, vt, B, T1, rs1.Tp, C)
-        h_f = ws.f32("exp_f", rs2, C)
-        h_p = ws.plane("exp_p", rs2, C, self.split)
+        h_f, h_p, h_l = self._stream_in(ws, "exp", rs2)
         O.gemm(a=ra_plane, b_ptr=vt.ptr, ldb=vt.ld, m=rs2.T, n=C, batch=B, a_batch_stride=rs2.Tp * ra_plane.ld,
                b_batch_stride=C * vt.ld, rowmask_ptr=len2_ptr, rowmask_batch_stride=rs2.Tp,
-               out_f32_ptr=h_f.ptr, ldo=C, out_batch_stride=rs2.Tp * C, out_plane=h_p,
-               outb_batch_stride=rs2.Tp * h_p.ld)
-        _, d_p = self._res_stack(ws, "dec", "decoder", pk, rs2, h_f, h_p, gap2.data_ptr(), self.split, False)
+               out_f32_ptr=None if h_f is None else h_f.ptr, ldo=C, out_batch_stride=rs2.Tp * C, out_plane=h_p,
+               outb_batch_stride=rs2.Tp * h_p.ld, out_plane_lo=h_l)
+        _, d_p = self._res_stack(ws, "dec", "decoder", pk, rs2, h_f, h_p, gap2.data_ptr(), self.split, False, x_lo=h_l)
         mel = ws.f32("mel_pred", rs2, self.odim)
         wh = pk["head"]
         O.gemm(a=d_p, b_ptr=wh.ptr, ldb=wh.ld, m=rs2.rows, n=self.odim, bias=self.mel_output_layer.bias,
@@ -411,11 +444,12 @@ class EfficientTTSCNN(torch.nn.Module):
             dur = self._duration(ws, pk, rs1, val_p, gap1, len1.data_ptr(), 0)    # :219
         mel_in = ws.plane("mel_in", rs2, self.odim, self.split)                   # :161 prenet
         O.pack_rows(speech, None, mel_in, rs2)
-        pre_f, pre_p = ws.f32("pre_f", rs2, C), ws.plane("pre_p", rs2, C, self.split)
+        pre_f, pre_p, pre_l = self._stream_in(ws, "pre", rs2)
         wp = pk["prenet"]
         O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, act=L.ACT_LEAKY, slope=self.slope,
-               bias=self.mel_prenet[0].bias, rowmask_ptr=gap2.data_ptr(), out_f32_ptr=pre_f.ptr, ldo=C, out_plane=pre_p)
-        _, q_p = self._res_stack(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2, False)   # :162
+               bias=self.mel_prenet[0].bias, rowmask_ptr=gap2.data_ptr(), out_f32_ptr=None if pre_f is None else pre_f.ptr,
+               ldo=C, out_plane=pre_p, out_plane_lo=pre_l)
+        _, q_p = self._res_stack(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2, False, x_lo=pre_l)   # :162
         main.wait_event(k_ready)
 
         scores = ws.tensor("scores", (B, T2, T1))                                 # :390 q.k/sqrt(D)

@@ -120,7 +120,8 @@ def gemm(*, a: Plane, a_ptr: Optional[int] = None, b_ptr: int, ldb: int, b_tap_s
          out_f32_ptr: Optional[int] = None, ldo: int = 0, out_batch_stride: int = 0,
          out_plane: Optional[Plane] = None, out_plane_ptr: Optional[int] = None, outb_batch_stride: int = 0,
          nchunk: Optional[int] = None, batch2: int = 0, a_batch2_stride: int = 0, b_batch2_stride: int = 0,
-         out_batch2_stride: int = 0, dilation: int = 1, plane_act: bool = False, plane_slope: float = 0.0) -> None:
+         out_batch2_stride: int = 0, dilation: int = 1, plane_act: bool = False, plane_slope: float = 0.0,
+         out_plane_lo: Optional[Plane] = None) -> None:
     g = L.GemmArgs()
     g.a, g.lda, g.a_batch_stride = (a_ptr if a_ptr is not None else a.ptr), a.ld, a_batch_stride
     g.b, g.ldb, g.b_tap_stride, g.b_batch_stride = b_ptr, ldb, b_tap_stride, b_batch_stride
@@ -137,6 +138,7 @@ def gemm(*, a: Plane, a_ptr: Optional[int] = None, b_ptr: int, ldb: int, b_tap_s
     g.outb_batch_stride = outb_batch_stride
     g.batch2, g.a_batch2_stride, g.b_batch2_stride, g.out_batch2_stride = batch2, a_batch2_stride, b_batch2_stride, out_batch2_stride
     g.dilation, g.plane_act, g.plane_slope = dilation, int(plane_act), plane_slope
+    g.out_bf16_lo = None if out_plane_lo is None else out_plane_lo.ptr
     if PROFILE is not None and (PROFILE_TAG is None or PROFILE_TAG == (taps, m, n)):
         s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s0.record()
@@ -161,6 +163,13 @@ def resconv5(*, x: Plane, x_lo: Optional[Plane] = None, x_f32_ptr: Optional[int]
     if y is not None:
         g.y, g.ldy, g.y_split = y.ptr, y.ld, y.split
         g.y_lo = None if y_lo is None else y_lo.ptr
+    if PROFILE is not None and (PROFILE_TAG is None or PROFILE_TAG == (5, m, n)):
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        L.check(L.load().efts_resconv5(C.byref(g), _stream()), "efts_resconv5")
+        s1.record()
+        PROFILE.append(((5, m, n), s0, s1))
+        return
     L.check(L.load().efts_resconv5(C.byref(g), _stream()), "efts_resconv5")
 
 

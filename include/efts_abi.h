@@ -111,6 +111,9 @@ typedef struct efts_gemm_args {
      * activation to their INPUT (pre-activation residual blocks); out_f32 stays un-activated. */
     int32_t plane_act;
     float plane_slope;
+    /* out_split 1 only, optional: a second plane of the layout of out_bf16 that receives the bf16 REMAINDER
+     * out - bf16(out), so that a consumer can rebuild out to 16 mantissa bits (the residual input of efts_resconv5). */
+    void* out_bf16_lo;
 } efts_gemm_args;
 
 int efts_gemm(const efts_gemm_args* a, void* stream);

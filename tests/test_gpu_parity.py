@@ -226,7 +226,9 @@ def test_full_size_properties(model):
     assert float((mel_pred[perm] - mel2).abs().max()) == 0.0            # bitwise: tiles never mix items and
     assert float((imv[perm] - imv2).abs().max()) == 0.0                 # every row sees the same summation order
     assert abs(float(loss) - float(loss2)) <= 1e-5 * float(loss)
-    assert float((mel_pred[sub] - mel3).abs().max()) <= 1e-4             # item independence (tile phase differs)
+    # item independence across kernels: the 64-item row space runs its stacks on efts_resconv5 with a hi/lo bf16 stream,
+    # the 4-item one on efts_gemm with an fp32 stream (2^-17 relative per layer; both sit within 1e-3 of the oracle)
+    assert float((mel_pred[sub] - mel3).abs().max()) <= 5e-4
     assert float((ralpha.sum(1) - 1).abs().max()) <= 1e-4
     assert float((imv[:, 1:] - imv[:, :-1]).min()) >= 0.0
     assert float((imv[:, -1] - (T1 - 1)).abs().max()) <= 1e-3

@@ -63,7 +63,7 @@ def case(B, T, split, check=True, time=True):
     with P.stream_scope():
         ref(); torch.cuda.synchronize()
         ok = True
-        for mode in ("f32in_split2out", "planes"):
+        for mode in os.environ.get("PMODES", "f32in_split2out,planes").split(","):
             o, y, yl, fn = mk(mode)
             fn(); torch.cuda.synchronize()
             if check:
@@ -87,7 +87,7 @@ def case(B, T, split, check=True, time=True):
             if time:
                 ts = [timeit(fn) for _ in range(3)]
                 print(f"  B={B} T={T} split={split} {mode}: " + " ".join(f"{t:.1f}" for t in ts) + " us", flush=True)
-        if time:
+        if time and os.environ.get("PREF", "1") == "1":
             ts = [timeit(ref) for _ in range(3)]
             print(f"  B={B} T={T} split={split} efts_gemm: " + " ".join(f"{t:.1f}" for t in ts) + " us", flush=True)
     return ok
@@ -98,5 +98,5 @@ if __name__ == "__main__":
     for sp in ((1, 2) if split == 0 else (split,)):
         for sh in shapes.split(","):
             B, T = map(int, sh.split("x"))
-            allok &= case(B, T, sp, time=B * T >= 4000)
+            allok &= case(B, T, sp, check=os.environ.get("PCHECK", "1") == "1", time=B * T >= 4000)
     print("ALL EQUAL" if allok else "MISMATCH", flush=True)
