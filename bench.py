@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--side-stream", type=int, default=1, help="0: text-length work on the main stream (A/B)")
     ap.add_argument("--resconv", type=int, default=1, help="0: residual stacks on efts_gemm + fp32 stream (A/B)")
+    ap.add_argument("--resconv-min-rows", type=int, default=-1, help="A/B: row-space size from which the stacks run on efts_resconv5")
     ap.add_argument("--graph", type=int, default=1, help="1 (default): replay the step from a captured hipGraph -- ~75 launches per forward are host-bound in eager mode (3.0 vs 2.6 ms); the roofline events then come from 3 eager steps right after the timed region. 0: eager, events inside the timed region")
     return ap.parse_args()
 
@@ -394,6 +395,8 @@ def main():
                             sigma=0.01, precision=a.precision).to(dev).eval()
     text, tl, mel, sl = synth(B, T1, T2, 1234 + rank, dev)
     model.side_stream, model.resconv = bool(a.side_stream), bool(a.resconv)
+    if a.resconv_min_rows >= 0:
+        model.RESCONV_MIN_ROWS = a.resconv_min_rows
 
     def step():
         with torch.no_grad():

@@ -497,32 +497,54 @@ static void rc_schedule(int m, int slots, RcSched* s, int* groups) {
     *groups = (int)g;
 }
 
-// EFTS_RC_SCHED="4,3;3,3" (experiments): tile heights of class 0 ; class 1
-static bool rc_schedule_env(int m, RcSched* s, int* groups) {
-    const char* e = getenv("EFTS_RC_SCHED");
-    if (!e || !*e) return false;
-    s->ncls = 0;
-    int cls = 0, t = 0;
-    s->rows[0] = 0; s->ntile[0] = 0;
-    for (const char* q = e;; ++q) {
-        if (*q >= '1' && *q <= '4') {
-            if (t < RC_MAXTILES) { s->ni[cls][t++] = (unsigned char)(*q - '0'); s->rows[cls] += 64 * (*q - '0') - 4; s->ntile[cls] = t; }
-        } else if (*q == ';' || *q == 0) {
-            if (t > 0) ++cls;
-            t = 0;
-            if (*q == 0 || cls >= RC_MAXCLS) break;
-            s->rows[cls] = 0; s->ntile[cls] = 0;
-        }
+// plan <-> RcSched.  A plan is an int32 array: [groups, classes, then per class: rows, ntile, ni[0..7]]
+constexpr int RC_PLAN_INTS = 2 + RC_MAXCLS * (2 + RC_MAXTILES);
+
+static void rc_plan_write(const RcSched& s, int groups, int32_t* plan) {
+    plan[0] = groups; plan[1] = s.ncls;
+    for (int c = 0; c < RC_MAXCLS; ++c) {
+        int32_t* q = plan + 2 + c * (2 + RC_MAXTILES);
+        q[0] = c < s.ncls ? s.rows[c] : 0;
+        q[1] = c < s.ncls ? s.ntile[c] : 0;
+        for (int t = 0; t < RC_MAXTILES; ++t) q[2 + t] = (c < s.ncls && t < s.ntile[c]) ? s.ni[c][t] : 0;
     }
-    if (cls == 0) return false;
-    s->ncls = cls;
+}
+
+// a caller-supplied plan: every class's tiles must add up to its rows, and the groups must cover m
+static const char* rc_plan_read(const int32_t* plan, int m, RcSched* s, int* groups) {
+    *groups = plan[0];
+    s->ncls = plan[1];
+    if (s->ncls < 1 || s->ncls > RC_MAXCLS || *groups < 1) return "plan: classes must be 1..4 and groups positive";
     long sum = 0;
-    for (int i = 0; i < cls; ++i) sum += s->rows[i];
-    long g = (m / sum) * cls;
-    long rem = m - (m / sum) * sum;
-    for (int i = 0; i < cls && rem > 0; ++i) { ++g; rem -= s->rows[i]; }
-    *groups = (int)g;
-    return true;
+    for (int c = 0; c < s->ncls; ++c) {
+        const int32_t* q = plan + 2 + c * (2 + RC_MAXTILES);
+        s->rows[c] = q[0]; s->ntile[c] = q[1];
+        if (q[1] < 1 || q[1] > RC_MAXTILES) return "plan: 1..8 tiles per class";
+        int rows = 0;
+        for (int t = 0; t < q[1]; ++t) {
+            if (q[2 + t] < 1 || q[2 + t] > 4) return "plan: tile heights must be 1..4 (units of 64 window rows)";
+            s->ni[c][t] = (unsigned char)q[2 + t];
+            rows += 64 * q[2 + t] - 4;
+        }
+        if (rows != q[0]) return "plan: a class's rows must equal the sum of 64 * ni - 4 over its tiles";
+        sum += rows;
+    }
+    long covered = (*groups / s->ncls) * sum;
+    for (int c = 0; c < *groups % s->ncls; ++c) covered += s->rows[c];
+    if (covered < m) return "plan: the groups do not cover m rows";
+    return nullptr;
+}
+
+extern "C" int efts_resconv5_plan(int32_t m, int32_t n, int32_t cus, int32_t* plan, int32_t cap) {
+    if (m <= 0 || n <= 0 || n % RC_BN) return efts_fail(EFTS_ESHAPE, "efts_resconv5_plan: m must be positive and n a positive multiple of 256");
+    if (!plan || cap < RC_PLAN_INTS) return efts_fail(EFTS_EINVAL, "efts_resconv5_plan: plan must hold %d int32", RC_PLAN_INTS);
+    if (cus <= 0) cus = efts_num_cus();
+    const int ntn = n / RC_BN;
+    RcSched s;
+    int groups = 0;
+    rc_schedule(m, cus / ntn > 0 ? cus / ntn : 1, &s, &groups);
+    rc_plan_write(s, groups, plan);
+    return RC_PLAN_INTS;
 }
 
 extern "C" int efts_resconv5(const efts_resconv5_args* a, void* stream) {
@@ -549,8 +571,12 @@ extern "C" int efts_resconv5(const efts_resconv5_args* a, void* stream) {
     k.lda = a->ldx; k.ldw = a->ldw; k.w_tap_stride = a->w_tap_stride; k.ldr = a->ldr; k.ldo = a->ldo; k.ldob = a->ldy;
     k.m = a->m; k.nchunk = a->nchunk; k.ntn = a->n / RC_BN; k.slope = a->slope; k.out_split = a->y_split;
     int groups = 0;
-    const int slots = efts_num_cus() / k.ntn > 0 ? efts_num_cus() / k.ntn : 1;
-    if (!rc_schedule_env(a->m, &k.s, &groups)) rc_schedule(a->m, slots, &k.s, &groups);
+    if (a->plan) {
+        const char* bad = rc_plan_read(a->plan, a->m, &k.s, &groups);
+        if (bad) return efts_fail(EFTS_EINVAL, "efts_resconv5: %s", bad);
+    } else {
+        rc_schedule(a->m, efts_num_cus() / k.ntn > 0 ? efts_num_cus() / k.ntn : 1, &k.s, &groups);
+    }
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)resconv5_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);

@@ -12,6 +12,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EFTS_LIB", os.path.join(HERE, "libefts_hip.so"))   # EFTS_LIB: kernel experiments only
 
+RC_PLAN_INTS = 42
 GAP = 2
 GUARD_LO = 8
 GUARD_HI = 144
@@ -47,6 +48,7 @@ class ResConv5Args(C.Structure):
         ("split", i32), ("m", i32), ("n", i32), ("nchunk", i32),
         ("bias", vp), ("slope", f32), ("rowmask", vp),
         ("y_f32", vp), ("ldo", i64), ("y", vp), ("y_lo", vp), ("ldy", i64), ("y_split", i32),
+        ("plan", C.POINTER(i32)),
     ]
 
 
@@ -56,6 +58,7 @@ _SIGS = {
     "efts_device_check": (i32, []),
     "efts_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "efts_resconv5": (i32, [C.POINTER(ResConv5Args), vp]),
+    "efts_resconv5_plan": (i32, [i32, i32, i32, C.POINTER(i32), i32]),
     "efts_pack_weight": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "efts_row_masks": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "efts_embed": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]),

@@ -151,9 +151,12 @@ def gemm(*, a: Plane, a_ptr: Optional[int] = None, b_ptr: int, ldb: int, b_tap_s
 
 def resconv5(*, x: Plane, x_lo: Optional[Plane] = None, x_f32_ptr: Optional[int] = None, ldr: int = 0, w: "PackedWeight",
              m: int, n: int, bias: Optional[torch.Tensor] = None, slope: float = 0.1, rowmask_ptr: Optional[int] = None,
-             y_f32_ptr: Optional[int] = None, ldo: int = 0, y: Optional[Plane] = None, y_lo: Optional[Plane] = None) -> None:
-    """one residual k5 convolution layer on hi/lo planes (efts_resconv5)"""
+             y_f32_ptr: Optional[int] = None, ldo: int = 0, y: Optional[Plane] = None, y_lo: Optional[Plane] = None,
+             plan=None) -> None:
+    """one residual k5 convolution layer on hi/lo planes (efts_resconv5); plan: explicit tile schedule (make_plan)"""
     g = L.ResConv5Args()
+    if plan is not None:
+        g.plan = plan
     g.x, g.x_lo, g.ldx = x.ptr, (None if x_lo is None else x_lo.ptr), x.ld
     g.x_f32, g.ldr = x_f32_ptr, ldr
     g.w, g.ldw, g.w_tap_stride = w.ptr, w.ld, w.tap_stride
@@ -171,6 +174,38 @@ def resconv5(*, x: Plane, x_lo: Optional[Plane] = None, x_f32_ptr: Optional[int]
         PROFILE.append(((5, m, n), s0, s1))
         return
     L.check(L.load().efts_resconv5(C.byref(g), _stream()), "efts_resconv5")
+
+
+def resconv5_plan(m: int, n: int, cus: int = 0):
+    """the automatic tile schedule as (groups, [(rows, [ni, ...]), ...])"""
+    buf = (C.c_int32 * L.RC_PLAN_INTS)()
+    rc = L.load().efts_resconv5_plan(m, n, cus, buf, L.RC_PLAN_INTS)
+    if rc < 0:
+        L.check(rc, "efts_resconv5_plan")
+    classes = []
+    for c in range(buf[1]):
+        q = 2 + c * 10
+        classes.append((buf[q], [buf[q + 2 + t] for t in range(buf[q + 1])]))
+    return buf[0], classes
+
+
+def make_plan(m: int, classes):
+    """explicit schedule for efts_resconv5: classes = [[ni, ...], ...] (tile heights per class, 1..4); enough groups to cover m"""
+    buf = (C.c_int32 * L.RC_PLAN_INTS)()
+    rows = [sum(64 * ni - 4 for ni in cl) for cl in classes]
+    full, rem, groups = m // sum(rows), m % sum(rows), 0
+    groups = full * len(classes)
+    for r in rows:
+        if rem <= 0:
+            break
+        groups, rem = groups + 1, rem - r
+    buf[0], buf[1] = groups, len(classes)
+    for c, cl in enumerate(classes):
+        q = 2 + c * 10
+        buf[q], buf[q + 1] = rows[c], len(cl)
+        for t, ni in enumerate(cl):
+            buf[q + 2 + t] = ni
+    return buf
 
 
 class PackedWeight:

@@ -1,0 +1,135 @@
+"""GPU (-m gpu): efts_resconv5 -- one residual k5 convolution layer on hi/lo planes, ResConv1d.forward of the reference
+(nntts/layers/efts_modules.py:48-51) -- against efts_gemm (bit-exact: same per-element summation order) and against an
+fp64 restatement of the layer; every tile height, multi-tile schedules, ragged row counts, both operand formats and all
+input / output stream formats."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+C = 512
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def bf16_split(x):
+    hi = x.to(torch.bfloat16)
+    return hi, (x - hi.float()).to(torch.bfloat16)
+
+
+class Case:
+    """x (exactly representable as hi + lo), weights, bias, gap mask of a B x T row space, and the efts_gemm result"""
+
+    def __init__(self, B, T, split, seed=0):
+        from efficient_tts_amd import lib as L, ops as P
+        L.load(); L.require_device()
+        self.L, self.P, self.split = L, P, split
+        dev = _dev()
+        torch.manual_seed(seed + 1000 * B + T)
+        self.rs = rs = P.Rows(B, T)
+        x = torch.randn(B, T, C, device=dev)
+        hi, lo = bf16_split(x)
+        x16 = hi.float() + lo.float()
+        hi, lo = bf16_split(x16)                      # bf16(x16) may differ from bf16(x) at rounding ties
+        self.x16 = x16
+        self.a = P.Plane.for_rows(rs, C, split, dev)
+        P.pack_rows(x16, None, self.a, rs)
+        self.a_lo = None
+        if split == 1:
+            self.a_lo = P.Plane.for_rows(rs, C, 1, dev)
+            P.pack_rows(lo.float().contiguous(), None, self.a_lo, rs)
+        self.xf = P.F32Rows(rs, C, dev); self.xf.view().copy_(x16)
+        self.w = (torch.randn(C, C, 5, device=dev) * 0.02).contiguous()
+        self.pw = P.PackedWeight(C, C, 5, split, dev); self.pw.pack(self.w)
+        self.bias = torch.randn(C, device=dev)
+        lens = torch.randint(max(1, T // 2), T + 1, (B,), dtype=torch.int32, device=dev)
+        self.mask = torch.zeros(rs.rows, device=dev)
+        P.row_masks(lens, rs, None, self.mask)        # a LENGTH mask: rows past an item's length are zeroed too
+        self.o_ref, self.p_ref = P.F32Rows(rs, C, dev), P.Plane.for_rows(rs, C, 2, dev)
+        P.gemm(a=self.a, b_ptr=self.pw.ptr, ldb=self.pw.ld, b_tap_stride=self.pw.tap_stride, taps=5, m=rs.rows, n=C,
+               act=L.ACT_LEAKY, slope=0.1, bias=self.bias, resid_ptr=self.xf.ptr, ldr=C, rowmask_ptr=self.mask.data_ptr(),
+               out_f32_ptr=self.o_ref.ptr, ldo=C, out_plane=self.p_ref)
+        torch.cuda.synchronize()
+
+    def run(self, mode, plan=None):
+        P, rs, dev = self.P, self.rs, _dev()
+        o = P.F32Rows(rs, C, dev)
+        if mode == "f32":          # fp32 residual in, fp32 + split-2 plane out
+            y, yl = P.Plane.for_rows(rs, C, 2, dev), None
+            P.resconv5(x=self.a, x_f32_ptr=self.xf.ptr, ldr=C, w=self.pw, m=rs.rows, n=C, bias=self.bias,
+                       rowmask_ptr=self.mask.data_ptr(), y_f32_ptr=o.ptr, ldo=C, y=y, plan=plan)
+        else:                      # planes in, planes of the same format out (+ fp32 for the comparison)
+            y = P.Plane.for_rows(rs, C, self.split, dev)
+            yl = P.Plane.for_rows(rs, C, 1, dev) if self.split == 1 else None
+            P.resconv5(x=self.a, x_lo=self.a_lo, w=self.pw, m=rs.rows, n=C, bias=self.bias, rowmask_ptr=self.mask.data_ptr(),
+                       y_f32_ptr=o.ptr, ldo=C, y=y, y_lo=yl, plan=plan)
+        torch.cuda.synchronize()
+        return o, y, yl
+
+    def check(self, mode, plan=None):
+        o, y, yl = self.run(mode, plan)
+        assert torch.equal(o.buf, self.o_ref.buf), f"fp32 differs: {(o.buf - self.o_ref.buf).abs().max().item():.3e}"
+        if mode == "f32" or self.split == 2:
+            assert torch.equal(y.buf, self.p_ref.buf)
+        else:
+            rh, rl = bf16_split(self.o_ref.buf)
+            n = self.rs.alloc
+            assert torch.equal(y.buf.view(torch.bfloat16).view(n, -1)[:, :C], rh)
+            assert torch.equal(yl.buf.view(torch.bfloat16).view(n, -1)[:, :C], rl)
+
+
+@pytest.mark.parametrize("split", [1, 2])
+@pytest.mark.parametrize("B,T", [(3, 37), (5, 300), (1, 1), (2, 801)])
+@pytest.mark.parametrize("mode", ["f32", "planes"])
+def test_resconv5_equals_gemm_automatic_schedule(split, B, T, mode):
+    Case(B, T, split).check(mode)
+
+
+@pytest.mark.parametrize("split", [1, 2])
+@pytest.mark.parametrize("classes", [[[1]], [[2]], [[3]], [[4]], [[2], [1]], [[3, 1]], [[4, 3], [3, 3]], [[1, 2, 3, 4]], [[4], [3], [2], [1]]])
+def test_resconv5_every_tile_height_and_multi_tile_schedules(split, classes):
+    """explicit plans: every tile height, tiles of different heights in one workgroup (window buffers / ring slots carried
+    across tiles, the next tile's first operands requested before the epilogue), 1 .. 4 classes"""
+    c = Case(5, 300, split, seed=7)
+    plan = c.P.make_plan(c.rs.rows, classes)
+    c.check("planes", plan)
+    c.check("f32", plan)
+
+
+def test_resconv5_vs_fp64_layer():
+    """the layer itself against an fp64 restatement: y = (x + LeakyReLU(conv1d_k5(x_hi) + b)) * mask per item"""
+    c = Case(3, 70, 2, seed=3)
+    o, _, _ = c.run("planes")
+    rs = c.rs
+    x = c.x16.double()                                                       # [B, T, C]
+    hi, lo = bf16_split(c.w)
+    w = (hi.double() + lo.double())                                          # bf16x3 operands: 16 mantissa bits of w
+    conv = torch.nn.functional.conv1d(x.transpose(1, 2), w, c.bias.double(), padding=2).transpose(1, 2)
+    y = x + torch.nn.functional.leaky_relu(conv, 0.1)
+    y = y * c.mask.view(rs.B, rs.Tp)[:, :rs.T, None].double()
+    got = o.view().double()
+    err = (got - y).abs().max().item()
+    assert err <= 2e-4, err                                                  # dropped lo*lo term + fp32 accumulation of 2560 products
+
+
+def test_resconv5_full_size_equals_gemm():
+    """BASELINE config 2 row space (64 x 802 rows), both operand formats, the automatic two-class schedule"""
+    for split in (1, 2):
+        Case(64, 800, split, seed=11).check("planes")
+
+
+def test_gemm_writes_the_remainder_plane():
+    """efts_gemm(out_bf16_lo): hi + lo planes of a split-1 output rebuild the fp32 result to 16 mantissa bits"""
+    from efficient_tts_amd import lib as L, ops as P
+    c = Case(2, 50, 1, seed=5)
+    dev = _dev()
+    rs = c.rs
+    o, y, yl = P.F32Rows(rs, C, dev), P.Plane.for_rows(rs, C, 1, dev), P.Plane.for_rows(rs, C, 1, dev)
+    P.gemm(a=c.a, b_ptr=c.pw.ptr, ldb=c.pw.ld, b_tap_stride=c.pw.tap_stride, taps=5, m=rs.rows, n=C, act=L.ACT_LEAKY, slope=0.1,
+           bias=c.bias, resid_ptr=c.xf.ptr, ldr=C, rowmask_ptr=c.mask.data_ptr(), out_f32_ptr=o.ptr, ldo=C, out_plane=y, out_plane_lo=yl)
+    torch.cuda.synchronize()
+    rh, rl = bf16_split(o.buf)
+    assert torch.equal(y.buf.view(torch.bfloat16).view(rs.alloc, -1)[:, :C], rh)
+    assert torch.equal(yl.buf.view(torch.bfloat16).view(rs.alloc, -1)[:, :C], rl)
