@@ -45,7 +45,10 @@ def parse():
     ap.add_argument("--side-stream", type=int, default=1, help="0: text-length work on the main stream (A/B)")
     ap.add_argument("--resconv", type=int, default=1, help="0: residual stacks on efts_gemm + fp32 stream (A/B)")
     ap.add_argument("--resconv-min-rows", type=int, default=-1, help="A/B: row-space size from which the stacks run on efts_resconv5")
-    ap.add_argument("--graph", type=int, default=1, help="1 (default): replay the step from a captured hipGraph -- ~75 launches per forward are host-bound in eager mode (3.0 vs 2.6 ms); the roofline events then come from 3 eager steps right after the timed region. 0: eager, events inside the timed region")
+    ap.add_argument("--graph", type=int, default=0, help="forward workloads. 0 (default): the timed step is a plain model(...) call, as a drop-in caller issues it (the model replays a per-shape hipGraph internally); 1: a bench-level hipGraph of the eager launches")
+    ap.add_argument("--model-graphs", type=int, default=1, help="0 with --graph 0: the model's internal graph cache off = every kernel launched eagerly")
+    ap.add_argument("--parity-mode", type=int, default=1, help="forward workloads in bf16: also time the bf16x3 parity-grade mode (same K / W) -> `parity_mode` in the JSON line")
+    ap.add_argument("--call-modes", type=int, default=1, help="forward workloads, N=1: 10 extra steps per call mode (plain call / bench graph / eager) -> `call_modes`")
     return ap.parse_args()
 
 
@@ -106,6 +109,7 @@ def cpu_baseline(T1, T2, hip_check=None):
         got = hip_check(P, text[:2], tl[:2], mel[:2], sl[:2])
         res["hip_vs_oracle_mel_max_abs"] = float((got.detach().cpu() - ref["mel_pred"]).abs().max())
         res["hip_vs_oracle_note"] = "same parameters and inputs (2 items, full length); north_star tolerance 1e-3 applies to the bf16x3 mode"
+        res["_ref_mel"] = ref["mel_pred"]
     return res
 
 
@@ -390,106 +394,166 @@ def main():
         from efficient_tts_amd.bench_train import run_train      # DP training step (config 3/4)
         return run_train(a, world, rank, dev, wl)
 
-    torch.manual_seed(0)
-    model = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, use_weighted_masking=False,
-                            sigma=0.01, precision=a.precision).to(dev).eval()
-    text, tl, mel, sl = synth(B, T1, T2, 1234 + rank, dev)
-    model.side_stream, model.resconv = bool(a.side_stream), bool(a.resconv)
-    if a.resconv_min_rows >= 0:
-        model.RESCONV_MIN_ROWS = a.resconv_min_rows
+    return run_forward(a, world, rank, dev, wl)
 
-    def step():
-        with torch.no_grad():
-            return model(text, tl, mel, sl)
 
-    graph = None
-    for _ in range(max(a.warmup, 2) if a.graph else a.warmup):
-        out = step()
+def conv_roofline(P, model, step, B, T2, precision, workload):
+    """The dominant kernel (k5 residual Conv1d 512 -> 512 at mel length): per-launch duration from HIP events recorded
+    on the launch stream around every such launch of 3 EAGER steps (graphs off), against the dense bf16 MFMA peak."""
+    rows = P.Rows(B, T2).rows
+    keep = model.graphs
+    model.graphs = False
+    step()                                                       # first eager step after graph replays: not measured
     torch.cuda.synchronize()
-    if a.graph:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = step()
-        graph.replay()
-        torch.cuda.synchronize()
+    P.PROFILE, P.PROFILE_TAG = [], (5, rows, 512)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in P.PROFILE if tag == (5, rows, 512)]
+    P.PROFILE, P.PROFILE_TAG = None, None
+    model.graphs = keep
+    avg = sum(durs) / max(len(durs), 1)
+    flop = 2.0 * B * T2 * 512 * 512 * 5
+    # algorithmic bytes per launch (DESIGN.md section 4): per element of the [rows, 512] stream 2 B hi + 2 B lo read, 4 B hi + lo
+    # written (bf16x3: one 4 B hi|lo chunk read, one written), plus the weight plane once
+    alg_bytes = rows * 512 * 8 + 5 * 512 * 512 * (2 if model.split == 1 else 4)
+    traffic, src = None, None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get(f"{precision}:{workload}")
+            src = "profiles/traffic.json (rocprofv3 PMC passes of this workload: 2 * FETCH_SIZE + WRITE_SIZE per launch; not measured in this run)"
+        except Exception:
+            traffic = None
+    return dict(bound="mfma", kernel=f"resconv5_kernel<split={model.split}> (efts_resconv5: persistent 8-wave workgroups, 256-column tiles, hi/lo bf16 stream): "
+                                      f"k5 Conv1d 512->512, {B}x{T2} frames",
+                achieved=flop / avg / 1e12, peak=PEAK_MFMA_BF16_TFLOPS, unit="TFLOP/s", frac=flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS,
+                traffic=traffic, traffic_source=src, avg_launch_us=avg * 1e6, launches_measured=len(durs),
+                algorithmic_flop_per_launch=flop, algorithmic_bytes_per_launch=alg_bytes,
+                hbm_frac_algorithmic=alg_bytes / avg / 1e9 / PEAK_HBM_GBS,
+                mfma_issue_frac=(3 if model.split == 2 else 1) * flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS)
+
+
+def run_forward(a, world, rank, dev, wl):
+    """BASELINE config 2 (fwd64) / config 5 (fwd16_long): the teacher-forced forward.  The timed step is a PLAIN
+    `model(text, tl, mel, sl)` call -- what a drop-in caller of the reference class executes; the model replays a per-shape
+    hipGraph internally (efficient_tts_amd/graphs.py).  --graph 1 times a bench-level graph of the eager launches instead."""
+    from efficient_tts_amd import EfficientTTSCNN, ops as P
+    B, T1, T2 = wl["B"], wl["T1"], wl["T2"]
+    text, tl, mel, sl = synth(B, T1, T2, 1234 + rank, dev)
+
+    def build(precision, params=None):
+        torch.manual_seed(0)
+        m = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, use_weighted_masking=False, sigma=0.01, precision=precision)
+        if params is not None:
+            m.load_state_dict(params)
+        m = m.to(dev).eval()
+        m.side_stream, m.resconv = bool(a.side_stream), bool(a.resconv)
+        if a.resconv_min_rows >= 0:
+            m.RESCONV_MIN_ROWS = a.resconv_min_rows
+        return m
 
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
 
-    # ---- timed region: exactly K steps, barrier + synchronize on both sides.  In eager mode every
-    # efts_gemm launch of the timed steps is bracketed by HIP events on its stream (roofline below).
-    rows_conv = P.Rows(B, T2).rows
-    if graph is None:
-        P.PROFILE, P.PROFILE_TAG = [], (5, rows_conv, 512)    # only the dominant kernel's launches
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        if graph is not None:
-            graph.replay()
-        else:
-            step()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    loss = float(out[0])
-    assert loss == loss, "NaN loss"
+    def timed(model, steps, warmup, mode):
+        """mode: 'call' plain model() calls; 'graph' a bench-level hipGraph of the eager launches; 'eager' graphs off"""
+        keep = model.graphs
+        model.graphs = mode == "call"
 
-    # ---- dominant kernel: per-launch duration from the HIP events of the timed region (eager), or
-    # from 3 extra eager steps right after it when the timed region replayed a hipGraph.
-    if graph is not None:
-        P.PROFILE, P.PROFILE_TAG = [], (5, rows_conv, 512)
-        for _ in range(3):
-            step()
+        def step():
+            with torch.no_grad():
+                return model(text, tl, mel, sl)
+        graph = None
+        for _ in range(max(warmup, 2)):
+            out = step()
         torch.cuda.synchronize()
-    durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in P.PROFILE if tag == (5, rows_conv, 512)]
-    P.PROFILE, P.PROFILE_TAG = None, None
-    n_launch = len(durs)
-    avg = sum(durs) / max(n_launch, 1)
-    conv_flop = 2.0 * B * T2 * 512 * 512 * 5
-    conv_bytes_alg = B * T2 * 512 * (2 + 4 + 4 + 2) + 512 * 512 * 5 * 2      # A bf16 + resid + out f32 + out bf16 + W
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tf):
-        try:
-            traffic = json.load(open(tf)).get(f"{a.precision}:{a.workload}")
-        except Exception:
-            traffic = None
-    kname = f"resconv5_kernel<split={model.split}> (persistent, 256-column tiles)"
-    roof = dict(bound="mfma", kernel=f"{kname}: k5 Conv1d 512->512, {B}x{T2} frames",
-                achieved=conv_flop / avg / 1e12, peak=PEAK_MFMA_BF16_TFLOPS, unit="TFLOP/s",
-                frac=conv_flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS, traffic=traffic,
-                avg_launch_us=avg * 1e6, launches_measured=n_launch, algorithmic_flop_per_launch=conv_flop,
-                hbm_frac_algorithmic=conv_bytes_alg / avg / 1e9 / PEAK_HBM_GBS,
-                mfma_issue_frac=(3 if model.split == 2 else 1) * conv_flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS)
+        if mode == "graph":
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = step()
+            graph.replay()
+            torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            if graph is not None:
+                graph.replay()
+            else:
+                out = step()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        model.graphs = keep
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        loss = float(out[0])
+        assert loss == loss, "NaN loss"
+        return dt, loss, step
 
+    model = build(a.precision)
+    mode = "graph" if a.graph == 1 else ("call" if a.model_graphs else "eager")
+    dt, loss, step = timed(model, a.steps, a.warmup, mode)               # ---- THE timed region: exactly K steps
+    roof = conv_roofline(P, model, step, B, T2, a.precision, a.workload)
+
+    def line(precision, dt, steps):
+        frames = world * B * T2 * steps
+        return dict(value=frames / dt, ms_per_step=dt / steps * 1e3, per_gpu=frames / dt / world,
+                    rtf=(dt / steps) / (B * T2 * 256 / 22050.0),
+                    tflops=FWD_FLOP_PER_ITEM * B * T2 / 800 * world * steps / dt / 1e12 if (T1, T2) == (128, 800) else None)
+
+    res = None
     if rank == 0:
-        frames = world * B * T2 * a.steps
-        res = dict(metric=f"mel-frames/sec (EFTS-CNN forward, batch {B}/GPU, 80-mel LJSpeech shape)", value=frames / dt,
-                   unit="mel-frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
-                   higher_is_better=True, scaling="weak", vs_baseline=None,
-                   dtype="bf16" if a.precision == "bf16" else "bf16x3 (split-bf16 MFMA, fp32-class)",
-                   data="synthetic", config=dict(workload=wl["desc"], batch_per_gpu=B, phoneme_len=T1, mel_len=T2,
-                                                 precision=a.precision, parallelism=f"replicas x{world}", hipgraph=bool(graph)),
-                   per_gpu=frames / dt / world, rtf=(dt / a.steps) / (B * T2 * 256 / 22050.0),
-                   tflops=FWD_FLOP_PER_ITEM * B * T2 / 800 * world * a.steps / dt / 1e12 if (T1, T2) == (128, 800) else None,
+        res = dict(metric=f"mel-frames/sec (EFTS-CNN forward, batch {B}/GPU, 80-mel LJSpeech shape)", unit="mel-frames/s", n_gpus=world,
+                   steps=a.steps, warmup=a.warmup, higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="bf16" if a.precision == "bf16" else "bf16x3 (split-bf16 MFMA, fp32-class)", data="synthetic",
+                   config=dict(workload=wl["desc"], batch_per_gpu=B, phoneme_len=T1, mel_len=T2, precision=a.precision,
+                               parallelism=f"replicas x{world}",
+                               hipgraph={"graph": "bench-level hipGraph of the eager launches", "call": "plain model() calls (per-shape hipGraph cache inside the model)",
+                                         "eager": "none: every kernel launched from the host"}[mode]),
                    loss=loss, roofline=roof)
+        res.update(line(a.precision, dt, a.steps))
+    # ---- the parity-grade mode under the same clock: bf16x3 (mel max-abs <= 1e-3 vs the fp32 oracle), same K / W, same inputs
+    parity_model = None
+    if a.precision == "bf16" and a.parity_mode:
+        parity_model = build("bf16x3", {k: v.detach() for k, v in model.state_dict().items()})
+        dt2, loss2, step2 = timed(parity_model, a.steps, a.warmup, mode)
+        roof2 = conv_roofline(P, parity_model, step2, B, T2, "bf16x3", a.workload)
+        if rank == 0:
+            res["parity_mode"] = dict(precision="bf16x3", dtype="bf16x3 (split-bf16 MFMA operands: hi*hi + hi*lo + lo*hi, fp32 accumulate)",
+                                      steps=a.steps, warmup=a.warmup, loss=loss2, roofline=roof2, **line("bf16x3", dt2, a.steps))
+    if rank == 0 and world == 1 and a.call_modes:
+        cm = {}
+        for md in ("call", "graph", "eager"):
+            d, _, _ = timed(model, 10, 2, md)
+            cm[md + "_ms"] = d / 10 * 1e3
+        res["call_modes"] = dict(cm, note="10 steps each after the timed region: plain model() call (internal per-shape hipGraph) / bench-level hipGraph / eager launches")
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
+            checks = {}
+
             def hip_check(Pd, text_c, tl_c, mel_c, sl_c):
-                m2 = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, use_weighted_masking=False,
-                                     sigma=0.01, precision=a.precision)
-                m2.load_state_dict(Pd)
-                m2 = m2.to(dev).eval()
-                with torch.no_grad():
-                    return m2(text_c.to(dev), tl_c.to(dev), mel_c.to(dev), sl_c.to(dev))[4]
+                out = None
+                for prec in ("bf16", "bf16x3"):
+                    m2 = build(prec, Pd)
+                    with torch.no_grad():
+                        checks[prec] = m2(text_c.to(dev), tl_c.to(dev), mel_c.to(dev), sl_c.to(dev))[4].detach().cpu()
+                    if prec == a.precision:
+                        out = checks[prec]
+                return out
             res["cpu_baseline"] = cpu_baseline(T1, T2, hip_check)
+            ref = res["cpu_baseline"].pop("_ref_mel", None)
+            if ref is not None and "parity_mode" in res:
+                res["parity_mode"]["hip_vs_oracle_mel_max_abs"] = float((checks["bf16x3"] - ref).abs().max())
+                res["parity_mode"]["tolerance"] = 1e-3
+            if ref is not None:
+                res["hip_vs_oracle_mel_max_abs"] = float((checks[a.precision] - ref).abs().max())
         print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist

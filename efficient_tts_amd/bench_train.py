@@ -11,6 +11,40 @@ import torch
 TRAIN_FLOP_PER_ITEM = 3 * 21.43e9
 
 
+def cpu_train_baseline(T1, T2):
+    """the oracle (CPU restatement of the reference path, torch autograd for the backward)
+    timed on this box's host cores for one training step -- fwd + bwd + clip 1.0 + Adam-amsgrad -- on a bounded sample
+    (B=4 full-length items instead of 32)."""
+    import time as _t
+    from oracle import efts_oracle as O          # the cpu_baseline leg: oracle as the thing timed
+    cores = os.cpu_count() or 1
+    nt = min(cores, 16)
+    torch.set_num_threads(nt)
+    P = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in O.fill_params().items()}
+    params = [v for v in P.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.99), eps=1e-9, weight_decay=1e-5, amsgrad=True)
+    Bc = 4
+    g = torch.Generator().manual_seed(1234)
+    text = torch.randint(0, 76, (Bc, T1), generator=g)
+    mel = torch.randn(Bc, T2, 80, generator=g)
+    tl = torch.full((Bc,), T1, dtype=torch.int64)
+    sl = torch.full((Bc,), T2, dtype=torch.int64)
+    times = []
+    for it in range(4):
+        t0 = _t.perf_counter()
+        out = O.forward(P, text, tl, mel, sl)
+        opt.zero_grad()
+        out["loss"].backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        if it:
+            times.append(_t.perf_counter() - t0)
+    med = sorted(times)[1]
+    return dict(value=Bc * T2 / med, unit="mel-frames/s", cores=nt, host_cpus=cores, kind="port",
+                sample=f"oracle training step fp32 (forward, autograd backward, clip 1.0, torch Adam-amsgrad), B={Bc} x (T1={T1}, T2={T2}), "
+                       f"median of 3 after 1 warm-up ({med:.3f} s/step at {nt} threads)")
+
+
 def run_train(a, world, rank, dev, wl):
     import torch.distributed as dist
     from . import EfficientTTSCNN, ops as P
@@ -68,6 +102,7 @@ def run_train(a, world, rank, dev, wl):
     split = model.split
     big = split == 1 and ((rows + 251) // 252) * 4 >= 400           # efts_gemm's own rule for the 256-row kernel
     kname = "conv5_kernel<split=1> (256-row tiles)" if big else f"gemm_kernel<taps=5,split={split}> (124-row tiles)"
+    cpu = cpu_train_baseline(T1, T2) if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None
     if rank == 0:
         frames = world * B * T2 * a.steps
         res = dict(metric="mel-frames/sec (EFTS-CNN training step, batch 32/GPU, 80-mel LJSpeech shape)", value=frames / dt,
@@ -82,6 +117,8 @@ def run_train(a, world, rank, dev, wl):
                                  achieved=conv_flop / avg / 1e12 if avg else None, peak=2500.0, unit="TFLOP/s",
                                  frac=conv_flop / avg / 1e12 / 2500.0 if avg else None, traffic=None,
                                  avg_launch_us=avg * 1e6, launches_measured=len(durs)))
+        if cpu is not None:
+            res["cpu_baseline"] = cpu
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -17,6 +17,7 @@ import torch
 
 from . import lib as L
 from . import ops as O
+from .graphs import GraphCache
 from .ops import F32Rows, PackedWeight, Plane, Rows
 
 
@@ -90,9 +91,13 @@ class _Workspace:
     """Named device buffers for one (B, T1, T2) shape; zero-initialised once, so guard and gap
     rows stay zero (kernels never write them with non-zero values)."""
 
+    _serial = 0
+
     def __init__(self, device):
         self.device = device
         self.bufs: Dict[str, object] = {}
+        _Workspace._serial += 1
+        self.serial = _Workspace._serial          # identifies the allocation: captured graphs point into these buffers
 
     def f32(self, name: str, rs: Rows, c: int) -> F32Rows:
         key = ("f", name, rs.B, rs.T, c)
@@ -180,11 +185,14 @@ class EfficientTTSCNN(torch.nn.Module):
         self.decoder = _ResConvBlock(n_decoder_layer, n_channels, k_size, a, ap, dropout_rate, use_weight_norm)
         self.mel_output_layer = torch.nn.Linear(n_channels, odim)
         self.duration_predictor = _DurationPredictor(n_channels, n_duration_layer, n_channels, offset=duration_offset)
+        self.graphs = True                  # plain eval calls replay a per-shape hipGraph (False: every kernel launched eagerly)
+        self._graph_cache = GraphCache()
         self.side_stream = True             # text-length work on a second HIP stream beside the mel-length kernels
         self.resconv = True                 # long row spaces: residual stacks on efts_resconv5 (False: efts_gemm + fp32 stream, A/B and tests)
         self.dropout_seed = 0x5EED          # base seed of the duration predictor's dropout masks (train mode)
         self._packed: Dict[str, PackedWeight] = {}
         self._packed_sig = None
+        self._ptr_sig = 0
         self._packed_gen = 0                # bumped by every repack: what derived caches (TrainEngine) compare
         self._folded_gen = -1               # the repack that last wrote the training engine's folded fp32 copies
         self._ws: Dict[Tuple, _Workspace] = {}
@@ -225,6 +233,7 @@ class EfficientTTSCNN(torch.nn.Module):
         sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if sig == self._packed_sig:
             return self._packed
+        self._ptr_sig = hash(tuple(a for a, _ in sig))       # parameter storage identity (captured graphs hold these pointers)
         dev = self.text_embedding_table.weight.device
         pk = self._packed
         folded = folded or {}
@@ -408,7 +417,22 @@ class EfficientTTSCNN(torch.nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from .autograd import training_forward
             return training_forward(self, text, text_lengths, speech, speech_lengths)
-        return self._forward_impl(text, text_lengths, speech, speech_lengths)[0]
+        if not self.graphs or torch.cuda.is_current_stream_capturing():
+            return self._forward_impl(text, text_lengths, speech, speech_lengths)[0]
+        # per-shape hipGraph: the launches of this shape are replayed as one graph (efficient_tts_amd/graphs.py)
+        pk = self._weights()                                  # (re)packing stays outside the graph
+        dev = text.device
+        key = ("fwd", tuple(text.shape), tuple(speech.shape), text.dtype, speech.dtype, text_lengths.dtype, speech_lengths.dtype)
+        ws = self._workspace(("fwd", text.shape[0], text.shape[1], speech.shape[1]), dev)
+        # the graph is valid while the buffers its launches point at live: this workspace, the packed planes, the parameters
+        tag = (ws.serial, self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.side_stream, self.RESCONV_MIN_ROWS)
+
+        def body(t, tl, sp, sl):
+            (_, stats, imv, ralpha, mel_pred, _), _ = self._forward_impl(t, tl, sp, sl)
+            return stats._t, imv, ralpha, mel_pred
+
+        out3, imv, ralpha, mel_pred = self._graph_cache.run(key, tag, (text, text_lengths.to(dev), speech, speech_lengths.to(dev)), body, keepalive=ws)
+        return out3[0], LazyStats(out3), imv, ralpha, mel_pred, speech
 
     def _forward_impl(self, text, text_lengths, speech, speech_lengths, keep: bool = False):
         with O.stream_scope():
