@@ -14,6 +14,11 @@ from .train import TrainEngine
 def engine_of(model) -> TrainEngine:
     eng = getattr(model, "_engine", None)
     if eng is None or eng.dev != next(model.parameters()).device or eng.stale(model):
+        if eng is not None and getattr(eng, "bound", None):
+            # a fused optimizer / bucket reducer holds the OLD engine's flat gradient buffer: rebuilding silently would
+            # leave it stepping on an orphaned zero gradient
+            raise RuntimeError("the model's parameters changed identity (weight norm applied / removed, .to(), new parameters) after "
+                               f"{', '.join(eng.bound)} was bound to its training engine: rebuild the optimizer / DistributedEFTS wrapper")
         eng = TrainEngine(model)
         object.__setattr__(model, "_engine", eng)
     return eng

@@ -56,6 +56,7 @@ class DistributedEFTS(torch.nn.Module):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         from .autograd import engine_of
         self.engine = engine_of(module)
+        self.engine.bound.add("DistributedEFTS")
         self.reducer: Optional[BucketReducer] = None
         if self.world > 1:
             self.reducer = BucketReducer(self.engine.flat, self.engine.bucket_ends, group)

@@ -77,6 +77,15 @@ class LazyStats(dict):
     def __getitem__(self, k):
         return self._vals()[k]
 
+    def get(self, k, default=None):
+        return self._vals().get(k, default)
+
+    def __iter__(self):
+        return iter(("loss", "mel_loss", "duration_loss"))
+
+    def keys(self):
+        return self._vals().keys()
+
     def items(self):
         return self._vals().items()
 
@@ -413,8 +422,15 @@ class EfficientTTSCNN(torch.nn.Module):
                 speech_lengths: torch.Tensor):
         """Teacher-forced forward.  Returns (loss, stats, imv[B,T2], reconst_alpha[B,T1,T2],
         mel_pred[B,T2,odim], speech) exactly like the reference (:228)."""
+        training_path = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if training_path and self.training and self.dropout_rate >= 1e-5:
+            # ResConv1d's Dropout (nntts/layers/efts_modules.py:38-47) and the prenet's (efficient_tts.py:76-80) are not part of
+            # the HIP training path (the shipped recipe trains with dropout_rate 0.0): refuse instead of training another model
+            raise NotImplementedError(f"dropout_rate={self.dropout_rate} in train() mode: the HIP training step implements the conv / "
+                                      "prenet Dropout only for dropout_rate 0.0 (egs/lj/conf/efficient_tts_cnn_phnseq_noDropout.v1.yaml); "
+                                      "construct the model with dropout_rate=0.0 or call eval()")
         self._require(text)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if training_path:
             from .autograd import training_forward
             return training_forward(self, text, text_lengths, speech, speech_lengths)
         if not self.graphs or torch.cuda.is_current_stream_capturing():

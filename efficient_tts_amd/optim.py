@@ -24,6 +24,7 @@ class EftsAdam(torch.optim.Optimizer):
         self.model = model
         self.eng = engine_of(model)
         eng = self.eng
+        eng.bound.add("EftsAdam")
         self.grad_norm = float(grad_norm)
         dev = eng.dev
         # re-home parameters into one flat buffer (engine layout)

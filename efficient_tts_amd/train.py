@@ -98,6 +98,7 @@ class TrainEngine:
         self._ws_tag = ""                       # "s" while work is being enqueued on the side stream
         self.bucket_hook: Optional[Callable[[int], None]] = None
         self.join_reduce: Optional[Callable[[], None]] = None
+        self.bound = set()                      # who holds views of `flat` (EftsAdam, DistributedEFTS): see autograd.engine_of
 
     def stale(self, model) -> bool:
         """True when the model's parameter set no longer matches the layout captured at construction

@@ -143,7 +143,8 @@ class EfficientTTSTrainer:
     def _train_step(self, batch) -> None:
         text, text_lengths, mel, mel_lengths = self._stage(batch)
         loss, stats, *_ = self.model(text=text, text_lengths=text_lengths, speech=mel, speech_lengths=mel_lengths)
-        self._unread.append(stats)
+        if int(self.config.get("rank", 0)) == 0:
+            self._unread.append(stats)                          # drained by _after_step, which only rank 0 runs
         self.optimizer.zero_grad()
         loss.backward()
         if hasattr(self.model, "finish_reduce"):

@@ -72,3 +72,24 @@ def test_model_fails_loudly_without_gpu():
     m = EfficientTTSCNN(num_symbols=76, use_masking=True)
     with pytest.raises(Exception):
         m.inference(torch.zeros(1, 8, dtype=torch.long))
+
+
+def test_conv_dropout_in_train_mode_is_refused_not_ignored():
+    """The reference applies Dropout inside ResConv1d and the prenet for dropout_rate > 0 (ctor default 0.1,
+    nntts/layers/efts_modules.py:38-47, efficient_tts.py:76-80); the HIP training step does not, so it must raise instead of
+    silently training a different model (eval() and dropout_rate=0.0 are fine)."""
+    import torch
+    from efficient_tts_amd import EfficientTTSCNN
+    m = EfficientTTSCNN(num_symbols=76, use_masking=True)                # dropout_rate = 0.1, train() mode
+    t = torch.zeros(1, 8, dtype=torch.long)
+    with pytest.raises(NotImplementedError, match="dropout_rate"):
+        m(t, torch.tensor([8]), torch.zeros(1, 16, 80), torch.tensor([16]))
+
+
+def test_lazy_stats_behaves_like_a_dict():
+    import torch
+    from efficient_tts_amd.model import LazyStats
+    s = LazyStats(torch.tensor([3.0, 2.0, 1.0]))
+    assert s["loss"] == 3.0 and s.get("mel_loss") == 2.0 and s.get("nope", 7) == 7
+    assert dict(s) == dict(loss=3.0, mel_loss=2.0, duration_loss=1.0)
+    assert list(s.keys()) == ["loss", "mel_loss", "duration_loss"] and sorted(s.values()) == [1.0, 2.0, 3.0]
