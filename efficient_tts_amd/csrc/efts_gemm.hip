@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
             v.z = (v.z + __uint_as_float(x.z)) * rm; v.w = (v.w + __uint_as_float(x.w)) * rm;
             if (of) {
                 const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-                __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo, ps * so, EFTS_AUX_STF);
+                { __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo, ps * so, EFTS_AUX_STF); asm volatile("s_nop 4" ::"v"(o)); }
             }
             if (ob) {
                 if (p.plane_act) {
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256, 2) void narrow_kernel(GemmKernelArgs p) {
             v.z = (v.z + __uint_as_float(x.z)) * rm; v.w = (v.w + __uint_as_float(x.w)) * rm;
             if (of) {
                 const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-                __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo, ps * so, EFTS_AUX_STF);
+                { __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo, ps * so, EFTS_AUX_STF); asm volatile("s_nop 4" ::"v"(o)); }
             }
             if (ob) {
                 if (p.plane_act) {
@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(256, 2) void conv5_kernel(GemmKernelArgs p) {
                 v.z = (v.z + __uint_as_float(x.z)) * rm; v.w = (v.w + __uint_as_float(x.w)) * rm;
                 if (of) {
                     const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-                    __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo, row_of(ep, ps) * (unsigned)p.ldo * 4, EFTS_AUX_STF);
+                    { __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo, row_of(ep, ps) * (unsigned)p.ldo * 4, EFTS_AUX_STF); asm volatile("s_nop 4" ::"v"(o)); }
                 }
                 if (ob) {
                     float r0, r1, r2, r3;
@@ -1213,7 +1213,7 @@ __global__ __launch_bounds__(256, 2) void resident32_kernel(GemmKernelArgs p) {
             v.z = (v.z + __uint_as_float(x.z)) * rm; v.w = (v.w + __uint_as_float(x.w)) * rm;
             if (of) {
                 const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-                __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo, ps * so, EFTS_AUX_STF);
+                { __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo, ps * so, EFTS_AUX_STF); asm volatile("s_nop 4" ::"v"(o)); }
             }
             if (ob) {
                 if (p.plane_act) {
@@ -1440,7 +1440,7 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(GemmKernelArgs p) {
             v.z = (v.z + __uint_as_float(x.z)) * rm; v.w = (v.w + __uint_as_float(x.w)) * rm;
             if (of) {
                 const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-                __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo, ps * 16 * (unsigned)p.ldo * 4, EFTS_AUX_STF);
+                { __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo, ps * 16 * (unsigned)p.ldo * 4, EFTS_AUX_STF); asm volatile("s_nop 4" ::"v"(o)); }
             }
             if (ob) {
                 float r0, r1, r2, r3;

@@ -31,7 +31,10 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
 // One LDS-DMA piece = one wave instruction = 8 tile rows x 128 B.  Lane l lands at LDS
 // m0 + 16*l, i.e. tile row 8*piece + l/8, physical slot l%8; its source is sbase + voff.
 __device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, const char* sbase) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase)
+    // s_nop 4 first: hipcc does not pad hazards across an asm boundary, and `sbase` (or `voff`) may have been written by a VALU
+    // instruction (v_readlane of a spilled SGPR, v_readfirstlane) right before this statement; a VMEM instruction reading
+    // an SGPR a VALU just wrote needs 5 wait states (cdna_hip_programming.md 5.7 item 2)
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase)
                  : "memory");
 }
 
@@ -55,6 +58,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long 
     const unsigned n = bytes <= 0 ? 0u : (bytes > 0xffffffffL ? 0xffffffffu : (unsigned)bytes);
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, n, 0x00020000);
 }
+// 16-byte buffer store whose data registers stay untouched for a few more issue slots.  hipcc pads a VALU write to the data
+// VGPRs of a dwordx4 store with `s_nop 1`; on gfx950 that was observed NOT to be enough: with the register file full the
+// compiler re-used data register 0 for the next store's address (v_add right behind the s_nop), and lanes 12-15 of every
+// 16-lane group stored the address instead of the value (tests/test_resconv_gpu.py caught it as 1e-40-sized outputs).
+// Naming the data as an input of a trailing asm keeps it live -- and unmodified -- across 5 more wait states.
+__device__ __forceinline__ void store_b128(u32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+    asm volatile("s_nop 4" ::"v"(v));
+}
+
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b, float* ra, float* rb) {
     const unsigned short ha = f32_to_bf16(a), hb = f32_to_bf16(b);
     *ra = a - bf16_to_f32(ha);

@@ -29,18 +29,13 @@
 
 #include "efts_mma.h"
 
-// EFTS_LAB builds only: RC_EXP ablation bits (1 no LDS-DMA in the loop, 2 no counted waits, 4 no MFMA + fragment reads,
-// 8 no epilogue loads / stores, 16 no epilogue at all, 32 no step barriers)
+// lab builds only (-DRC_EXP=...): ablation bits 1 no LDS-DMA in the loop, 4 no MFMA + fragment reads, 8 no epilogue loads / stores,
+// 16 no epilogue at all.  RC_ILV 0: the step's weight pieces go out as a burst at step start (A/B of the interleave).
 #ifndef RC_EXP
 #define RC_EXP 0
 #endif
-// tunables (A/B'd on the GPU): epilogue operand prefetch depth in passes; LDS-DMA issue staggered between
-// the two waves of a SIMD; s_setprio around the MFMA clusters
-#ifndef RC_PF
-#define RC_PF 1
-#endif
-#ifndef RC_STAGGER
-#define RC_STAGGER 0
+#ifndef RC_ILV
+#define RC_ILV 1
 #endif
 #ifndef RC_PRIO
 #define RC_PRIO 0
@@ -115,31 +110,35 @@ __device__ __forceinline__ void rc_window_offsets(const RcArgs& p, const RcCtx& 
     }
 }
 
-// One (64 * NI) x 256 tile at output row m0: main loop over (chunk, tap) steps, then the fused epilogue.  On entry the
-// window of chunk 0 and the weights of steps 0 and 1 are in flight (or landed); before its epilogue the tile issues
-// the same for the next tile (rows m1, height ni1; ni1 == 0: none).
+// One (64 * NI) x 256 tile at output row m0: main loop over (chunk, tap) steps, then the fused epilogue.
+// The operand streams are CONTINUOUS across the tiles of a workgroup: its weights do not depend on the tile (n0 is fixed), so
+// the weight requests two steps ahead simply wrap into the next tile's steps 0 and 1, and the next tile's first window
+// (rows m1, height ni1; 0 = no next tile) is requested at the first tap of this tile's last chunk.  On entry the window of
+// chunk 0 and the weights of steps 0 and 1 are therefore in flight or landed.
 template <int SPLIT, int NI>
 __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int rows_out, int m1, int ni1) {
     constexpr int TAPS = 5;
-    const int nsteps = p.nchunk * TAPS;
     char* const smem = c.smem;
     const int lane = c.lane, wave = c.wave, lrow = c.lrow, lhalf = c.lhalf, wm = c.wm, wn = c.wn;
 
     unsigned voa[NI];
     rc_window_offsets<NI>(p, c, m0, voa);
     const char* a_base = p.a + (long)(m0 - 2) * p.lda;
-    auto issue_w = [&](int cn, int kn, int slot) {
-        const char* sb = (RC_EXP & 64) ? p.w + (((long)kn * p.nchunk + cn) * p.ntn + c.n0 / RC_BN) * RC_W_BYTES    // timing only: tile-contiguous weights
-                                       : c.w_base + (long)kn * p.w_tap_stride + (long)cn * 128;
-        const unsigned l = c.lds0 + RC_RING + slot * RC_W_BYTES + wave * 1024;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dma16(l + q * 8192, c.vow[q], sb);
-    };
     auto issue_a = [&](int cn, int buf) {
         const char* sb = a_base + (long)cn * 128;
         const unsigned l = c.lds0 + buf * RC_WIN_BYTES + wave * 1024;
 #pragma unroll
         for (int q = 0; q < NI; ++q) dma16(l + q * 8192, voa[q], sb);
+    };
+    auto issue_a_next = [&](int buf) {                     // chunk 0 of the next tile (its own height and rows)
+        const int rmax = p.m + 143 - (m1 - 2);
+        const char* sb = p.a + (long)(m1 - 2) * p.lda;
+        const unsigned l = c.lds0 + buf * RC_WIN_BYTES + wave * 1024;
+        for (int q = 0; q < ni1; ++q) {
+            const int r = (q * 8 + wave) * 8 + (lane >> 3);
+            const int sl = (lane & 7) ^ ((r >> 1) & 7);
+            dma16(l + q * 8192, (unsigned)((r < rmax ? r : rmax) * (int)p.lda + (sl << 4)), sb);
+        }
     };
 
     f32x16 acc[NI][2];
@@ -150,9 +149,9 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // `mid`: called once in the middle of the step's MFMAs (the second wave of every SIMD issues its LDS-DMA there, so the
-    // two waves of a SIMD do not stall on DMA issue at the same moment)
-    auto compute = [&](int wbuf, int slot, int k, auto&& mid) {
+    // MFMAs of one (chunk, tap) step.  `hook(g)`, g = 0..3, runs between the MFMA groups: the step's four weight pieces
+    // are issued there one at a time, in the shadow of the MFMAs already queued, instead of as a burst that idles the pipe
+    auto compute = [&](int wbuf, int slot, int k, auto&& hook) {
         const char* at = smem + wbuf * RC_WIN_BYTES;
         const char* wt = smem + RC_RING + slot * RC_W_BYTES;
         const int arow = wm * (32 * NI) + lrow + k;
@@ -179,7 +178,8 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j], 0, 0, 0);
                 if (RC_PRIO) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk == 1) { mid(); __builtin_amdgcn_sched_barrier(0); }
+                hook(kk);
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
 #pragma unroll
@@ -200,59 +200,63 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
                         al[(i + 1) & 1] = *(const bf16x8*)(at + lds_off(arow + (i + 1) * 32, slot16 + 4));
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    if (RC_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i & 1], bh[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bl[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bh[j], acc[i][j], 0, 0, 0);
                     }
+                    if (RC_PRIO) __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (i == 0) hook(kk * 2);
+                    if (i == NI - 1) hook(kk * 2 + 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (kk == 0) { mid(); __builtin_amdgcn_sched_barrier(0); }
             }
         }
     };
 
-    // ---- the tile's first operands were requested earlier (kernel start / previous epilogue); nothing else is outstanding
+    // ---- the tile's first operands were requested earlier (kernel start / previous tile); the previous epilogue's loads
+    // and stores share the counter, so everything is waited for once here
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    int ch = 0, k = 0, ws = c.ws, c2 = 0, k2 = 2;
-    for (int s = 0; s < nsteps; ++s) {
-        const bool do_w = s + 2 < nsteps;
-        const bool do_a = (k == 0) && (ch + 1 < p.nchunk);
-        auto issue = [&]() {
-            if (do_w && !(RC_EXP & 1)) issue_w(c2, k2, ws == 0 ? 2 : ws - 1);             // weights two steps ahead, slot (ws + 2) % 3
-            if (do_a && !(RC_EXP & 1)) issue_a(ch + 1, (c.wpar + ch + 1) & 1);            // next chunk's window into the idle buffer
-        };
-        const bool late = RC_STAGGER && wm == 1;       // waves 4-7: the second wave of each SIMD
-        if (!late) issue();
-        if (!(RC_EXP & 4)) compute((c.wpar + ch) & 1, ws, k, [&]() { if (late) issue(); });
-        else if (late) issue();
-        // step end: the weights of step s+1 (issued one step ago) and anything older must have landed; LDS-DMA completes
-        // in issue order, so it is enough to bound what may still be in flight: this step's own requests
-        if (!(RC_EXP & 2)) rc_wait((do_w ? 4 : 0) + (do_a ? NI : 0));
-        if (!(RC_EXP & 32)) lds_barrier();
-        if (++k == TAPS) { k = 0; ++ch; }
-        if (++k2 == TAPS) { k2 = 0; ++c2; }
-        ws = (ws == 2) ? 0 : ws + 1;
+    int ws = c.ws;
+    for (int ch = 0; ch < p.nchunk; ++ch) {
+        const int wbuf = (c.wpar + ch) & 1;
+        const bool lastc = ch + 1 == p.nchunk;
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) {
+            // weights of the step two ahead -> ring slot (ws + 2) % 3, wrapping into the next tile at the end of this one
+            const int kn = (k + 2) % TAPS;
+            int cn = ch + (k + 2) / TAPS;
+            cn = cn == p.nchunk ? 0 : cn;
+            const char* wsrc = c.w_base + (long)kn * p.w_tap_stride + (long)cn * 128;
+            const unsigned wdst = c.lds0 + RC_RING + (ws == 0 ? 2 : ws - 1) * RC_W_BYTES + wave * 1024;
+            int nwin = 0;
+            if (k == 0 && !(RC_EXP & 1)) {                 // next window into the idle buffer: next chunk, or the next tile's chunk 0
+                if (!lastc) { issue_a(ch + 1, wbuf ^ 1); nwin = NI; }
+                else if (ni1 > 0) { issue_a_next(wbuf ^ 1); nwin = ni1; }
+            }
+            if (!RC_ILV && !(RC_EXP & 1)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dma16(wdst + q * 8192, c.vow[q], wsrc);
+            }
+            auto hook = [&](int g) { if (RC_ILV && !(RC_EXP & 1)) dma16(wdst + g * 8192, c.vow[g], wsrc); };
+            int kv = k;                                     // opaque: the taps' LDS addresses are recomputed per step, not hoisted
+            asm volatile("" : "+s"(kv));                    // out of the chunk loop into 5 x (NI + 2) live registers
+            if (!(RC_EXP & 4)) compute(wbuf, ws, kv, hook);
+            else { hook(0); hook(1); hook(2); hook(3); }
+            // step end: the weights of the next step (requested one step ago) and anything older must have landed; LDS-DMA
+            // completes in issue order, so it is enough to bound what may still be in flight: this step's own requests
+            if (RC_EXP & 1) rc_wait(0); else rc_wait(4 + nwin);
+            lds_barrier();
+            ws = (ws == 2) ? 0 : ws + 1;
+        }
     }
     c.ws = ws;
     c.wpar = (c.wpar + p.nchunk) & 1;
-
-    // ---- next tile's window 0 and weights of steps 0 / 1: every buffer they touch was last read before the final barrier
-    if (ni1 > 0) {
-        const int rmax = p.m + 143 - (m1 - 2);
-        const char* sb = p.a + (long)(m1 - 2) * p.lda;
-        const unsigned l = c.lds0 + c.wpar * RC_WIN_BYTES + wave * 1024;
-        for (int q = 0; q < ni1; ++q) {
-            const int r = (q * 8 + wave) * 8 + (lane >> 3);
-            const int sl = (lane & 7) ^ ((r >> 1) & 7);
-            dma16(l + q * 8192, (unsigned)((r < rmax ? r : rmax) * (int)p.lda + (sl << 4)), sb);
-        }
-        issue_w(0, 0, ws);
-        issue_w(0, 1, ws == 2 ? 0 : ws + 1);
-    }
 
     if (RC_EXP & 16) {
 #pragma unroll
@@ -289,7 +293,7 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
     const unsigned sob_row = (unsigned)p.ldob, sob_j = p.out_split == 1 ? 64u : 128u;
 
     // operands of pass (i, j), sweep it: 8 residual values (fp32, or bf16 hi + lo) and the row mask
-    constexpr int PF = RC_PF < NI * 2 ? RC_PF : NI * 2;      // passes in flight ahead of the one being written out
+    constexpr int PF = 1;                                    // passes in flight ahead of the one being written out (2, 3: no gain measured)
     u32x4 xa[PF + 1][2], xb[PF + 1][2];
     float rmv[PF + 1][2];
     auto request = [&](int i, int j, int b) {
@@ -299,13 +303,13 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
             if (RC_EXP & 8) { xa[b][it] = u32x4{0, 0, 0, 0}; xb[b][it] = xa[b][it]; }
             else if (res_f32) {
                 xa[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_x, vx, so, 0);
-                xb[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_x, vx + 16, so, 0);
+                xb[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_x, vx, so + 16, 0);
             } else if (SPLIT == 1) {
                 xa[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_a, vx, so, 0);
                 xb[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_al, vx, so, 0);      // null plane: zeros
             } else {
                 xa[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_a, vx, so, 0);
-                xb[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_a, vx + 64, so, 0);
+                xb[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_a, vx, so + 64, 0);
             }
             rmv[b][it] = has_mask ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_m, vm, (i * 32 + it * 16) * 4, 0)) : 1.f;
         }
@@ -355,8 +359,8 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
                 if (p.out_f32) {
                     const u32x4 o0 = {__float_as_uint(y[0]), __float_as_uint(y[1]), __float_as_uint(y[2]), __float_as_uint(y[3])};
                     const u32x4 o1 = {__float_as_uint(y[4]), __float_as_uint(y[5]), __float_as_uint(y[6]), __float_as_uint(y[7])};
-                    __builtin_amdgcn_raw_buffer_store_b128(o0, r_of, vof, brow * sof_row + j * 128, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(o1, r_of, vof + 16, brow * sof_row + j * 128, 0);
+                    store_b128(o0, r_of, vof, brow * sof_row + j * 128);             // constant displacements go into the scalar
+                    store_b128(o1, r_of, vof, brow * sof_row + j * 128 + 16);        // offset: no VALU address math between stores
                 }
                 if (p.ob) {
                     float rr[8];
@@ -366,9 +370,9 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
                     const u32x4 lo = {pack_bf16x2(rr[0], rr[1], &d0_, &d1_), pack_bf16x2(rr[2], rr[3], &d0_, &d1_),
                                       pack_bf16x2(rr[4], rr[5], &d0_, &d1_), pack_bf16x2(rr[6], rr[7], &d0_, &d1_)};
                     const unsigned so = brow * sob_row + j * sob_j;
-                    __builtin_amdgcn_raw_buffer_store_b128(hi, r_ob, vob, so, 0);
-                    if (p.out_split == 2) __builtin_amdgcn_raw_buffer_store_b128(lo, r_ob, vob + 64, so, 0);
-                    else if (p.ob_lo) __builtin_amdgcn_raw_buffer_store_b128(lo, r_ol, vob, so, 0);
+                    store_b128(hi, r_ob, vob, so);
+                    if (p.out_split == 2) store_b128(lo, r_ob, vob, so + 64);
+                    else if (p.ob_lo) store_b128(lo, r_ol, vob, so);
                 }
             }
         }
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
     for (int q = 0; q < 4; ++q) {
         const int r = (q * 8 + c.wave) * 8 + (c.lane >> 3);
         const int sl = (c.lane & 7) ^ ((r >> 1) & 7);
-        c.vow[q] = (RC_EXP & 64) ? (unsigned)(r * 128 + (sl << 4)) : (unsigned)(r * (int)p.ldw + (sl << 4));
+        c.vow[q] = (unsigned)(r * (int)p.ldw + (sl << 4));
     }
     c.w_base = p.w + (long)c.n0 * p.ldw;
 #pragma unroll
@@ -451,6 +455,8 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
         m0 = m1;
         ni = ni1;
     }
+    // the last tile's wrapped weight requests may still be landing: LDS must not be handed to another workgroup under them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 }  // namespace efts
