@@ -714,7 +714,7 @@ extern "C" int efts_pack_weights_grouped(const efts_pack_item* items, int32_t n_
     if (ldb < (split == 1 ? kp * 2 : kp * 4) || (ldb & 15)) return efts_fail(EFTS_EALIGN, "efts_pack_weights_grouped: ldb too small or not 16-byte aligned");
     if (with_t && (ldb_t < (split == 1 ? kpt * 2 : kpt * 4) || (ldb_t & 15)))
         return efts_fail(EFTS_EALIGN, "efts_pack_weights_grouped: ldb_t too small or not 16-byte aligned");
-    if (scale_ws && cout % 64 == 0 && cin % PT_CI == 0 && taps <= PT_MAXT && !getenv("EFTS_PACK_ROWS")) {
+    if (scale_ws && cout % 64 == 0 && cin % PT_CI == 0 && taps <= PT_MAXT) {
         hipLaunchKernelGGL(weight_scale_kernel, dim3(cout, n_items), dim3(256), 0, ST, (const PackItem*)items, scale_ws, cout, cin * taps);
         hipLaunchKernelGGL(pack_weight_tile_kernel, dim3(cout / PT_CO, cin / PT_CI, n_items), dim3(256), 0, ST, (const PackItem*)items,
                            (const float*)scale_ws, (long)ldb, (long)ldb_t, cout, cin, taps, split);
@@ -781,7 +781,6 @@ extern "C" int efts_layernorm_bwd(const float* x, const float* gamma, const floa
     if (!x || !gamma || !beta || (!dy && !ddur) || (ddur && !w) || !dgamma || !dbeta) return efts_fail(EFTS_EINVAL, "efts_layernorm_bwd: null pointer");
     if (c % 256 || c > 2048) return efts_fail(EFTS_ESHAPE, "efts_layernorm_bwd: c must be a multiple of 256, <= 2048");
     int rpb = LNB_ROWS;                        // rows per block
-    { const char* e = getenv("EFTS_LNB_ROWS"); if (e && atoi(e) >= 4) rpb = atoi(e) & ~3; }
     if (c > 768) (void)hipFuncSetAttribute((const void*)layernorm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * c * (int)sizeof(float));
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), (size_t)16 * c * sizeof(float), ST, x, gamma, beta, eps, dy, ddur, w,
                        rowmask, dz, (char*)plane, (long)ld_plane, split, dgamma, dbeta, dbias, dw, db, rows, c, drop_p, drop_seed, rpb);

@@ -18,6 +18,7 @@ GUARD_LO = 8
 GUARD_HI = 144
 TILE_M = 128
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+TILING_AUTO, TILING_GENERIC, TILING_WIDE, TILING_NARROW, TILING_RESIDENT = 0, 1, 2, 3, 4
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -36,7 +37,7 @@ class GemmArgs(C.Structure):
         ("out_split", i32), ("batch2", i32),
         ("a_batch2_stride", i64), ("b_batch2_stride", i64), ("out_batch2_stride", i64),
         ("dilation", i32), ("plane_act", i32), ("plane_slope", f32),
-        ("out_bf16_lo", vp),
+        ("out_bf16_lo", vp), ("tiling", i32),
     ]
 
 

@@ -15,6 +15,8 @@ from . import lib as L
 
 # When set to a list, every efts_gemm launch is bracketed by HIP events recorded on the launch
 # stream (torch's current stream) and (tag, start, end) is appended; tag = (taps, m, n).
+# Default `tiling` of efts_gemm launches (L.TILING_*): AUTO in the product; the equality tests between the kernels flip it
+GEMM_TILING = 0
 PROFILE = None
 # optional filter: only launches whose tag equals PROFILE_TAG are bracketed (keeps the host light)
 PROFILE_TAG = None
@@ -121,7 +123,7 @@ def gemm(*, a: Plane, a_ptr: Optional[int] = None, b_ptr: int, ldb: int, b_tap_s
          out_plane: Optional[Plane] = None, out_plane_ptr: Optional[int] = None, outb_batch_stride: int = 0,
          nchunk: Optional[int] = None, batch2: int = 0, a_batch2_stride: int = 0, b_batch2_stride: int = 0,
          out_batch2_stride: int = 0, dilation: int = 1, plane_act: bool = False, plane_slope: float = 0.0,
-         out_plane_lo: Optional[Plane] = None) -> None:
+         out_plane_lo: Optional[Plane] = None, tiling: Optional[int] = None) -> None:
     g = L.GemmArgs()
     g.a, g.lda, g.a_batch_stride = (a_ptr if a_ptr is not None else a.ptr), a.ld, a_batch_stride
     g.b, g.ldb, g.b_tap_stride, g.b_batch_stride = b_ptr, ldb, b_tap_stride, b_batch_stride
@@ -139,6 +141,7 @@ def gemm(*, a: Plane, a_ptr: Optional[int] = None, b_ptr: int, ldb: int, b_tap_s
     g.batch2, g.a_batch2_stride, g.b_batch2_stride, g.out_batch2_stride = batch2, a_batch2_stride, b_batch2_stride, out_batch2_stride
     g.dilation, g.plane_act, g.plane_slope = dilation, int(plane_act), plane_slope
     g.out_bf16_lo = None if out_plane_lo is None else out_plane_lo.ptr
+    g.tiling = GEMM_TILING if tiling is None else tiling
     if PROFILE is not None and (PROFILE_TAG is None or PROFILE_TAG == (taps, m, n)):
         s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s0.record()

@@ -114,7 +114,16 @@ typedef struct efts_gemm_args {
     /* out_split 1 only, optional: a second plane of the layout of out_bf16 that receives the bf16 REMAINDER
      * out - bf16(out), so that a consumer can rebuild out to 16 mantissa bits (the residual input of efts_resconv5). */
     void* out_bf16_lo;
+    /* which of the (bit-identical) kernels runs: EFTS_TILING_AUTO picks by shape; the explicit values are for A/B timing and
+     * for the equality tests between the kernels.  An explicit tiling the shape does not allow is an error. */
+    int32_t tiling;
 } efts_gemm_args;
+
+#define EFTS_TILING_AUTO 0
+#define EFTS_TILING_GENERIC 1  /* 124-row x 128-column tiles, two 4-wave workgroups per CU: every shape */
+#define EFTS_TILING_WIDE 2     /* 252-row x 128-column tiles: dense k5 launches */
+#define EFTS_TILING_NARROW 3   /* 64- / 32-column tiles */
+#define EFTS_TILING_RESIDENT 4 /* window + all taps resident in LDS: n <= 64, one K chunk, taps 3 / 7 / 11 */
 
 int efts_gemm(const efts_gemm_args* a, void* stream);
 

@@ -80,10 +80,10 @@ def test_gemm_conv_vs_fp64(split, taps, cin, cout, B, T):
 
 @pytest.mark.parametrize("split", [2, 1])
 @pytest.mark.parametrize("taps,dil,c,T", [(3, 1, 32, 2600), (7, 3, 32, 2500), (11, 5, 32, 3000), (11, 1, 64, 2200), (7, 5, 24, 2100)])
-def test_resident_kernel_vs_fp64_and_ring_kernels(split, taps, dil, c, T, monkeypatch):
+def test_resident_kernel_vs_fp64_and_ring_kernels(split, taps, dil, c, T):
     """One-K-chunk convolutions with <= 64 columns over many rows (the vocoder's narrow stages) take resident32_kernel
     (window + every tap's weights resident in LDS).  Dilated taps, residual, row mask (a ragged second item), activated
-    output plane: against float64 and, bit for bit, against the ring kernels (EFTS_NO_RESIDENT, read per launch).
+    output plane: against float64 and, bit for bit, against the ring kernels (efts_gemm_args.tiling: narrow vs resident vs auto).
     Row space of the vocoder (64 zero guard rows in front: the halo of a dilated k = 11 tap is 25 rows)."""
     from efficient_tts_amd import lib as L, ops as P
     from efficient_tts_amd.vocoder import _GUARD, _Rows
@@ -108,17 +108,20 @@ def test_resident_kernel_vs_fp64_and_ring_kernels(split, taps, dil, c, T, monkey
     lenmask = torch.zeros(rows, device=dev)
     L.check(lib.efts_row_masks(torch.tensor(lens, dtype=torch.int32, device=dev).data_ptr(), None, lenmask.data_ptr(), B, T, Tp, None), "efts_row_masks")
     outs = {}
-    for flag in ("1", None):
-        if flag is None:
-            monkeypatch.delenv("EFTS_NO_RESIDENT", raising=False)
-        else:
-            monkeypatch.setenv("EFTS_NO_RESIDENT", flag)
+    resident_ok = a.p.nchunk == 1                     # the resident tiling needs the whole K in one 128-byte chunk
+    for flag, tiling in (("1", L.TILING_NARROW), ("r", L.TILING_RESIDENT if resident_ok else L.TILING_NARROW), (None, L.TILING_AUTO)):
         out = _Rows(rows, c, split, dev)
         P.gemm(a=a.p, b_ptr=pw.ptr, ldb=pw.ld, b_tap_stride=pw.tap_stride, taps=taps, m=rows, n=c, bias=bias, resid_ptr=resid.fptr, ldr=c,
-               rowmask_ptr=lenmask.data_ptr(), out_f32_ptr=out.fptr, ldo=c, out_plane=out.p, dilation=dil, plane_act=True, plane_slope=0.1)
+               rowmask_ptr=lenmask.data_ptr(), out_f32_ptr=out.fptr, ldo=c, out_plane=out.p, dilation=dil, plane_act=True, plane_slope=0.1,
+               tiling=tiling)
         torch.cuda.synchronize()
         outs[flag] = (out.f.clone(), out.p.buf.clone())
     assert torch.equal(outs[None][0], outs["1"][0]) and torch.equal(outs[None][1], outs["1"][1])
+    assert torch.equal(outs["r"][0], outs["1"][0]) and torch.equal(outs["r"][1], outs["1"][1])
+    if not resident_ok:
+        with pytest.raises(ValueError):                # an explicit tiling the shape does not allow is an error, not a fallback
+            P.gemm(a=a.p, b_ptr=pw.ptr, ldb=pw.ld, b_tap_stride=pw.tap_stride, taps=taps, m=rows, n=c, out_f32_ptr=out.fptr, ldo=c,
+                   dilation=dil, tiling=L.TILING_RESIDENT)
     ref = torch.nn.functional.conv1d(x.double().transpose(1, 2), w.double(), bias.cpu().double(), padding=(taps - 1) // 2 * dil, dilation=dil)
     ref = (res[:, :T].double() + ref.transpose(1, 2)).float()
     ref[1, lens[1]:] = 0.0
@@ -278,58 +281,63 @@ def test_odd_shapes_and_ragged_lengths_vs_oracle(model, B, T1, T2, tl, sl):
     assert abs(float(loss) - float(o["loss"])) <= 2e-4 * float(o["loss"])
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
-def test_narrow_tiles_equal_gemm_kernel(golden_dir, precision, monkeypatch):
-    """64-column tiles (narrow_kernel, taken by launches too small to give every CU two workgroups -- every
-    launch at this size) against the 128-column gemm_kernel: the same K order per output element, so the results
-    must agree to the last bits.  EFTS_NARROW_FEW is read per launch: 0 disables the rule."""
+def test_narrow_tiles_equal_gemm_kernel(golden_dir, precision):
+    """Launches that leave most CUs idle (the text side of a 2-item batch: 260 rows) take 64-column tiles in the automatic
+    tiling; forcing the generic 124 x 128 kernel for EVERY launch of the forward must give the same outputs to the last bits
+    (same per-element summation order)."""
+    from efficient_tts_amd import EfficientTTSCNN, lib as L, ops as P
     g = np.load(os.path.join(golden_dir, "fwd_full.npz"))
     args = [torch.from_numpy(g[k]).cuda() for k in ("text", "text_lengths", "speech", "speech_lengths")]
-    from efficient_tts_amd import EfficientTTSCNN
     m = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, sigma=0.01, precision=precision)
     m.load_state_dict(O.fill_params())
     m = m.cuda().eval()
+    m.graphs = False                                   # the tiling is baked into a captured graph
     outs = {}
-    for flag in ("0", "2"):
-        monkeypatch.setenv("EFTS_NARROW_FEW", flag)
-        with torch.no_grad():
-            o = m(*args)
-        torch.cuda.synchronize()
-        outs[flag] = (float(o[0]), o[4].clone(), o[3].clone())
-    monkeypatch.delenv("EFTS_NARROW_FEW")
-    assert (outs["0"][1] - outs["2"][1]).abs().max().item() <= 1e-6
-    assert (outs["0"][2] - outs["2"][2]).abs().max().item() <= 1e-6
-    assert abs(outs["0"][0] - outs["2"][0]) <= 1e-6 * abs(outs["0"][0])
+    try:
+        for tiling in (L.TILING_GENERIC, L.TILING_AUTO):
+            P.GEMM_TILING = tiling
+            with torch.no_grad():
+                o = m(*args)
+            torch.cuda.synchronize()
+            outs[tiling] = (float(o[0]), o[4].clone(), o[3].clone())
+    finally:
+        P.GEMM_TILING = L.TILING_AUTO
+    a, b = outs[L.TILING_GENERIC], outs[L.TILING_AUTO]
+    assert (a[1] - b[1]).abs().max().item() <= 1e-6
+    assert (a[2] - b[2]).abs().max().item() <= 1e-6
+    assert abs(a[0] - b[0]) <= 1e-6 * abs(a[0])
     if precision == "bf16x3":
         stride = int(g["mel_pred_stride"])
-        assert np.abs(outs["0"][1].cpu().numpy()[:, ::stride] - g["mel_pred"]).max() <= 1e-3
+        assert np.abs(b[1].cpu().numpy()[:, ::stride] - g["mel_pred"]).max() <= 1e-3
 
 
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
-def test_conv5_kernel_equals_gemm_kernel(golden_dir, precision, monkeypatch):
-    """The 256-row k5 kernel (conv5_kernel, used for large launches) against the 124-row gemm_kernel on the same
-    batch: identical summation order per output element, so the results must agree to the last bits; plus the
-    golden / oracle gate of the active mode.  EFTS_CONV5 is read per launch: 1 forces the 256-row kernel, 0 disables it."""
-    g = np.load(os.path.join(golden_dir, "fwd_full.npz"))
-    args = [torch.from_numpy(g[k]).cuda() for k in ("text", "text_lengths", "speech", "speech_lengths")]
-    from efficient_tts_amd import EfficientTTSCNN
-    m = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, sigma=0.01, precision=precision)
-    m.load_state_dict(O.fill_params())
-    m = m.cuda().eval()
+@pytest.mark.parametrize("split", [1, 2])
+@pytest.mark.parametrize("B,T", [(5, 300), (2, 750)])      # row counts whose last 256-row window stays inside the guard rows
+def test_conv5_kernel_equals_gemm_kernel(split, B, T):
+    """The 256-row k5 kernel (conv5_kernel: the training step's large forward / dgrad launches) against the 124-row
+    gemm_kernel on the same operands: identical summation order per output element, so fp32 stream and operand plane must
+    agree to the last bits (ragged length mask, residual, LeakyReLU, both operand formats)."""
+    from efficient_tts_amd import lib as L, ops as P
+    L.load(); L.require_device()
+    dev = _dev()
+    C = 512
+    torch.manual_seed(B * 1000 + T + split)
+    rs = P.Rows(B, T)
+    x = torch.randn(B, T, C, device=dev)
+    a = P.Plane.for_rows(rs, C, split, dev)
+    P.pack_rows(x, None, a, rs)
+    xf = P.F32Rows(rs, C, dev); xf.view().copy_(x)
+    pw = P.PackedWeight(C, C, 5, split, dev); pw.pack((torch.randn(C, C, 5, device=dev) * 0.02).contiguous())
+    bias = torch.randn(C, device=dev)
+    mask = torch.zeros(rs.rows, device=dev)
+    P.row_masks(torch.randint(T // 2, T + 1, (B,), dtype=torch.int32, device=dev), rs, None, mask)
     outs = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("EFTS_CONV5", flag)
-        with torch.no_grad():
-            o = m(*args)
+    for tiling in (L.TILING_GENERIC, L.TILING_WIDE):
+        o, pl = P.F32Rows(rs, C, dev), P.Plane.for_rows(rs, C, 2, dev)
+        P.gemm(a=a, b_ptr=pw.ptr, ldb=pw.ld, b_tap_stride=pw.tap_stride, taps=5, m=rs.rows, n=C, act=L.ACT_LEAKY, slope=0.1, bias=bias,
+               resid_ptr=xf.ptr, ldr=C, rowmask_ptr=mask.data_ptr(), out_f32_ptr=o.ptr, ldo=C, out_plane=pl, tiling=tiling)
         torch.cuda.synchronize()
-        outs[flag] = (float(o[0]), o[4].clone(), o[3].clone())
-    monkeypatch.delenv("EFTS_CONV5")
-    assert (outs["0"][1] - outs["1"][1]).abs().max().item() <= 1e-6
-    assert (outs["0"][2] - outs["1"][2]).abs().max().item() <= 1e-6
-    assert abs(outs["0"][0] - outs["1"][0]) <= 1e-6 * abs(outs["0"][0])
-    if precision == "bf16x3":
-        stride = int(g["mel_pred_stride"])
-        assert np.abs(outs["1"][1].cpu().numpy()[:, ::stride] - g["mel_pred"]).max() <= 1e-3
+        outs[tiling] = (o.buf, pl.buf)
+    assert torch.equal(outs[L.TILING_GENERIC][0], outs[L.TILING_WIDE][0])
+    assert torch.equal(outs[L.TILING_GENERIC][1], outs[L.TILING_WIDE][1])
