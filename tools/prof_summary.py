@@ -17,7 +17,8 @@ def short(name):
     return name.replace("void ", "").replace("efts::", "")[:72]
 
 
-print(f"# rocprofv3 summary {tag}: python bench.py --steps 5 --warmup 2 --precision {os.environ.get('PREC', 'bf16')}")
+print(f"# rocprofv3 summary {tag}: python bench.py --steps {os.environ.get('STEPS', '5')} --warmup 2 --no-cpu-baseline --parity-mode 0 --call-modes 0 "
+      f"--precision {os.environ.get('PREC', 'bf16')} --workload {os.environ.get('WL', 'fwd64')} {os.environ.get('BARGS', '')}")
 con = db("trace")
 if con:
     print("\n## kernel-trace --stats: top kernels (name, calls, total, average [as reported by rocprofv3, us], %)")
@@ -31,7 +32,7 @@ if con:
             print(f"{short(r[0]):60s} grid={r[1]:9d} n={r[2]:4d} avg={r[3]:9.2f} us total={r[4]:10.1f} us vgpr={r[5]} lds={r[6]}")
     except Exception as e:
         print("(kernels view unavailable:", e, ")")
-for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_l2"):
+for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_l2"):
     con = db(sub)
     if not con:
         print(f"\n## {sub}: no database (pass failed, see {sub}.log)")
