@@ -56,7 +56,7 @@ def run_train(a, world, rank, dev, wl):
                             precision=a.precision).to(dev).train()
     opt = EftsAdam(model, lr=1e-3, betas=(0.9, 0.99), eps=1e-9, weight_decay=1e-5, amsgrad=True, grad_norm=1.0)
     sch = WarmupLR(opt, warmup_steps=4000)
-    ddp = DistributedEFTS(model) if world > 1 else None
+    ddp = DistributedEFTS(model, algo=getattr(a, "dp_algo", "allreduce"), timing=True) if world > 1 else None
     net = ddp if ddp is not None else model
     g = torch.Generator().manual_seed(1234 + rank)
     text = torch.randint(0, 76, (B, T1), generator=g).to(dev)
@@ -117,6 +117,12 @@ def run_train(a, world, rank, dev, wl):
                                  achieved=conv_flop / avg / 1e12 if avg else None, peak=2500.0, unit="TFLOP/s",
                                  frac=conv_flop / avg / 1e12 / 2500.0 if avg else None, traffic=None,
                                  avg_launch_us=avg * 1e6, launches_measured=len(durs)))
+        if ddp is not None:
+            # the last timed step's communication: one record that explains the scaling number (backend, ranks, algorithm,
+            # bytes and time per bucket, how much of it the backward did NOT hide)
+            res["dp"] = dict(backend=dist.get_backend(), ranks=dist.get_world_size(), grad_mb=ddp.engine.numel * 4 / 1e6,
+                             nccl_env={k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))},
+                             **ddp.reducer.stats())
         if cpu is not None:
             res["cpu_baseline"] = cpu
         print(json.dumps(res), flush=True)

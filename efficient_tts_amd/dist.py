@@ -19,37 +19,106 @@ import torch.distributed as dist
 
 
 class BucketReducer:
-    """Sum-all-reduce contiguous slices of one flat tensor, asynchronously, in call order."""
+    """Sum-reduce contiguous slices of one flat tensor across the group, asynchronously, in call order.
 
-    def __init__(self, flat: torch.Tensor, bucket_ends: List[int], group=None):
-        self.flat, self.ends, self.group = flat, list(bucket_ends), group
+    algo "allreduce": one `all_reduce` per bucket (RCCL picks ring / tree).
+    algo "rs_ag"    : `reduce_scatter_tensor` + `all_gather_into_tensor` per bucket (xGMI is
+                      point-to-point, 7 links per GPU; a ring all-reduce of 82 MB is bound by ONE link (~0.94 ms), the direct
+                      reduce-scatter + all-gather exchange uses all of them (~0.135 ms)).  The bucket is staged through a
+                      scratch buffer padded to a multiple of the world size (two device copies of the bucket, ~10 us).
+    timing          : HIP events around every bucket's collective on the communication stream, and on the compute stream
+                      when the first bucket is handed over / when the optimizer starts waiting: `stats()`."""
+
+    def __init__(self, flat: torch.Tensor, bucket_ends: List[int], group=None, algo: str = "allreduce", timing: bool = False):
+        if algo not in ("allreduce", "rs_ag"):
+            raise ValueError("algo must be 'allreduce' or 'rs_ag'")
+        self.flat, self.ends, self.group, self.algo, self.timing = flat, list(bucket_ends), group, algo, timing
         self.starts = [0] + self.ends[:-1]
+        self.world = dist.get_world_size(group)
         self.works = []
         self.comm_stream = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
+        self.pad, self.shard = [], []
+        if algo == "rs_ag":
+            for s0, e0 in zip(self.starts, self.ends):
+                chunk = (e0 - s0 + self.world - 1) // self.world
+                self.pad.append(torch.zeros(chunk * self.world, dtype=flat.dtype, device=flat.device))
+                self.shard.append(torch.empty(chunk, dtype=flat.dtype, device=flat.device))
+        self.events = {}                  # timing: name -> torch.cuda.Event of the current step
+        self.pending = False              # buckets handed over since the last finish()
+
+    def _event(self, name: str, stream=None) -> None:
+        if self.timing and self.comm_stream is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream if stream is not None else torch.cuda.current_stream(self.flat.device))
+            self.events[name] = ev
+
+    def mark(self, name: str) -> None:
+        """an event on the COMPUTE stream (the training engine calls mark("backward_start"))"""
+        self._event(name)
+
+    def _collective(self, i: int) -> None:
+        view = self.flat[self.starts[i]:self.ends[i]]
+        if self.algo == "allreduce":
+            w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if self.comm_stream is not None:
+                w.wait()                                          # the COMMUNICATION stream waits (the host and the compute stream do not)
+            else:
+                self.works.append(w)
+            return
+        pad, shard, n = self.pad[i], self.shard[i], view.numel()
+        pad[:n].copy_(view)                                       # the tail beyond n stays zero
+        w = dist.reduce_scatter_tensor(shard, pad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        w.wait()                                                  # orders the stream (NCCL) / blocks the host (gloo)
+        w = dist.all_gather_into_tensor(pad, shard, group=self.group, async_op=True)
+        w.wait()
+        view.copy_(pad[:n])
 
     def reduce(self, i: int) -> None:
-        view = self.flat[self.starts[i]:self.ends[i]]
+        self.pending = True
         if self.comm_stream is not None:
+            if i == 0:
+                self._event("first_bucket_ready")
             # the bucket is final once everything already enqueued on the compute stream has run
             self.comm_stream.wait_stream(torch.cuda.current_stream(self.flat.device))
             with torch.cuda.stream(self.comm_stream):
-                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._event(f"b{i}_start", self.comm_stream)
+                self._collective(i)
+                self._event(f"b{i}_end", self.comm_stream)
         else:
-            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._collective(i)
 
     def finish(self) -> None:
         """make the compute stream (or the host, on CPU) wait for every outstanding bucket"""
+        if not self.pending:
+            return
+        self.pending = False
+        self._event("wait_start")
         for w in self.works:
             w.wait()
         self.works = []
         if self.comm_stream is not None:
             torch.cuda.current_stream(self.flat.device).wait_stream(self.comm_stream)
+        self._event("wait_end")
+
+    def stats(self) -> dict:
+        """after a synchronize: milliseconds of the last step (timing=True, GPU only)"""
+        ev = self.events
+        if not self.timing or "wait_end" not in ev:
+            return {}
+        out = dict(algo=self.algo, world=self.world,
+                   bucket_mb=[(e0 - s0) * self.flat.element_size() / 1e6 for s0, e0 in zip(self.starts, self.ends)],
+                   bucket_ms=[ev[f"b{i}_start"].elapsed_time(ev[f"b{i}_end"]) for i in range(len(self.ends)) if f"b{i}_end" in ev],
+                   exposed_ms=ev["wait_start"].elapsed_time(ev["wait_end"]))
+        if "backward_start" in ev:
+            out["backward_ms"] = ev["backward_start"].elapsed_time(ev["wait_start"])
+            out["first_bucket_after_ms"] = ev["backward_start"].elapsed_time(ev["first_bucket_ready"])
+        return out
 
 
 class DistributedEFTS(torch.nn.Module):
     """DDP stand-in with the attributes the reference trainer uses (`.module`, call-through)."""
 
-    def __init__(self, module, group=None):
+    def __init__(self, module, group=None, algo: str = "allreduce", timing: bool = False):
         super().__init__()
         self.module = module
         self.group = group
@@ -59,9 +128,10 @@ class DistributedEFTS(torch.nn.Module):
         self.engine.bound.add("DistributedEFTS")
         self.reducer: Optional[BucketReducer] = None
         if self.world > 1:
-            self.reducer = BucketReducer(self.engine.flat, self.engine.bucket_ends, group)
+            self.reducer = BucketReducer(self.engine.flat, self.engine.bucket_ends, group, algo=algo, timing=timing)
             self.engine.bucket_hook = self.reducer.reduce
             self.engine.join_reduce = self.reducer.finish
+            self.engine.mark = self.reducer.mark if timing else None
             # identical initial parameters on every rank (DDP broadcasts rank 0's)
             for p in module.parameters():
                 dist.broadcast(p.data, src=0, group=group)

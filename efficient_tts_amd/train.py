@@ -98,6 +98,7 @@ class TrainEngine:
         self._ws_tag = ""                       # "s" while work is being enqueued on the side stream
         self.bucket_hook: Optional[Callable[[int], None]] = None
         self.join_reduce: Optional[Callable[[], None]] = None
+        self.mark: Optional[Callable[[str], None]] = None      # timing probe of the data-parallel wrapper (bench only)
         self.bound = set()                      # who holds views of `flat` (EftsAdam, DistributedEFTS): see autograd.engine_of
 
     def stale(self, model) -> bool:
@@ -325,6 +326,8 @@ class TrainEngine:
         O.masked_losses(mel.ptr, odim, speech, ml, dur, lde, tl, out3, ws.tensor("loss_ws", (1024,)), B, T1, rs1.Tp, T2, rs2.Tp, odim)
 
         # ============================ backward
+        if self.mark is not None:
+            self.mark("backward_start")
         g = self.g
         dmel_f = ws.f32("Bdmel_f", rs2, odim)
         dmel_p = ws.plane("Bdmel_p", rs2, odim, split)

@@ -53,15 +53,22 @@ def _worker(rank, world, port, golden, out):
         if n == [k for k, _ in layout if k.startswith("decoder.layers.0.")][-1] or n == [k for k, _ in layout if k.startswith("mel_prenet.")][-1]:
             ends.append(acc)
     ends.append(numel)
+    flat2 = flat.clone()
     red = BucketReducer(flat, ends)
     for i in range(len(ends)):
         red.reduce(i)
     red.finish()
+    red.finish()                                  # idempotent: the autograd hook and the trainer both join
+    red2 = BucketReducer(flat2, ends, algo="rs_ag")   # reduce_scatter + all_gather per bucket (bucket sizes are not multiples of 2)
+    for i in range(len(ends)):
+        red2.reduce(i)
+    red2.finish()
+    same = bool(torch.allclose(flat, flat2, rtol=0, atol=1e-7))
     flat /= world
     gathered = [torch.empty_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
     ref = sum(gathered) / world
-    ok = bool(torch.allclose(flat, ref, rtol=0, atol=1e-7)) and ends[-1] == 20587601 and len(ends) == 3
+    ok = bool(torch.allclose(flat, ref, rtol=0, atol=1e-7)) and ends[-1] == 20587601 and len(ends) == 3 and same
     if rank == 0:
         open(out, "w").write("ok" if ok else f"mismatch {float((flat - ref).abs().max())} {ends}")
     dist.destroy_process_group()
