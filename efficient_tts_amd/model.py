@@ -18,7 +18,7 @@ import torch
 from . import lib as L
 from . import ops as O
 from .graphs import GraphCache
-from .ops import F32Rows, PackedWeight, Plane, Rows
+from .ops import F32Rows, PackedWeight, Plane, Rows, roundup
 
 
 # --------------------------------------------------------------------------------------
@@ -196,6 +196,7 @@ class EfficientTTSCNN(torch.nn.Module):
         self.duration_predictor = _DurationPredictor(n_channels, n_duration_layer, n_channels, offset=duration_offset)
         self.graphs = True                  # plain eval calls replay a per-shape hipGraph (False: every kernel launched eagerly)
         self._graph_cache = GraphCache()
+        self._infer_cache = GraphCache(capacity=64)      # free-running inference: two phases per (bucketed) shape
         self.side_stream = True             # text-length work on a second HIP stream beside the mel-length kernels
         self.resconv = True                 # long row spaces: residual stacks on efts_resconv5 (False: efts_gemm + fp32 stream, A/B and tests)
         self.dropout_seed = 0x5EED          # base seed of the duration predictor's dropout masks (train mode)
@@ -205,6 +206,7 @@ class EfficientTTSCNN(torch.nn.Module):
         self._packed_gen = 0                # bumped by every repack: what derived caches (TrainEngine) compare
         self._folded_gen = -1               # the repack that last wrote the training engine's folded fp32 copies
         self._ws: Dict[Tuple, _Workspace] = {}
+        self._ws_infer: Dict[Tuple, _Workspace] = {}
 
     # ------------------------------------------------------------------ weight norm (efficient_tts.py:400-418)
     def remove_weight_norm(self):
@@ -299,11 +301,14 @@ class EfficientTTSCNN(torch.nn.Module):
         return st
 
     def _workspace(self, key, device) -> _Workspace:
-        if key not in self._ws:
-            if len(self._ws) >= 4:                      # bound cached shapes (each holds full activations)
-                self._ws.pop(next(iter(self._ws)))
-            self._ws[key] = _Workspace(device)
-        return self._ws[key]
+        # bound the cached shapes (each holds full activations): 4 teacher-forced / training shapes, 64 free-running ones
+        # (their row spaces are one or a few utterances, a few MB each)
+        pool, cap = (self._ws_infer, 64) if key[0] in ("infb", "infb2", "inf", "inf2") else (self._ws, 4)
+        if key not in pool:
+            if len(pool) >= cap:
+                pool.pop(next(iter(pool)))
+            pool[key] = _Workspace(device)
+        return pool[key]
 
     # ------------------------------------------------------------------ building blocks
     # row spaces of at least this many rows run their residual stacks on efts_resconv5 (hi/lo planes, one persistent
@@ -526,6 +531,12 @@ class EfficientTTSCNN(torch.nn.Module):
         if text.shape[0] != 1:
             raise ValueError("inference() takes one utterance, like the reference (efficient_tts.py:361); "
                              "use inference_batch() for B > 1")
+        if self.graphs and not torch.cuda.is_current_stream_capturing():
+            # same arithmetic as a ragged batch of one (every layer masked by the length; equal to the unmasked B = 1 pass
+            # below to ~1e-4), on bucketed shapes whose launches replay as two hipGraphs around the one host sync
+            tl1 = torch.full((1,), text.shape[1], dtype=torch.int64, device=text.device) if text_lengths is None else text_lengths
+            mel, _, ralpha = self.inference_batch(text, tl1)
+            return mel, ralpha
         dev = text.device
         T1, C = text.shape[1], self.n_channels
         pk = self._weights()
@@ -552,6 +563,58 @@ class EfficientTTSCNN(torch.nn.Module):
         return mel.view().clone(), ralpha
 
     # ------------------------------------------------------------------ batched ragged inference (extension)
+    T1_BUCKET, T2_BUCKET = 16, 64       # free-running inference runs on shapes rounded up to these multiples (graph / workspace reuse)
+
+    def _infer_text(self, text, tl, force_delta):
+        """phase 1 (no host sync): embed -> text encoder -> value -> duration predictor -> aligned positions e = cumsum(durations)
+        and the mel length of every item (efficient_tts.py:246-260).  text [B, T1] int64 (positions >= tl are ignored), tl int32 [B]."""
+        dev = text.device
+        B, T1 = text.shape
+        C = self.n_channels
+        pk = self._weights()
+        ws = self._workspace(("infb", B, T1), dev)
+        rs1 = Rows(B, T1)
+        gap1, len1 = ws.tensor("gap1", (rs1.rows,)), ws.tensor("len1", (rs1.rows,))
+        O.row_masks(tl, rs1, gap1, len1)
+        # embedding with padded positions zeroed, then every layer masked by the item length
+        e_f = ws.f32("emb_raw", rs1, C)
+        O.embed(text.contiguous(), self.text_embedding_table.weight.detach(), e_f, None, rs1)
+        x_f, x_p = ws.f32("emb_f", rs1, C), ws.plane("emb_p", rs1, C, self.split)
+        O.mask_rows(e_f.ptr, len1.data_ptr(), x_f, x_p, rs1.rows, C)
+        _, h_p = self._res_stack(ws, "te", "text_encoder", pk, rs1, x_f, x_p, len1.data_ptr(), self.split, False)
+        val_f, val_p = ws.f32("val_f", rs1, C), ws.plane("val_p", rs1, C, self.split)
+        wv = pk["value"]
+        O.gemm(a=h_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=self.text_encoder_value.bias,
+               rowmask_ptr=len1.data_ptr(), out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p)
+        delta = self._duration(ws, pk, rs1, val_p, len1, len1.data_ptr(), 1)          # zero beyond each length
+        d2 = delta.view(B, rs1.Tp)[:, :T1].contiguous()
+        if force_delta is not None:
+            d2 = (torch.arange(T1, device=dev)[None, :] < tl[:, None]).to(torch.float32) * float(force_delta)
+        e = torch.empty(B, T1, dtype=torch.float32, device=dev)
+        O.cumsum_rows(d2, e, B, T1)
+        last = e.gather(1, (tl.long() - 1).clamp(min=0)[:, None]).squeeze(1)
+        ml = torch.round(last).to(torch.int32)
+        return e, ml
+
+    def _infer_mel(self, e, tl, ml, T2: int):
+        """phase 2: Gaussian re-alignment from e, expand, decoder, mel head on a [B, T2] row space (efficient_tts.py:270-284);
+        reads the value projection phase 1 left in the (B, T1) workspace."""
+        dev = e.device
+        B, T1 = e.shape
+        C = self.n_channels
+        pk = self._weights()
+        ws = self._workspace(("infb", B, T1), dev)
+        rs1, rs2 = Rows(B, T1), Rows(B, T2)
+        ws2 = self._workspace(("infb2", B, T1, T2), dev)
+        val_f = ws.f32("val_f", rs1, C)
+        gap2, len2 = ws2.tensor("gap2", (rs2.rows,)), ws2.tensor("len2", (rs2.rows,))
+        O.row_masks(ml, rs2, gap2, len2)
+        ralpha = torch.empty(B, T1, T2, dtype=torch.float32, device=dev)
+        ra_p = ws2.plane("ra_p", rs2, T1, 2)
+        O.reconst_alpha(e, tl, ml, float(self.sigma), ralpha, ra_p, B, T1, T2, rs2.Tp)
+        mel = self._expand_decode(ws2, pk, B, T1, rs1, rs2, val_f, ra_p, len2.data_ptr(), len2)
+        return mel.view().clone(), ralpha
+
     @torch.no_grad()
     def inference_batch(self, text: torch.Tensor, text_lengths: torch.Tensor, force_delta: Optional[float] = None):
         """Free-running synthesis of B utterances at once -- an extension the reference cannot do
@@ -563,47 +626,42 @@ class EfficientTTSCNN(torch.nn.Module):
         Returns (mel_pred [B, max T2_b, odim] zero-padded, mel_lengths [B] int64, reconst_alpha
         [B, T1, max T2_b]).  One host sync (max T2_b), like the reference's single `.item()`.
 
+        With `graphs` on, the two phases run on bucketed shapes (T1 up to a multiple of 16, T2 of 64: padding is masked
+        like any other ragged tail) and replay per-shape hipGraphs from the second call of a shape on.
+
         force_delta (benchmark hook): the duration predictor still runs, but every
         valid phoneme then gets this many frames, so a synthetic batch yields a known, equal T2."""
         self._require(text)
         with O.stream_scope():
             dev = text.device
             B, T1 = text.shape
-            C = self.n_channels
-            pk = self._weights()
-            ws = self._workspace(("infb", B, T1), dev)
-            rs1 = Rows(B, T1)
             tl = text_lengths.to(device=dev, dtype=torch.int32)
-            gap1, len1 = ws.tensor("gap1", (rs1.rows,)), ws.tensor("len1", (rs1.rows,))
-            O.row_masks(tl, rs1, gap1, len1)
-            # embedding with padded positions zeroed, then every layer masked by the item length
-            e_f, e_p = ws.f32("emb_raw", rs1, C), None
-            O.embed(text.contiguous(), self.text_embedding_table.weight.detach(), e_f, None, rs1)
-            x_f, x_p = ws.f32("emb_f", rs1, C), ws.plane("emb_p", rs1, C, self.split)
-            O.mask_rows(e_f.ptr, len1.data_ptr(), x_f, x_p, rs1.rows, C)
-            _, h_p = self._res_stack(ws, "te", "text_encoder", pk, rs1, x_f, x_p, len1.data_ptr(), self.split, False)
-            val_f, val_p = ws.f32("val_f", rs1, C), ws.plane("val_p", rs1, C, self.split)
-            wv = pk["value"]
-            O.gemm(a=h_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=self.text_encoder_value.bias,
-                   rowmask_ptr=len1.data_ptr(), out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p)
-            delta = self._duration(ws, pk, rs1, val_p, len1, len1.data_ptr(), 1)          # zero beyond each length
-            d2 = delta.view(B, rs1.Tp)[:, :T1].contiguous()
-            if force_delta is not None:
-                d2 = (torch.arange(T1, device=dev)[None, :] < tl[:, None]).to(torch.float32) * float(force_delta)
-            e = ws.tensor("e", (B, T1))
-            O.cumsum_rows(d2, e, B, T1)
-            last = e.gather(1, (text_lengths.to(dev).long() - 1).clamp(min=0)[:, None]).squeeze(1)
-            ml = torch.round(last).to(torch.int32)
+            graphs = self.graphs and not torch.cuda.is_current_stream_capturing()
+            T1b = roundup(T1, self.T1_BUCKET) if graphs else T1
+            if T1b != T1:
+                text = torch.nn.functional.pad(text, (0, T1b - T1))
+            pk = self._weights()
+            wsig = (self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.RESCONV_MIN_ROWS)
+            if graphs:
+                ws = self._workspace(("infb", B, T1b), dev)
+                def phase1(t, l):
+                    with O.stream_scope():              # resolved INSIDE the capture: the launches must go to the capturing stream
+                        return self._infer_text(t, l, force_delta)
+                e, ml = self._infer_cache.run(("text", B, T1b, force_delta), (ws.serial, wsig), (text.contiguous(), tl), phase1, keepalive=ws)
+            else:
+                e, ml = self._infer_text(text, tl, force_delta)
             t2 = int(ml.max().item())                                                      # the one host sync
             if t2 <= 0:
                 raise ValueError("predicted total durations round to 0 frames")
-            rs2 = Rows(B, t2)
-            ws2 = self._workspace(("infb2", B, T1, t2), dev)
-            gap2, len2 = ws2.tensor("gap2", (rs2.rows,)), ws2.tensor("len2", (rs2.rows,))
-            O.row_masks(ml, rs2, gap2, len2)
-            ralpha = torch.empty(B, T1, t2, dtype=torch.float32, device=dev)
-            ra_p = ws2.plane("ra_p", rs2, T1, 2)
-            O.reconst_alpha(e, tl, ml, float(self.sigma), ralpha, ra_p, B, T1, t2, rs2.Tp)
-            mel = self._expand_decode(ws2, pk, B, T1, rs1, rs2, val_f, ra_p, len2.data_ptr(), len2)
-            return mel.view().clone(), ml.to(torch.int64), ralpha
-
+            T2b = roundup(t2, self.T2_BUCKET) if graphs else t2
+            if graphs:
+                ws2 = self._workspace(("infb2", B, T1b, T2b), dev)
+                def phase2(e_, l, m):
+                    with O.stream_scope():
+                        return self._infer_mel(e_, l, m, T2b)
+                mel, ralpha = self._infer_cache.run(("mel", B, T1b, T2b), (ws.serial, ws2.serial, wsig), (e, tl, ml), phase2, keepalive=(ws, ws2))
+            else:
+                mel, ralpha = self._infer_mel(e, tl, ml, T2b)
+            if T2b != t2 or T1b != T1:
+                mel, ralpha = mel[:, :t2].contiguous(), ralpha[:, :T1, :t2].contiguous()
+            return mel, ml.to(torch.int64), ralpha

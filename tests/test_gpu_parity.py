@@ -341,3 +341,25 @@ def test_conv5_kernel_equals_gemm_kernel(split, B, T):
         outs[tiling] = (o.buf, pl.buf)
     assert torch.equal(outs[L.TILING_GENERIC][0], outs[L.TILING_WIDE][0])
     assert torch.equal(outs[L.TILING_GENERIC][1], outs[L.TILING_WIDE][1])
+
+
+def test_inference_graph_path_equals_exact_path(golden_dir, model):
+    """inference() with the graph cache on runs as a ragged batch of one on bucketed shapes (T1 up to a multiple of 16, T2 of 64)
+    and replays two hipGraphs around the single host sync; it must give the T2 of the exact unmasked B = 1 pass and the same
+    mel to ~1e-4, call after call (eager first call, capture, replays), for utterances that fall into different buckets."""
+    g = _golden(golden_dir, "inference_lj")
+    dev = _dev()
+    for n in range(4):
+        ids = torch.from_numpy(g[f"text{n}"]).to(dev)
+        model.graphs = False
+        try:
+            exact, ra_exact = model.inference(ids)
+        finally:
+            model.graphs = True
+        outs = [model.inference(ids) for _ in range(3)]          # eager / captured + replayed / replayed
+        for mel, ra in outs:
+            assert mel.shape == exact.shape and ra.shape == ra_exact.shape and mel.shape[1] == int(g[f"t2_{n}"])
+            assert float((mel - exact).abs().max()) <= 2e-4
+            assert float((ra - ra_exact).abs().max()) <= 1e-5
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[1][0], outs[2][0])
+        assert float((outs[2][0][0, ::2].cpu() - torch.from_numpy(g[f"mel_pred{n}"])[0]).abs().max()) <= MEL_TOL
