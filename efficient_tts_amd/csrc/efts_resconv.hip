@@ -40,6 +40,12 @@
 #ifndef RC_PRIO
 #define RC_PRIO 0
 #endif
+// RC_SGB 1 (bf16 planes): the ds_reads of k-slice kk+1 are interleaved 1:1 with the MFMAs of slice kk (sched_group_barrier)
+// instead of being issued as a block in front of them: both waves of a SIMD run the same stream in phase, so a block of
+// non-MFMA instructions in one wave coincides with the same block in the other and the matrix pipe idles under it
+#ifndef RC_SGB
+#define RC_SGB 1
+#endif
 
 namespace efts {
 
@@ -168,8 +174,9 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
             ld(0, 0);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                if (kk + 1 < 4) ld(kk + 1, (kk + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < 4) ld(kk + 1, (kk + 1) & 1);
+                if (!RC_SGB) __builtin_amdgcn_sched_barrier(0);
                 if (RC_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
@@ -177,6 +184,16 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j], 0, 0, 0);
                 if (RC_PRIO) __builtin_amdgcn_s_setprio(0);
+                if (RC_SGB && kk + 1 < 4) {
+                    // 2 NI MFMAs and NI + 2 fragment reads of the next slice: MFMA, read, MFMA, read, ... (the reads' address
+                    // VALU goes wherever the scheduler likes)
+#pragma unroll
+                    for (int q = 0; q < 2 * NI; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (q < NI + 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    if (NI + 2 > 2 * NI) __builtin_amdgcn_sched_group_barrier(0x100, NI + 2 - 2 * NI, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 hook(kk);
                 __builtin_amdgcn_sched_barrier(0);
