@@ -67,14 +67,49 @@ class EftsAdam(torch.optim.Optimizer):
             p.grad = None
 
     def state_dict(self):
-        return dict(t=self.t, m=self.m, v=self.v, vmax=self.vmax, param_groups=[{k: v for k, v in g.items() if k != "params"}
-                                                                              for g in self.param_groups])
+        """torch.optim.Adam(amsgrad=True) layout -- {"state": {i: {step, exp_avg, exp_avg_sq, max_exp_avg_sq}}, "param_groups"}
+        with i = the parameter's position in model.parameters(), as the reference's optimizer numbers them
+        (nntts/bin/train.py:196-205) -- so `--resume` works across the two implementations
+        (nntts/trainers/efficient_tts_trainer.py:90-103 saves optimizer.state_dict() as is)."""
+        eng, state = self.eng, {}
+        names = [n for n, _ in self.model.named_parameters()]
+        for i, n in enumerate(names):
+            a, b = eng.offsets[n]
+            shape = dict(eng.layout)[n].shape
+            state[i] = dict(step=torch.tensor(float(self.t)), exp_avg=self.m[a:b].view(shape).clone(),
+                            exp_avg_sq=self.v[a:b].view(shape).clone(), max_exp_avg_sq=self.vmax[a:b].view(shape).clone())
+        groups = []
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != "params"}
+            d.update(amsgrad=True, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                     params=list(range(len(names))))
+            groups.append(d)
+        return dict(state=state, param_groups=groups)
 
     def load_state_dict(self, sd):
-        self.t = int(sd["t"])
-        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.vmax.copy_(sd["vmax"])
-        for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update(s)
+        eng = self.eng
+        if "state" in sd:                                        # torch Adam layout (ours or the reference's)
+            names = [n for n, _ in self.model.named_parameters()]
+            if len(sd["state"]) not in (0, len(names)):
+                raise ValueError(f"optimizer state holds {len(sd['state'])} parameters, the model has {len(names)}")
+            steps = set()
+            for i, n in enumerate(names):
+                st = sd["state"].get(i)
+                if st is None:
+                    continue
+                a, b = eng.offsets[n]
+                self.m[a:b].copy_(st["exp_avg"].reshape(-1))
+                self.v[a:b].copy_(st["exp_avg_sq"].reshape(-1))
+                self.vmax[a:b].copy_(st.get("max_exp_avg_sq", st["exp_avg_sq"]).reshape(-1))
+                steps.add(int(float(st["step"])))
+            if len(steps) > 1:
+                raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused kernel keeps one")
+            self.t = steps.pop() if steps else 0
+        else:                                                    # round-1 flat layout
+            self.t = int(sd["t"])
+            self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.vmax.copy_(sd["vmax"])
+        for g, s_ in zip(self.param_groups, sd["param_groups"]):
+            g.update({k: v for k, v in s_.items() if k in ("lr", "betas", "eps", "weight_decay", "initial_lr")})
 
 
 class WarmupLR(_LRScheduler):

@@ -103,8 +103,10 @@ class EfficientTTSTrainer:
         if self.frontend is None:
             return text, text_lengths, third, third_lengths
         n_frames = int(self.frontend.frames_of(third_lengths).max())
-        frame_step = int(self.config.get("bucket_frames", 0))
-        phone_step = int(self.config.get("bucket_phones", 0))
+        # default buckets: ragged LJSpeech batches otherwise bring a new (B, T1, T2) almost every step, and every new shape
+        # allocates and zero-fills a multi-GB activation workspace (4 are cached); 0 in the YAML turns the padding off
+        frame_step = int(self.config.get("bucket_frames", 64))
+        phone_step = int(self.config.get("bucket_phones", 16))
         if frame_step > 0:
             n_frames = -(-n_frames // frame_step) * frame_step
         mel, mel_lengths = self.frontend(third, third_lengths, max_frames=n_frames)
