@@ -8,12 +8,17 @@ on both sides (:69), torch.stft n_fft 1024 / hop 256 / win 1024 / periodic hann,
 magnitude sqrt(re^2 + im^2 + 1e-9) (:75), 80-bin mel projection (:77), log(clamp(., 1e-5)) (:78, :27-28),
 and TextMelCollate's zero padding of the time axis AFTER the log (nntts/datasets/taco2_data.py:122-134).
 
-PARITY UNPINNED for the mel filterbank: the reference takes it from `librosa.filters.mel(22050, 1024, 80, 0, 8000)`
+Mel filterbank -- NOT pinned by the reference itself, pinned by an independent implementation: the reference takes it from `librosa.filters.mel(22050, 1024, 80, 0, 8000)`
 (meldataset.py:9,65; setup.py pins librosa>=0.8.0), a third-party dependency that is not vendored in
 /root/reference and not installed here.  `slaney_mel_basis` restates librosa 0.8's published algorithm
 (htk=False Slaney mel scale: linear below 1 kHz at 200/3 Hz per mel, log above with step log(6.4)/27;
 triangular filters on the FFT bin centre frequencies; norm='slaney': each filter scaled by
-2 / (f[m+2] - f[m])).  The STFT / magnitude / log part is pinned by construction: it IS torch.stft, the call
+2 / (f[m+2] - f[m])).  It is checked bin for bin (max |diff| 9.2e-10, identical support) against
+tests/golden/mel_basis_hf.npz, the same filterbank produced by Hugging Face transformers'
+`audio_utils.mel_filter_bank(norm="slaney", mel_scale="slaney")` -- the librosa.filters.mel replacement of the Whisper
+feature extractor -- by tools/gen_golden_melbasis.py (tests/test_frontend.py).  librosa's own output remains unavailable
+here, so this is a pin by a second independent implementation of the published algorithm, not by the reference's
+dependency.  The STFT / magnitude / log part is pinned by construction: it IS torch.stft, the call
 the reference makes (with return_complex=True, which the reference's torch predates).
 """
 from __future__ import annotations

@@ -32,6 +32,24 @@ def test_mel_basis_known_answers():
         assert nz.size and (np.diff(nz) == 1).all()
 
 
+def test_mel_basis_matches_independent_slaney_filterbank():
+    """f-3 pin: the oracle's filterbank against tests/golden/mel_basis_hf.npz, produced by an implementation outside this repo
+    (transformers.audio_utils.mel_filter_bank, the librosa.filters.mel stand-in of the Whisper feature extractor;
+    tools/gen_golden_melbasis.py), and against that implementation live where it is installed."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mel_basis_hf.npz"))
+    assert g["consts"].tolist() == [LO.SR, LO.N_FFT, LO.N_MELS, LO.FMIN, LO.FMAX]
+    b = LO.slaney_mel_basis()
+    assert b.shape == g["basis"].shape
+    assert np.abs(b - g["basis"]).max() < 2e-9                       # float32 rounding of weights <= 0.0265 (measured 9.2e-10)
+    assert ((b > 0) == (g["basis"] > 1e-12)).all()                   # same support, bin for bin
+    try:
+        from transformers.audio_utils import mel_filter_bank
+    except Exception:
+        return
+    live = mel_filter_bank(LO.N_FFT // 2 + 1, LO.N_MELS, LO.FMIN, LO.FMAX, LO.SR, norm="slaney", mel_scale="slaney").T
+    assert np.abs(live - g["basis"]).max() < 1e-12
+
+
 def test_oracle_matches_committed_fixture_and_naive_dft():
     g = np.load(GOLD)
     audio = torch.from_numpy(g["audio"]).float() / 32768.0

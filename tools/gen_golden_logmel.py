@@ -2,7 +2,7 @@
 (oracle/logmel_oracle.py) computes for it.  NOTE: unlike the other goldens this one does NOT come from
 the imported reference: nntts/datasets/meldataset.py imports librosa at module level (absent here) and
 calls torch.stft without return_complex (rejected by this torch), so the oracle's restatement is the
-source; its mel filterbank is "parity unpinned" (see the oracle header)."""
+source; its mel filterbank is pinned by tests/golden/mel_basis_hf.npz (tools/gen_golden_melbasis.py; see the oracle header)."""
 import os, sys
 import numpy as np
 import torch
