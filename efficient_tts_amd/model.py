@@ -359,9 +359,10 @@ class EfficientTTSCNN(torch.nn.Module):
             x_f32, x_pl = o_f32, o_pl
         return x_f32, x_pl
 
-    def _text_side(self, ws, pk, text, rs1: Rows, gap1, len1):
+    def _text_side(self, ws, pk, text, rs1: Rows, gap1, len1, on_key=None, vt: Optional[Plane] = None):
         """embed -> text encoder -> key (split-2 plane, masked), value (fp32 + plane, masked)
-        (efficient_tts.py:144-157 / :246-255)."""
+        (efficient_tts.py:144-157 / :246-255).  `on_key()` is called as soon as the key projection is enqueued (the q.k^T launch
+        of the other stream waits for that, not for the value); `vt`: also pack V^T for the alpha'.V launch here."""
         C = self.n_channels
         x_f = ws.f32("emb_f", rs1, C)
         x_p = ws.plane("emb_p", rs1, C, self.split)
@@ -374,8 +375,12 @@ class EfficientTTSCNN(torch.nn.Module):
         wk, wv = pk["key"], pk["value"]
         O.gemm(a=h_p, b_ptr=wk.ptr, ldb=wk.ld, m=rs1.rows, n=C, bias=self.text_encoder_key.bias,
                rowmask_ptr=lm if lm is not None else gap1.data_ptr(), out_plane=key_p)
+        if on_key is not None:
+            on_key()
         O.gemm(a=h_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=self.text_encoder_value.bias,
                rowmask_ptr=lm if lm is not None else gap1.data_ptr(), out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p)
+        if vt is not None:
+            O.pack_vt(val_f, vt, rs1.B, rs1.T, rs1.Tp, C)
         return key_p, val_f, val_p
 
     def _duration(self, ws, pk, rs1: Rows, val_p: Plane, gap1, out_mask_ptr, mode: int) -> torch.Tensor:
@@ -399,11 +404,13 @@ class EfficientTTSCNN(torch.nn.Module):
                                 dp.linear.bias.detach(), out_mask_ptr, mode, float(dp.offset), out, rs1.rows, C)
         return out
 
-    def _expand_decode(self, ws, pk, B, T1, rs1: Rows, rs2: Rows, val_f: F32Rows, ra_plane: Plane, len2_ptr, gap2):
-        """bmm(V^T, alpha') -> decoder -> mel head (efficient_tts.py:190-200 / :278-284)."""
+    def _expand_decode(self, ws, pk, B, T1, rs1: Rows, rs2: Rows, val_f: F32Rows, ra_plane: Plane, len2_ptr, gap2,
+                       vt: Optional[Plane] = None):
+        """bmm(V^T, alpha') -> decoder -> mel head (efficient_tts.py:190-200 / :278-284).  `vt`: V^T already packed."""
         C = self.n_channels
-        vt = ws.raw_plane("vt", B * C, T1, 2)
-        O.pack_vt(val_f, vt, B, T1, rs1.Tp, C)
+        if vt is None:
+            vt = ws.raw_plane("vt", B * C, T1, 2)
+            O.pack_vt(val_f, vt, B, T1, rs1.Tp, C)
         h_f, h_p, h_l = self._stream_in(ws, "exp", rs2)
         O.gemm(a=ra_plane, b_ptr=vt.ptr, ldb=vt.ld, m=rs2.T, n=C, batch=B, a_batch_stride=rs2.Tp * ra_plane.ld,
                b_batch_stride=C * vt.ld, rowmask_ptr=len2_ptr, rowmask_batch_stride=rs2.Tp,
@@ -482,10 +489,11 @@ class EfficientTTSCNN(torch.nn.Module):
         main = torch.cuda.current_stream(dev)
         side = self._side_stream(dev)
         side.wait_stream(main)
+        k_ready, v_ready = torch.cuda.Event(), torch.cuda.Event()
+        vt = ws.raw_plane("vt", B * C, T1, 2)
         with O.on_stream(side):
-            key_p, val_f, val_p = self._text_side(ws, pk, text, rs1, gap1, len1)  # :144-157
-            k_ready = torch.cuda.Event()
-            k_ready.record(side)
+            key_p, val_f, val_p = self._text_side(ws, pk, text, rs1, gap1, len1, on_key=lambda: k_ready.record(side), vt=vt)  # :144-157
+            v_ready.record(side)
             dur = self._duration(ws, pk, rs1, val_p, gap1, len1.data_ptr(), 0)    # :219
         mel_in = ws.plane("mel_in", rs2, self.odim, self.split)                   # :161 prenet
         O.pack_rows(speech, None, mel_in, rs2)
@@ -512,7 +520,8 @@ class EfficientTTSCNN(torch.nn.Module):
         ra_p = ws.plane("ra_p", rs2, T1, 2)
         O.reconst_alpha(e, tl, ml, float(self.sigma), ralpha, ra_p, B, T1, T2, rs2.Tp)   # :184-186
 
-        mel = self._expand_decode(ws, pk, B, T1, rs1, rs2, val_f, ra_p, len2.data_ptr(), gap2)   # :190-200
+        main.wait_event(v_ready)
+        mel = self._expand_decode(ws, pk, B, T1, rs1, rs2, val_f, ra_p, len2.data_ptr(), gap2, vt=vt)   # :190-200
         main.wait_stream(side)                                                     # duration predictor done
 
         out3 = torch.empty(3, dtype=torch.float32, device=dev)                     # :220-227

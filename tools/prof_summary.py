@@ -42,3 +42,25 @@ for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_l2"):
          "where kernel_name like '%efts::%' group by kernel_name, grid_size, counter_name order by kernel_name, grid_size")
     for r in con.execute(q):
         print(f"{short(r[0]):72s} {r[1]:28s} {r[2]:18.1f}  n={r[3]} grid={r[4]:.0f}")
+
+# ---- timeline of the last traced step: kernels in start order with the idle gap before each one on the device
+con = db("trace")
+if con and os.environ.get("TIMELINE"):
+    cur = con.execute("select * from kernels limit 1")
+    cols = [c[0] for c in cur.description]
+    print("\n## kernels view columns:", ", ".join(cols))
+    qcol = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else None)
+    rows = con.execute(f"select name, start, end, {qcol or '0'}, grid_x * grid_y * grid_z from kernels order by start").fetchall()
+    n = int(os.environ["TIMELINE"])
+    rows = rows[-n:]
+    t0 = rows[0][1]
+    print(f"\n## last {n} kernels in start order: start us (from the first), duration us, gap to the latest end so far us, {qcol}, grid, name")
+    latest = rows[0][1]
+    busy = 0.0
+    for name, s, e, q, g in rows:
+        gap = (s - latest) / 1000.0
+        print(f"{(s - t0) / 1000.0:10.1f} {(e - s) / 1000.0:8.1f} {gap:8.1f}  q={q} grid={g:8d} {short(name)[:60]}")
+        if e > latest:
+            busy += (e - max(s, latest)) / 1000.0
+            latest = e
+    print(f"span {(latest - t0) / 1000.0:.1f} us, device busy (union of kernel intervals) {busy:.1f} us")
