@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import torch
 
+from . import lib as L, ops as O
 from .model import LazyStats
 from .train import TrainEngine
 
@@ -39,7 +40,10 @@ class _FusedStep(torch.autograd.Function):
         eng = ctx.eng
         if eng.join_reduce is not None:                      # data-parallel: the bucketed all-reduce launched during the
             eng.join_reduce()                                # fused pass works in place on `flat`; join it before scaling
-        eng.flat.mul_(g_loss)                               # d(loss) scaling (1.0 in the reference loop)
+        # d(loss) scaling (1.0 in the reference loop: the kernel returns at once, no pass over the buffer)
+        gl = g_loss.detach().to(device=eng.flat.device, dtype=torch.float32).reshape(1)
+        with O.stream_scope():
+            L.check(L.load().efts_scale_unless_one(eng.flat.data_ptr(), eng.numel, gl.data_ptr(), O._stream()), "efts_scale_unless_one")
         # The per-parameter gradients ARE views of the engine's flat buffer (what the fused clip + Adam and
         # the bucketed all-reduce work on).  They are attached as `.grad` directly: handing them to
         # autograd's AccumulateGrad would clone all ~75 of them every step.  Consequence: gradients do

@@ -51,6 +51,9 @@ def run_train(a, world, rank, dev, wl):
     from .dist import DistributedEFTS
     from .optim import EftsAdam, WarmupLR
     B, T1, T2 = wl["B"], wl["T1"], wl["T2"]
+    if not getattr(a, "sign_mask", 1):
+        from . import train as _tr
+        _tr._SIGN_MIN_ROWS = 0
     torch.manual_seed(0)
     model = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, use_weighted_masking=False, sigma=0.01,
                             precision=a.precision).to(dev).train()

@@ -192,6 +192,8 @@ __global__ __launch_bounds__(256, 2) void conv5_kernel(GemmKernelArgs p) {
     const unsigned vo = trow * (unsigned)p.ldo * 4 + col * 4;
     const unsigned vb = trow * (unsigned)p.ldob + (unsigned)plane_off_hi(col, p.out_split);
     const bool has_mask = rowmask != nullptr;
+    const unsigned ld_sg = (unsigned)(p.n >> 3);
+    const __amdgpu_buffer_rsrc_t rsg = make_rsrc(p.sign ? p.sign + (long)m0 * ld_sg : nullptr, p.sign ? (long)rows_out * ld_sg : 0);
 #pragma unroll
     for (int ep = 0; ep < 2; ++ep) {
         if (pre) {
@@ -223,6 +225,14 @@ __global__ __launch_bounds__(256, 2) void conv5_kernel(GemmKernelArgs p) {
             for (int ps = 0; ps < NPS; ++ps) {
                 const int rl = ps * RPP + trow;
                 float4 v = *(const float4*)(cs + rl * 128 + c4);
+                if (p.sign) {                                // sign words of efts_abi.h `sign_mask` (see gemm_kernel)
+                    const unsigned long long b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f), b2 = __ballot(v.z > 0.f), b3 = __ballot(v.w > 0.f);
+                    if ((tid & 31) == 0) {
+                        const int sh = tid & 32;
+                        const u32x4 w = {(unsigned)(b0 >> sh), (unsigned)(b1 >> sh), (unsigned)(b2 >> sh), (unsigned)(b3 >> sh)};
+                        store_b128(w, rsg, trow * ld_sg + (unsigned)(n0 >> 7) * 16, row_of(ep, ps) * ld_sg);
+                    }
+                }
                 const u32x4 x = rres[ps % NRING];
                 const float rm = has_mask ? rmv[ps % NRING] : 1.f;
                 if (ps + NRING < NPS) request(ep, ps + NRING);

@@ -298,10 +298,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
         const unsigned vo = trow * (unsigned)p.ldo * 4 + col * 4, so = RPP * (unsigned)p.ldo * 4;
         const unsigned vb = trow * (unsigned)p.ldob + (unsigned)plane_off_hi(col, p.out_split), sb = RPP * (unsigned)p.ldob;
         const bool has_mask = rowmask != nullptr;
+        const unsigned ld_sg = (unsigned)(p.n >> 3);
+        const __amdgpu_buffer_rsrc_t rsg = make_rsrc(p.sign ? p.sign + (long)m0 * ld_sg : nullptr, p.sign ? (long)rows_out * ld_sg : 0);
 #pragma unroll
         for (int ps = 0; ps < NPS; ++ps) {
             const int rl = ps * RPP + trow;
             float4 v = *(const float4*)(cs + rl * 128 + c4);
+            if (p.sign) {                                    // (n % 128 == 0: `pre` is uniform, every lane of the wave is here)
+                const unsigned long long b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f), b2 = __ballot(v.z > 0.f), b3 = __ballot(v.w > 0.f);
+                if ((tid & 31) == 0) {                       // lanes 0 / 32: the two rows this wave sweeps
+                    const int sh = tid & 32;
+                    const u32x4 w = {(unsigned)(b0 >> sh), (unsigned)(b1 >> sh), (unsigned)(b2 >> sh), (unsigned)(b3 >> sh)};
+                    store_b128(w, rsg, trow * ld_sg + (unsigned)(n0 >> 7) * 16, ps * RPP * ld_sg);
+                }
+            }
             const u32x4 x = rres[ps];
             const float rm = has_mask ? rmv[ps] : 1.f;
             v.x = (v.x + __uint_as_float(x.x)) * rm; v.y = (v.y + __uint_as_float(x.y)) * rm;
@@ -441,7 +451,7 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     GemmKernelArgs k;
     k.a = (const char*)a->a; k.b = (const char*)a->b;
     k.bias = a->bias; k.resid = a->resid; k.rowmask = a->rowmask;
-    k.out_f32 = a->out_f32; k.out_bf16 = (char*)a->out_bf16; k.out_lo = (char*)a->out_bf16_lo;
+    k.out_f32 = a->out_f32; k.out_bf16 = (char*)a->out_bf16; k.out_lo = (char*)a->out_bf16_lo; k.sign = (char*)a->sign_mask;
     if (a->out_bf16_lo && (!a->out_bf16 || a->out_split != 1 || a->plane_act || ((uintptr_t)a->out_bf16_lo & 7)))
         return efts_fail(EFTS_EINVAL, "efts_gemm: out_bf16_lo goes with an un-activated split-1 out_bf16 plane (8-byte aligned)");
     k.lda = a->lda; k.ldb = a->ldb; k.b_tap_stride = a->b_tap_stride; k.ldr = a->ldr; k.ldo = a->ldo; k.ldob = a->ldob;
@@ -460,6 +470,8 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
                (!a->resid || ((a->ldr & 3) == 0 && ((uintptr_t)a->resid & 15) == 0 && (a->resid_batch_stride & 3) == 0)) &&
                (!a->out_bf16 || ((a->ldob & 7) == 0 && ((uintptr_t)a->out_bf16 & 7) == 0 && (a->outb_batch_stride & 7) == 0));
     k.prof = nullptr; k.dbg = 0;
+    if (a->sign_mask && (a->n % 128 || a->batch > 1 || nb2 > 1 || !k.vec_ok || ((uintptr_t)a->sign_mask & 15)))
+        return efts_fail(EFTS_EINVAL, "efts_gemm: sign_mask needs n %% 128 == 0, batch 1, 16-byte aligned output rows and mask");
     hipStream_t st = (hipStream_t)stream;
 
     // ---- which kernel.  `tiling` AUTO (0) applies the measured rules below; the explicit values exist for A/B runs and
@@ -467,6 +479,7 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     const int tiling = a->tiling;
     if (tiling < EFTS_TILING_AUTO || tiling > EFTS_TILING_RESIDENT) return efts_fail(EFTS_EINVAL, "efts_gemm: unknown tiling %d", tiling);
     const bool generic_only = a->out_bf16_lo != nullptr || nb2 > 1;      // the remainder plane / the outer batch: gemm_kernel only
+    const bool no_narrow = generic_only || a->sign_mask != nullptr;      // the sign words: gemm_kernel and conv5_kernel write them
     if (generic_only && tiling > EFTS_TILING_GENERIC) return efts_fail(EFTS_EINVAL, "efts_gemm: out_bf16_lo / batch2 need the generic tiling");
     const dim3 grid(k.mtiles * k.ntiles, a->batch, nb2);                  // one workgroup per 124 x 128 tile, 2 resident per CU
 
@@ -474,7 +487,9 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     //     resident in LDS, 32-column tiles (2.11 -> 2.03 ms per utterance, 11.1 -> 10.5 ms per batch of 8)
     const bool resident_ok = a->n <= 64 && a->nchunk == 1 && (a->taps - 1) * dil <= 64 && (a->taps == 3 || a->taps == 7 || a->taps == 11);
     if (tiling == EFTS_TILING_RESIDENT && !resident_ok) return efts_fail(EFTS_ESHAPE, "efts_gemm: the resident tiling needs n <= 64, one K chunk, taps 3 / 7 / 11");
-    if (!generic_only && resident_ok && (tiling == EFTS_TILING_RESIDENT || (tiling == EFTS_TILING_AUTO && a->m >= 8 * R32_WIN))) {
+    if (no_narrow && !generic_only && (tiling == EFTS_TILING_NARROW || tiling == EFTS_TILING_RESIDENT))
+        return efts_fail(EFTS_EINVAL, "efts_gemm: sign_mask needs the generic or wide tiling");
+    if (!no_narrow && resident_ok && (tiling == EFTS_TILING_RESIDENT || (tiling == EFTS_TILING_AUTO && a->m >= 8 * R32_WIN))) {
         GemmKernelArgs kr = k;
         kr.bm = R32_WIN - (a->taps - 1) * dil;
         kr.mtiles = (a->m + kr.bm - 1) / kr.bm;
@@ -486,7 +501,7 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     //     at one utterance: 110): such a launch is bound by the per-workgroup step latency, and 64-column tiles double the
     //     number of workgroups that overlap (one per CU is the measured threshold; two was slower for the text side)
     const bool few = (long)k.mtiles * k.ntiles * a->batch < (long)efts_num_cus() && a->n > 64;
-    if (!generic_only && (tiling == EFTS_TILING_NARROW || (tiling == EFTS_TILING_AUTO && (a->n <= 64 || few)))) {
+    if (!no_narrow && (tiling == EFTS_TILING_NARROW || (tiling == EFTS_TILING_AUTO && (a->n <= 64 || few)))) {
         GemmKernelArgs kn = k;
         kn.ntiles = a->n <= 32 ? 1 : (a->n + 63) / 64;
         if (launch_narrow_any(a->split, a->n <= 32 ? 32 : 64, a->taps, dim3(k.mtiles * kn.ntiles, a->batch, 1), st, kn)) return efts_check_launch("efts_gemm");

@@ -26,6 +26,7 @@ struct GemmKernelArgs {
     float* out_f32;
     char* out_bf16;
     char* out_lo;               // out_split 1 only: separate plane for the bf16 remainder (generic gemm_kernel only)
+    char* sign;                 // sign words of the activated outputs (efts_abi.h `sign_mask`), row stride n / 8 bytes, or null
     long lda, ldb, b_tap_stride, ldr, ldo, ldob;
     long a_bs, b_bs, r_bs, m_bs, o_bs, ob_bs;
     long a_bs2, b_bs2, o_bs2;   // outer batch (blockIdx.z)

@@ -70,6 +70,7 @@ __global__ void loss_bwd_kernel(const float* __restrict__ mp, long ldm, const fl
 //   mode 1 (LeakyReLU residual layer y = x + leaky(z)): z > 0  <=>  y - x > 0
 //   mode 2 (ReLU, h = relu(z))                        : h > 0
 //   mode 3 (LeakyReLU, no residual, out = leaky(z))   : out > 0
+//   mode 4 (LeakyReLU, sign words from the forward)    : y points at efts_gemm's `sign_mask` words (row stride c / 8 bytes)
 //   mode 0 : identity
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
@@ -97,6 +98,11 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
                 const float4 yv = *(const float4*)(y + o), xv = *(const float4*)(x + o);
                 m.x = (yv.x - xv.x) > 0.f ? 1.f : slope; m.y = (yv.y - xv.y) > 0.f ? 1.f : slope;
                 m.z = (yv.z - xv.z) > 0.f ? 1.f : slope; m.w = (yv.w - xv.w) > 0.f ? 1.f : slope;
+            } else if (mode == 4) {
+                // 16 bytes per row and 128-column group: word u, bit q = column 4 q + u of the group (this thread: q)
+                const uint4 w = *(const uint4*)((const char*)y + (long)r * (c >> 3) + blockIdx.y * 16);
+                m.x = (w.x >> q) & 1u ? 1.f : slope; m.y = (w.y >> q) & 1u ? 1.f : slope;
+                m.z = (w.z >> q) & 1u ? 1.f : slope; m.w = (w.w >> q) & 1u ? 1.f : slope;
             } else if (mode == 2 || mode == 3) {
                 const float4 yv = *(const float4*)(y + o);
                 const float neg = mode == 2 ? 0.f : slope;
@@ -565,6 +571,16 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restric
     s = block_sum256t(s, sh);
     if (threadIdx.x == 0) out[0] += s;
 }
+// x *= *s unless *s == 1 (the d(loss) factor autograd hands to backward(): 1 in the reference loop, where the pass over the
+// 82 MB gradient buffer is skipped on the device without a host round trip)
+__global__ __launch_bounds__(256) void scale_unless_one_kernel(float* __restrict__ x, long n, const float* __restrict__ s) {
+    const float sv = *s;
+    if (sv == 1.f) return;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        if (i + 3 < n) { float4 v = *(float4*)(x + i); v.x *= sv; v.y *= sv; v.z *= sv; v.w *= sv; *(float4*)(x + i) = v; }
+        else for (long k = i; k < n; ++k) x[k] *= sv;
+    }
+}
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, float* __restrict__ vmax, long n,
                                                    const float* __restrict__ sumsq, float max_norm, float gscale, float lr,
@@ -750,7 +766,8 @@ extern "C" int efts_loss_bwd(const float* mel_pred, int64_t ldm, const float* sp
 extern "C" int efts_act_bwd(const float* g, const float* y, const float* x, const float* rowmask, float slope, int32_t mode, float* dz,
                             void* plane, int64_t ld_plane, int32_t split, float* dbias, int32_t rows, int32_t c, void* stream) {
     if (!g || (!dz && !plane)) return efts_fail(EFTS_EINVAL, "efts_act_bwd: null pointer");
-    if (c % 4 || (mode == 1 && (!x || !y)) || ((mode == 2 || mode == 3) && !y)) return efts_fail(EFTS_EINVAL, "efts_act_bwd: bad mode/shape");
+    if (c % 4 || (mode == 1 && (!x || !y)) || ((mode == 2 || mode == 3) && !y) || (mode == 4 && (!y || c % 128 || ((uintptr_t)y & 15))) || mode < 0 || mode > 4)
+        return efts_fail(EFTS_EINVAL, "efts_act_bwd: bad mode/shape");
     hipLaunchKernelGGL(act_bwd_kernel, dim3((rows + 63) / 64, (c + 127) / 128), dim3(256), 0, ST, g, y, x, rowmask, slope, mode, dz, (char*)plane, (long)ld_plane,
                        split, dbias, rows, c);
     return efts_check_launch("efts_act_bwd");
@@ -837,6 +854,13 @@ extern "C" int efts_sumsq(const float* g, int64_t n, float* out1, void* workspac
     hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, ST, g, (long)n, (float*)workspace);
     hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, ST, (const float*)workspace, 1024, out1);
     return efts_check_launch("efts_sumsq");
+}
+
+extern "C" int efts_scale_unless_one(float* x, int64_t n, const float* scale, void* stream) {
+    if (!x || !scale || n <= 0) return efts_fail(EFTS_EINVAL, "efts_scale_unless_one: bad arguments");
+    if ((uintptr_t)x & 15) return efts_fail(EFTS_EALIGN, "efts_scale_unless_one: buffer must be 16-byte aligned");
+    hipLaunchKernelGGL(scale_unless_one_kernel, dim3(2048), dim3(256), 0, ST, x, (long)n, scale);
+    return efts_check_launch("efts_scale_unless_one");
 }
 
 extern "C" int efts_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, const float* sumsq, float max_norm,

@@ -37,7 +37,7 @@ class GemmArgs(C.Structure):
         ("out_split", i32), ("batch2", i32),
         ("a_batch2_stride", i64), ("b_batch2_stride", i64), ("out_batch2_stride", i64),
         ("dilation", i32), ("plane_act", i32), ("plane_slope", f32),
-        ("out_bf16_lo", vp), ("tiling", i32),
+        ("out_bf16_lo", vp), ("tiling", i32), ("sign_mask", vp),
     ]
 
 
@@ -90,6 +90,7 @@ _SIGS = {
     "efts_embed_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "efts_sumsq_workspace_bytes": (C.c_size_t, []),
     "efts_sumsq": (i32, [vp, i64, vp, vp, vp]),
+    "efts_scale_unless_one": (i32, [vp, i64, vp, vp]),
     "efts_adam_amsgrad": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
     # log-mel front-end
     "efts_frame_pack": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]),

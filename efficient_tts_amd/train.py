@@ -26,6 +26,9 @@ def _ptr(t):
 
 
 _WGRAD_TN_SPLITS = int(os.environ.get("EFTS_WGRAD_TN_SPLITS", "8"))     # K-splits of the direct (row-major) k5 wgrad; 0 disables it
+_SIGN_MIN_ROWS = 16384       # row spaces from here on: the forward convolutions of the stacks write the activation's sign words
+                             # (efts_gemm `sign_mask`) and efts_act_bwd reads those instead of y and x in fp32 (14 -> 6 B per element);
+                             # shorter ones (the text side) keep the narrow tiling, which does not write them.  0 = never
 _WGRAD_WGS = int(os.environ.get("EFTS_WGRAD_WGS", "480"))   # split-K target: 480 workgroups per wgrad launch measured best (6.30 vs 6.60 ms/step at 640)
 
 
@@ -178,9 +181,11 @@ class TrainEngine:
             w = pk[f"{blk}.{i}"]
             o_f = ws.f32(f"T{tag}_f{i}", rs, C)
             o_p = ws.plane(f"T{tag}_p{i}", rs, C, last_split if last else m.split)
+            sg = ws.tensor(f"T{tag}_sg{i}", (rs.rows, C // 8), torch.uint8) if (0 < _SIGN_MIN_ROWS <= rs.rows and C % 128 == 0) else None
             O.gemm(a=x_p, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=5, m=rs.rows, n=C, act=L.ACT_LEAKY, slope=m.slope,
-                   bias=layer.conv[0].bias, resid_ptr=x_f.ptr, ldr=C, rowmask_ptr=gap_ptr, out_f32_ptr=o_f.ptr, ldo=C, out_plane=o_p)
-            saved.append((x_f, o_f, x_p))
+                   bias=layer.conv[0].bias, resid_ptr=x_f.ptr, ldr=C, rowmask_ptr=gap_ptr, out_f32_ptr=o_f.ptr, ldo=C, out_plane=o_p,
+                   sign_mask_ptr=None if sg is None else sg.data_ptr())
+            saved.append((x_f, o_f, x_p, sg))
             x_f, x_p = o_f, o_p
         return x_f, x_p, saved
 
@@ -189,7 +194,7 @@ class TrainEngine:
         m, C = self.m, self.m.n_channels
         layers = getattr(m, blk).layers
         for i in reversed(range(len(layers))):
-            x_f, y_f, x_pl = saved[i]
+            x_f, y_f, x_pl, sg = saved[i]
             conv = layers[i].conv[0]
             pre = f"{blk}.layers.{i}.conv.0."
             dz_p = ws.plane(f"B{tag}_dzp", rs, C, m.split)
@@ -197,7 +202,10 @@ class TrainEngine:
             # the direct wgrad and the dgrad both read dZ as the bf16 plane: its fp32 copy is only written for the
             # transposed-plane path
             dz_f = None if direct else ws.f32(f"B{tag}_dz", rs, C)
-            self._act_bwd(G.ptr, y_f.ptr, x_f.ptr, gap_ptr, 1, dz_f, dz_p, self.g[pre + "bias"], rs.rows, C)
+            if sg is not None:
+                self._act_bwd(G.ptr, sg.data_ptr(), None, gap_ptr, 4, dz_f, dz_p, self.g[pre + "bias"], rs.rows, C)
+            else:
+                self._act_bwd(G.ptr, y_f.ptr, x_f.ptr, gap_ptr, 1, dz_f, dz_p, self.g[pre + "bias"], rs.rows, C)
             wn = hasattr(conv, "weight_g")
             v_, g_ = (conv.weight_v.detach(), conv.weight_g.detach()) if wn else (None, None)
             dw_, dg_ = (self.g[pre + "weight_v"], self.g[pre + "weight_g"]) if wn else (self.g[pre + "weight"], None)

@@ -117,6 +117,12 @@ typedef struct efts_gemm_args {
     /* which of the (bit-identical) kernels runs: EFTS_TILING_AUTO picks by shape; the explicit values are for A/B timing and
      * for the equality tests between the kernels.  An explicit tiling the shape does not allow is an error. */
     int32_t tiling;
+    /* training forward of a LeakyReLU / ReLU layer: the sign of every activated output BEFORE the residual add, as bit words
+     * for efts_act_bwd mode 4 (instead of keeping y and x in fp32 for the backward: 1/8 B instead of 8 B per element read
+     * there).  Row stride n / 8 bytes; within a row, 16 bytes per 128-column group: word u (0..3), bit q (0..31) = column
+     * 128 * group + 4 * q + u is positive.  Needs n % 128 == 0, batch 1, 16-byte aligned fp32 / plane rows (the vector epilogue),
+     * and runs on the generic or wide tiling only.  NULL: not written. */
+    void* sign_mask;
 } efts_gemm_args;
 
 #define EFTS_TILING_AUTO 0
@@ -295,7 +301,9 @@ int efts_loss_bwd(const float* mel_pred, int64_t ldm, const float* speech, const
                   float* dmel, void* dmel_plane, int64_t ld_plane, int32_t split, float* ddur, int32_t B, int32_t T1,
                   int32_t T1p, int32_t T2, int32_t T2p, int32_t odim, void* stream);
 /* dZ = G * act'(.) * rowmask, bias grad += column sums.  mode 1: residual LeakyReLU layer
- * (sign from y - x); 2: ReLU (sign of y); 3: LeakyReLU without residual (sign of y); 0: identity. */
+ * (sign from y - x); 2: ReLU (sign of y); 3: LeakyReLU without residual (sign of y); 0: identity;
+ * 4: LeakyReLU with the sign words efts_gemm wrote (`sign_mask` of the forward launch) passed as y (row stride c / 8 bytes,
+ * c % 128 == 0), x unused. */
 int efts_act_bwd(const float* g, const float* y, const float* x, const float* rowmask, float slope, int32_t mode,
                  float* dz, void* plane, int64_t ld_plane, int32_t split, float* dbias, int32_t rows, int32_t c,
                  void* stream);
@@ -341,6 +349,9 @@ int efts_embed_bwd(const int64_t* ids, const float* g, float* dtable, int32_t B,
  * efts_adam_amsgrad scales g by gscale * min(1, max_norm / (gscale*sqrt(sumsq) + 1e-6)). */
 size_t efts_sumsq_workspace_bytes(void);
 int efts_sumsq(const float* g, int64_t n, float* out1, void* workspace, void* stream);
+/* x[0..n) *= *scale (device scalar), skipped on the device when *scale == 1: the `grad_output` factor of
+ * loss.backward() on the flat gradient buffer (torch autograd semantics of nntts/trainers/efficient_tts_trainer.py:150). */
+int efts_scale_unless_one(float* x, int64_t n, const float* scale, void* stream);
 int efts_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, const float* sumsq,
                       float max_norm, float gscale, float lr, float beta1, float beta2, float eps, float weight_decay,
                       int32_t step, void* stream);
