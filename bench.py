@@ -42,7 +42,8 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
     ap.add_argument("--workload", default="fwd64", choices=["fwd64", "fwd16_long", "train32", "infer_lj", "infer64", "logmel64", "vocoder", "vocoder8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sign-mask", type=int, default=1, help="train32 A/B: 0 = efts_act_bwd reads y and x in fp32 instead of the forward's sign words")
+    ap.add_argument("--train-set", action="append", default=[], metavar="NAME=INT",
+                    help="train32 A/B runs: set a switch of efficient_tts_amd.train (_SIGN_MIN_ROWS=0, _BIAS_PARTS=0, ...)")
     ap.add_argument("--dp-algo", default="allreduce", choices=["allreduce", "rs_ag"], help="train32, N > 1: per-bucket all_reduce, or reduce_scatter + all_gather (point-to-point xGMI)")
     ap.add_argument("--side-stream", type=int, default=1, help="0: text-length work on the main stream (A/B)")
     ap.add_argument("--resconv", type=int, default=1, help="0: residual stacks on efts_gemm + fp32 stream (A/B)")

@@ -51,9 +51,11 @@ def run_train(a, world, rank, dev, wl):
     from .dist import DistributedEFTS
     from .optim import EftsAdam, WarmupLR
     B, T1, T2 = wl["B"], wl["T1"], wl["T2"]
-    if not getattr(a, "sign_mask", 1):
+    for kv in getattr(a, "train_set", []):
         from . import train as _tr
-        _tr._SIGN_MIN_ROWS = 0
+        k, v = kv.split("=")
+        assert hasattr(_tr, k), f"efficient_tts_amd.train has no switch {k}"
+        setattr(_tr, k, int(v))
     torch.manual_seed(0)
     model = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, use_weighted_masking=False, sigma=0.01,
                             precision=a.precision).to(dev).train()

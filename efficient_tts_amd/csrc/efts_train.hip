@@ -76,7 +76,7 @@ __global__ void loss_bwd_kernel(const float* __restrict__ mp, long ldm, const fl
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
                                                       const float* __restrict__ x, const float* __restrict__ rowmask,
                                                       float slope, int mode, float* __restrict__ dz, char* __restrict__ plane,
-                                                      long ldp, int split, float* __restrict__ dbias, int rows, int c) {
+                                                      long ldp, int split, float* __restrict__ dbias, int bias_parts, int rows, int c) {
     // block: 64 rows x 128 columns (blockIdx.y = column group); 256 threads = 32 column quads x 8
     // rows in flight.  Column sums are combined in LDS first: ONE global atomic per column per
     // block (same-address atomics serialise at L2 and were the bottleneck of the first version).
@@ -122,7 +122,10 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
                 float t = 0.f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) t += colsum[k][threadIdx.x];
-                atomicAdd(dbias + cbase + threadIdx.x, t);
+                // bias_parts: dbias is a [row blocks][c] workspace of per-block sums (plain stores, summed by efts_wgrad_reduce_bias):
+                // at mel length the 400 same-address atomics per column cost ~8 us of a 22 us launch
+                if (bias_parts) dbias[(long)blockIdx.x * c + cbase + threadIdx.x] = t;
+                else atomicAdd(dbias + cbase + threadIdx.x, t);
             }
         }
     }
@@ -170,12 +173,20 @@ __global__ __launch_bounds__(256) void pack_t_kernel(const float* __restrict__ x
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, const float* __restrict__ v,
                                                            const float* __restrict__ g, float* __restrict__ dw_or_dv,
-                                                           float* __restrict__ dg, int cout, int cin, int taps) {
+                                                           float* __restrict__ dg, int cout, int cin, int taps,
+                                                           const float* __restrict__ bias_part, int nparts, float* __restrict__ dbias) {
     extern __shared__ float dw_s[];                    // [cin * taps]
     __shared__ float sh[4];
     const int co = blockIdx.x;
     const int n = cin * taps;
     float dot = 0.f, nn = 0.f;
+    if (bias_part) {                                   // bias gradient of this output channel: the row-block sums efts_act_bwd left, fixed order
+        float b = 0.f;
+        for (int i = threadIdx.x; i < nparts; i += 256) b += bias_part[(long)i * cout + co];
+        b = block_sum256t(b, sh);
+        if (threadIdx.x == 0) dbias[co] += b;
+        __syncthreads();
+    }
     if ((cin & 3) == 0 && (((uintptr_t)part) & 15) == 0) {
         // float4 along ci, one (tap, 4 ci) item per thread and pass, the K-split sum unrolled by 4:
         // 4 independent 16-byte loads in flight per thread (the scalar version was latency-bound at ~2 TB/s)
@@ -766,10 +777,13 @@ extern "C" int efts_loss_bwd(const float* mel_pred, int64_t ldm, const float* sp
 extern "C" int efts_act_bwd(const float* g, const float* y, const float* x, const float* rowmask, float slope, int32_t mode, float* dz,
                             void* plane, int64_t ld_plane, int32_t split, float* dbias, int32_t rows, int32_t c, void* stream) {
     if (!g || (!dz && !plane)) return efts_fail(EFTS_EINVAL, "efts_act_bwd: null pointer");
-    if (c % 4 || (mode == 1 && (!x || !y)) || ((mode == 2 || mode == 3) && !y) || (mode == 4 && (!y || c % 128 || ((uintptr_t)y & 15))) || mode < 0 || mode > 4)
+    const int parts = mode & EFTS_ACT_BWD_BIAS_PARTS ? 1 : 0;
+    mode &= ~EFTS_ACT_BWD_BIAS_PARTS;
+    if (c % 4 || (mode == 1 && (!x || !y)) || ((mode == 2 || mode == 3) && !y) || (mode == 4 && (!y || c % 128 || ((uintptr_t)y & 15))) || mode < 0 || mode > 4 ||
+        (parts && !dbias))
         return efts_fail(EFTS_EINVAL, "efts_act_bwd: bad mode/shape");
     hipLaunchKernelGGL(act_bwd_kernel, dim3((rows + 63) / 64, (c + 127) / 128), dim3(256), 0, ST, g, y, x, rowmask, slope, mode, dz, (char*)plane, (long)ld_plane,
-                       split, dbias, rows, c);
+                       split, dbias, parts, rows, c);
     return efts_check_launch("efts_act_bwd");
 }
 
@@ -783,12 +797,19 @@ extern "C" int efts_pack_t(const float* x, int64_t ldx, void* plane, int64_t ld_
     return efts_check_launch("efts_pack_t");
 }
 
+extern "C" int efts_wgrad_reduce_bias(const float* part, int32_t nsplit, const float* v, const float* g, float* dw_or_dv, float* dg, int32_t cout,
+                                      int32_t cin, int32_t taps, const float* bias_part, int32_t nparts, float* dbias, void* stream) {
+    if (!part || !dw_or_dv || (g && (!v || !dg))) return efts_fail(EFTS_EINVAL, "efts_wgrad_reduce: null pointer");
+    if (bias_part && (!dbias || nparts < 1)) return efts_fail(EFTS_EINVAL, "efts_wgrad_reduce_bias: bias_part needs dbias and nparts >= 1");
+    if ((size_t)cin * taps * 4 > 60000) return efts_fail(EFTS_ESHAPE, "efts_wgrad_reduce: cin*taps too large for LDS");
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cout), dim3(256), (size_t)cin * taps * sizeof(float), ST, part, nsplit, v, g, dw_or_dv, dg, cout, cin, taps,
+                       bias_part, nparts, dbias);
+    return efts_check_launch("efts_wgrad_reduce");
+}
+
 extern "C" int efts_wgrad_reduce(const float* part, int32_t nsplit, const float* v, const float* g, float* dw_or_dv, float* dg, int32_t cout,
                                  int32_t cin, int32_t taps, void* stream) {
-    if (!part || !dw_or_dv || (g && (!v || !dg))) return efts_fail(EFTS_EINVAL, "efts_wgrad_reduce: null pointer");
-    if ((size_t)cin * taps * 4 > 60000) return efts_fail(EFTS_ESHAPE, "efts_wgrad_reduce: cin*taps too large for LDS");
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cout), dim3(256), (size_t)cin * taps * sizeof(float), ST, part, nsplit, v, g, dw_or_dv, dg, cout, cin, taps);
-    return efts_check_launch("efts_wgrad_reduce");
+    return efts_wgrad_reduce_bias(part, nsplit, v, g, dw_or_dv, dg, cout, cin, taps, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int efts_layernorm_bwd(const float* x, const float* gamma, const float* beta, float eps, const float* dy, const float* ddur,

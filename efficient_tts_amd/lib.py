@@ -18,6 +18,7 @@ GUARD_LO = 8
 GUARD_HI = 144
 TILE_M = 128
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+ACT_BWD_BIAS_PARTS = 16
 TILING_AUTO, TILING_GENERIC, TILING_WIDE, TILING_NARROW, TILING_RESIDENT = 0, 1, 2, 3, 4
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -81,6 +82,7 @@ _SIGS = {
     "efts_act_bwd": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, i64, i32, vp, i32, i32, vp]),
     "efts_pack_t": (i32, [vp, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, vp]),
     "efts_wgrad_reduce": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "efts_wgrad_reduce_bias": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp, vp]),
     "efts_wgrad_tn": (i32, [vp, i64, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp]),
     "efts_layernorm_bwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, i32, i32, f32, C.c_uint32, vp]),
     "efts_alpha_bwd": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, vp]),

@@ -29,6 +29,7 @@ _WGRAD_TN_SPLITS = int(os.environ.get("EFTS_WGRAD_TN_SPLITS", "8"))     # K-spli
 _SIGN_MIN_ROWS = 16384       # row spaces from here on: the forward convolutions of the stacks write the activation's sign words
                              # (efts_gemm `sign_mask`) and efts_act_bwd reads those instead of y and x in fp32 (14 -> 6 B per element);
                              # shorter ones (the text side) keep the narrow tiling, which does not write them.  0 = never
+_BIAS_PARTS = 1              # direct-wgrad layers: bias gradient as per-row-block sums finished by the wgrad reduction (0: atomics in act_bwd)
 _WGRAD_WGS = int(os.environ.get("EFTS_WGRAD_WGS", "480"))   # split-K target: 480 workgroups per wgrad launch measured best (6.30 vs 6.60 ms/step at 640)
 
 
@@ -162,14 +163,16 @@ class TrainEngine:
         L.check(_lib().efts_wgrad_reduce(part.data_ptr(), S, _ptr(v), _ptr(g), out_dw.data_ptr(), _ptr(out_dg), cout, cin, taps,
                                          O._stream()), "efts_wgrad_reduce")
 
-    def _wgrad_tn(self, ws, dz_p: Plane, x_p: Plane, cout, cin, rows, v, g, out_dw, out_dg):
-        """k5 wgrad straight from the row-major bf16 planes (csrc/efts_wgrad.hip): no transposed copies"""
+    def _wgrad_tn(self, ws, dz_p: Plane, x_p: Plane, cout, cin, rows, v, g, out_dw, out_dg, bias_part=None, dbias=None):
+        """k5 wgrad straight from the row-major bf16 planes (csrc/efts_wgrad.hip): no transposed copies.
+        bias_part: the [row blocks][cout] column sums efts_act_bwd left; the reduction adds them into dbias"""
         S = _WGRAD_TN_SPLITS
         part = ws.get(("part", self._ws_tag, 5, S, cout, cin), lambda: torch.empty(5, S, cout, cin, device=self.dev))
         L.check(_lib().efts_wgrad_tn(dz_p.ptr, dz_p.ld, x_p.ptr, x_p.ld, part.data_ptr(), rows, cout, cin, 5, S, dz_p.split, O._stream()),
                 "efts_wgrad_tn")
-        L.check(_lib().efts_wgrad_reduce(part.data_ptr(), S, _ptr(v), _ptr(g), out_dw.data_ptr(), _ptr(out_dg), cout, cin, 5,
-                                         O._stream()), "efts_wgrad_reduce")
+        L.check(_lib().efts_wgrad_reduce_bias(part.data_ptr(), S, _ptr(v), _ptr(g), out_dw.data_ptr(), _ptr(out_dg), cout, cin, 5,
+                                              _ptr(bias_part), 0 if bias_part is None else bias_part.shape[0], _ptr(dbias), O._stream()),
+                "efts_wgrad_reduce_bias")
 
     # ------------------------------------------------------------------ forward with saved activations
     def _stack_fwd(self, ws, tag, blk, pk, rs, x_f, x_p, gap_ptr, last_split):
@@ -202,15 +205,19 @@ class TrainEngine:
             # the direct wgrad and the dgrad both read dZ as the bf16 plane: its fp32 copy is only written for the
             # transposed-plane path
             dz_f = None if direct else ws.f32(f"B{tag}_dz", rs, C)
+            # direct path: the bias gradient leaves act_bwd as per-row-block sums and is finished by the wgrad reduction
+            # (no same-address atomics: ~8 of 22 us per launch at mel length)
+            bp = ws.tensor(f"B{tag}_bp", ((rs.rows + 63) // 64, C)) if (direct and _BIAS_PARTS) else None
+            db, parts = (bp, L.ACT_BWD_BIAS_PARTS) if bp is not None else (self.g[pre + "bias"], 0)
             if sg is not None:
-                self._act_bwd(G.ptr, sg.data_ptr(), None, gap_ptr, 4, dz_f, dz_p, self.g[pre + "bias"], rs.rows, C)
+                self._act_bwd(G.ptr, sg.data_ptr(), None, gap_ptr, 4 | parts, dz_f, dz_p, db, rs.rows, C)
             else:
-                self._act_bwd(G.ptr, y_f.ptr, x_f.ptr, gap_ptr, 1, dz_f, dz_p, self.g[pre + "bias"], rs.rows, C)
+                self._act_bwd(G.ptr, y_f.ptr, x_f.ptr, gap_ptr, 1 | parts, dz_f, dz_p, db, rs.rows, C)
             wn = hasattr(conv, "weight_g")
             v_, g_ = (conv.weight_v.detach(), conv.weight_g.detach()) if wn else (None, None)
             dw_, dg_ = (self.g[pre + "weight_v"], self.g[pre + "weight_g"]) if wn else (self.g[pre + "weight"], None)
             if direct:
-                self._wgrad_tn(ws, dz_p, x_pl, C, C, rs.rows, v_, g_, dw_, dg_)
+                self._wgrad_tn(ws, dz_p, x_pl, C, C, rs.rows, v_, g_, dw_, dg_, bias_part=bp, dbias=self.g[pre + "bias"])
             else:
                 self._wgrad(ws, dz_f.ptr, C, x_f.ptr, C, C, 5, rs.rows, v_, g_, dw_, dg_)
             wt = self.wt[f"{blk}.{i}"]

@@ -303,7 +303,10 @@ int efts_loss_bwd(const float* mel_pred, int64_t ldm, const float* speech, const
 /* dZ = G * act'(.) * rowmask, bias grad += column sums.  mode 1: residual LeakyReLU layer
  * (sign from y - x); 2: ReLU (sign of y); 3: LeakyReLU without residual (sign of y); 0: identity;
  * 4: LeakyReLU with the sign words efts_gemm wrote (`sign_mask` of the forward launch) passed as y (row stride c / 8 bytes,
- * c % 128 == 0), x unused. */
+ * c % 128 == 0), x unused.
+ * mode | EFTS_ACT_BWD_BIAS_PARTS: dbias is a [ceil(rows / 64)][c] workspace that receives one column sum per 64-row block
+ * (plain stores, overwritten) instead of atomic adds into the gradient; efts_wgrad_reduce_bias adds them up. */
+#define EFTS_ACT_BWD_BIAS_PARTS 16
 int efts_act_bwd(const float* g, const float* y, const float* x, const float* rowmask, float slope, int32_t mode,
                  float* dz, void* plane, int64_t ld_plane, int32_t split, float* dbias, int32_t rows, int32_t c,
                  void* stream);
@@ -323,6 +326,11 @@ int efts_wgrad_tn(const void* dz_plane, int64_t ldz, const void* x_plane, int64_
  * (dv -> dw_or_dv, dg) of w = g v / ||v|| */
 int efts_wgrad_reduce(const float* part, int32_t nsplit, const float* v, const float* g, float* dw_or_dv, float* dg,
                       int32_t cout, int32_t cin, int32_t taps, void* stream);
+/* the same, plus the bias gradient of the layer: dbias[co] += sum_i bias_part[i][co], i < nparts (the workspace efts_act_bwd
+ * fills in EFTS_ACT_BWD_BIAS_PARTS mode), in a fixed order */
+int efts_wgrad_reduce_bias(const float* part, int32_t nsplit, const float* v, const float* g, float* dw_or_dv, float* dg,
+                           int32_t cout, int32_t cin, int32_t taps, const float* bias_part, int32_t nparts, float* dbias,
+                           void* stream);
 /* backward of [ReLU ->] LayerNorm [-> Linear(c,1)] (duration_predictor.py:57-77); accumulates
  * dgamma, dbeta, conv-bias grad (dbias), and with ddur != NULL the Linear's dw, db. */
 int efts_layernorm_bwd(const float* x, const float* gamma, const float* beta, float eps, const float* dy,
