@@ -8,9 +8,10 @@
 // Why a kernel of its own: at 64 x 800 frames this layer is 134 GFLOP and ~80 % of the forward.
 // The general contraction (efts_gemm.hip) runs two independent 4-wave workgroups per CU which collide on the matrix
 // pipe and pay their HBM-bound epilogues in lock-step.  Here:
-//   * ONE persistent 8-wave workgroup per CU, one barrier domain: 2 x 4 waves of (32*NI) x 64 outputs each on a
-//     (64*NI) x 256 tile, NI = 1..4 picked per tile.  A 256-column weight tile (32 KiB) feeds 8 waves, so the LDS-DMA
-//     line requests per MFMA are half those of a 128-column tile.
+//   * ONE persistent 8-wave workgroup per CU, one barrier domain: 2 x 4 waves on a (32*h) x 256 tile, h = 2..8 half units
+//     picked per tile; the upper wave row takes ceil(h/2) 32-row blocks, the lower one floor(h/2) (each SIMD hosts one wave
+//     of either row, so odd heights still load the four matrix pipes equally).  A 256-column weight tile (32 KiB) feeds 8
+//     waves, so the LDS-DMA line requests per MFMA are half those of a 128-column tile.
 //   * LDS = two 256-row windows (double-buffered: the next K chunk's window lands while the current one is read at its
 //     5 tap shifts) + a 3-stage ring of 32 KiB weight tiles = exactly 160 KiB.  All operands arrive by LDS-DMA issued
 //     from inline asm with counted s_waitcnt vmcnt(N); one s_barrier per (chunk, tap) step.
@@ -60,7 +61,7 @@ struct RcSched {
     int ncls;                                // workgroup group g belongs to class g % ncls
     int rows[RC_MAXCLS];                     // output rows a group of this class owns
     int ntile[RC_MAXCLS];
-    unsigned char ni[RC_MAXCLS][RC_MAXTILES];   // tile heights in units of 64 window rows (a tile yields 64 * ni - 4 rows)
+    unsigned char ni[RC_MAXCLS][RC_MAXTILES];   // tile heights in half units of 32 window rows, 2..8 (a tile yields 32 * h - 4 rows)
 };
 
 struct RcArgs {
@@ -103,44 +104,48 @@ struct RcCtx {
     int wpar;               // window buffer of the next tile's chunk 0
 };
 
-// window pieces of one tile: piece P = q * 8 + wave covers window rows 8P .. 8P+7 (lane l: row 8P + l/8, physical slot l%8);
-// rows past the guard band after the matrix are clamped (their outputs are never stored)
-template <int NI>
-__device__ __forceinline__ void rc_window_offsets(const RcArgs& p, const RcCtx& c, int m0, unsigned (&voa)[NI]) {
-    const int rmax = p.m + 143 - (m0 - 2);
-#pragma unroll
-    for (int q = 0; q < NI; ++q) {
-        const int r = (q * 8 + c.wave) * 8 + (c.lane >> 3);
-        const int sl = (c.lane & 7) ^ ((r >> 1) & 7);
-        voa[q] = (unsigned)((r < rmax ? r : rmax) * (int)p.lda + (sl << 4));
-    }
-}
+// window pieces of one tile of h half units: piece P = q * 8 + wave, P < 4 h, covers window rows 8P .. 8P+7 (lane l: row 8P + l/8,
+// physical slot l%8); rows past the guard band after the matrix are clamped (their outputs are never stored)
+__device__ __forceinline__ int rc_pieces(int h, int wave) { return (4 * h - wave + 7) >> 3; }
 
-// One (64 * NI) x 256 tile at output row m0: main loop over (chunk, tap) steps, then the fused epilogue.
+// One (32 * h) x 256 tile at output row m0, as seen by one wave: NI = the 32-row blocks of its wave row (ceil(h/2) for wm = 0,
+// floor(h/2) for wm = 1; waves of the two rows run different instantiations with the same barrier sequence).  Main loop over
+// (chunk, tap) steps, then the fused epilogue.
 // The operand streams are CONTINUOUS across the tiles of a workgroup: its weights do not depend on the tile (n0 is fixed), so
 // the weight requests two steps ahead simply wrap into the next tile's steps 0 and 1, and the next tile's first window
-// (rows m1, height ni1; 0 = no next tile) is requested at the first tap of this tile's last chunk.  On entry the window of
+// (rows m1, height h1; 0 = no next tile) is requested at the first tap of this tile's last chunk.  On entry the window of
 // chunk 0 and the weights of steps 0 and 1 are therefore in flight or landed.
 template <int SPLIT, int NI>
-__device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int rows_out, int m1, int ni1) {
+__device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int h, int rows_out, int m1, int h1) {
     constexpr int TAPS = 5;
     char* const smem = c.smem;
     const int lane = c.lane, wave = c.wave, lrow = c.lrow, lhalf = c.lhalf, wm = c.wm, wn = c.wn;
+    const int row0w = wm ? 32 * ((h + 1) >> 1) : 0;         // first tile row of this wave row
+    const int nq = rc_pieces(h, wave), nq1 = rc_pieces(h1, wave);      // window pieces this wave requests (this tile / the next)
 
-    unsigned voa[NI];
-    rc_window_offsets<NI>(p, c, m0, voa);
+    unsigned voa[4];
+    {
+        const int rmax = p.m + 143 - (m0 - 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = (q * 8 + wave) * 8 + (lane >> 3);
+            const int sl = (lane & 7) ^ ((r >> 1) & 7);
+            voa[q] = (unsigned)((r < rmax ? r : rmax) * (int)p.lda + (sl << 4));
+        }
+    }
     const char* a_base = p.a + (long)(m0 - 2) * p.lda;
     auto issue_a = [&](int cn, int buf) {
         const char* sb = a_base + (long)cn * 128;
         const unsigned l = c.lds0 + buf * RC_WIN_BYTES + wave * 1024;
 #pragma unroll
-        for (int q = 0; q < NI; ++q) dma16(l + q * 8192, voa[q], sb);
+        for (int q = 0; q < 4; ++q)
+            if (q < nq) dma16(l + q * 8192, voa[q], sb);
     };
     auto issue_a_next = [&](int buf) {                     // chunk 0 of the next tile (its own height and rows)
         const int rmax = p.m + 143 - (m1 - 2);
         const char* sb = p.a + (long)(m1 - 2) * p.lda;
         const unsigned l = c.lds0 + buf * RC_WIN_BYTES + wave * 1024;
-        for (int q = 0; q < ni1; ++q) {
+        for (int q = 0; q < nq1; ++q) {
             const int r = (q * 8 + wave) * 8 + (lane >> 3);
             const int sl = (lane & 7) ^ ((r >> 1) & 7);
             dma16(l + q * 8192, (unsigned)((r < rmax ? r : rmax) * (int)p.lda + (sl << 4)), sb);
@@ -160,7 +165,7 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
     auto compute = [&](int wbuf, int slot, int k, auto&& hook) {
         const char* at = smem + wbuf * RC_WIN_BYTES;
         const char* wt = smem + RC_RING + slot * RC_W_BYTES;
-        const int arow = wm * (32 * NI) + lrow + k;
+        const int arow = row0w + lrow + k;
         const int brow = wn * 64 + lrow;
         if constexpr (SPLIT == 1) {
             bf16x8 af[2][NI], bfr[2][2];
@@ -253,8 +258,8 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
             const unsigned wdst = c.lds0 + RC_RING + (ws == 0 ? 2 : ws - 1) * RC_W_BYTES + wave * 1024;
             int nwin = 0;
             if (k == 0 && !(RC_EXP & 1)) {                 // next window into the idle buffer: next chunk, or the next tile's chunk 0
-                if (!lastc) { issue_a(ch + 1, wbuf ^ 1); nwin = NI; }
-                else if (ni1 > 0) { issue_a_next(wbuf ^ 1); nwin = ni1; }
+                if (!lastc) { issue_a(ch + 1, wbuf ^ 1); nwin = nq; }
+                else if (h1 > 0) { issue_a_next(wbuf ^ 1); nwin = nq1; }
             }
             if (!RC_ILV && !(RC_EXP & 1)) {
 #pragma unroll
@@ -298,7 +303,7 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int r
 
     // Addressing: one per-lane byte offset per stream (this lane's row of the sweep, its 8 columns); the block row
     // (i, it) and the block column j go into the scalar offset of the buffer instruction.
-    const unsigned lrow0 = wm * (32 * NI) + srow;                  // tile row of this lane in sweep (i = 0, it = 0)
+    const unsigned lrow0 = row0w + srow;                           // tile row of this lane in sweep (i = 0, it = 0)
     const unsigned col0 = c.n0 + wn * 64 + sc8;                    // its first column in block j = 0
     const unsigned vx = res_f32 ? lrow0 * (unsigned)p.ldr * 4 + col0 * 4
                                 : lrow0 * (unsigned)p.lda + (SPLIT == 1 ? col0 * 2 : (col0 >> 5) * 128 + (col0 & 31) * 2);
@@ -424,14 +429,16 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
     int m0 = (g / p.s.ncls) * sum_rows + pre;
     const int end = m0 + p.s.rows[cls] < p.m ? m0 + p.s.rows[cls] : p.m;
     const int ntile = p.s.ntile[cls];
-    // height of tile t starting at row m: the scheduled one, cut to what is left of this group's rows
+    // height (half units) of tile t starting at row m: the scheduled one, cut to what is left of this group's rows
     auto height = [&](int t, int m) -> int {
         if (t >= ntile || m >= end) return 0;
-        const int ni = p.s.ni[cls][t], need = (end - m + 4 + 63) >> 6;
-        return ni < need ? ni : need;
+        int need = (end - m + 4 + 31) >> 5;
+        need = need < 2 ? 2 : need;
+        const int hs = p.s.ni[cls][t];
+        return hs < need ? hs : need;
     };
-    int ni = height(0, m0);
-    if (ni == 0) return;
+    int h = height(0, m0);
+    if (h == 0) return;
 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -448,7 +455,8 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
     {
         const int rmax = p.m + 143 - (m0 - 2);
         const char* sb = p.a + (long)(m0 - 2) * p.lda;
-        for (int q = 0; q < ni; ++q) {
+        const int nq = rc_pieces(h, c.wave);
+        for (int q = 0; q < nq; ++q) {
             const int r = (q * 8 + c.wave) * 8 + (c.lane >> 3);
             const int sl = (c.lane & 7) ^ ((r >> 1) & 7);
             dma16(c.lds0 + c.wave * 1024 + q * 8192, (unsigned)((r < rmax ? r : rmax) * (int)p.lda + (sl << 4)), sb);
@@ -459,18 +467,18 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
             for (int q = 0; q < 4; ++q)
                 dma16(c.lds0 + RC_RING + s * RC_W_BYTES + c.wave * 1024 + q * 8192, c.vow[q], c.w_base + (long)s * p.w_tap_stride);
     }
-    for (int t = 0; ni > 0; ++t) {
-        const int m1 = m0 + 64 * ni - 4;
-        const int ni1 = height(t + 1, m1);
-        const int rows_out = end - m0 < 64 * ni - 4 ? end - m0 : 64 * ni - 4;
-        switch (ni) {
-            case 1: rc_tile<SPLIT, 1>(p, c, m0, rows_out, m1, ni1); break;
-            case 2: rc_tile<SPLIT, 2>(p, c, m0, rows_out, m1, ni1); break;
-            case 3: rc_tile<SPLIT, 3>(p, c, m0, rows_out, m1, ni1); break;
-            default: rc_tile<SPLIT, 4>(p, c, m0, rows_out, m1, ni1); break;
+    for (int t = 0; h > 0; ++t) {
+        const int m1 = m0 + 32 * h - 4;
+        const int h1 = height(t + 1, m1);
+        const int rows_out = end - m0 < 32 * h - 4 ? end - m0 : 32 * h - 4;
+        switch (c.wm ? h >> 1 : (h + 1) >> 1) {             // 32-row blocks of this wave's row (wave-uniform)
+            case 1: rc_tile<SPLIT, 1>(p, c, m0, h, rows_out, m1, h1); break;
+            case 2: rc_tile<SPLIT, 2>(p, c, m0, h, rows_out, m1, h1); break;
+            case 3: rc_tile<SPLIT, 3>(p, c, m0, h, rows_out, m1, h1); break;
+            default: rc_tile<SPLIT, 4>(p, c, m0, h, rows_out, m1, h1); break;
         }
         m0 = m1;
-        ni = ni1;
+        h = h1;
     }
     // the last tile's wrapped weight requests may still be landing: LDS must not be handed to another workgroup under them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -482,14 +490,14 @@ using namespace efts;
 
 // ---------------------------------------------------------------------------------------------------------------
 // The static tile schedule.  `groups` workgroup groups (one workgroup per column tile each) share the m rows; a group's
-// rows are cut into tiles of 64 * ni - 4 rows, ni <= 4.  Two classes of groups alternate (g % 2): when the rows allow it
-// class 1 gets one 64-row unit less than class 0, so that its last epilogue -- an HBM burst no MFMA work of the same CU
+// rows are cut into tiles of 32 * h - 4 rows, h = 2..8 half units.  Two classes of groups alternate (g % 2): when the rows allow it
+// class 1 gets one 32-row half unit less than class 0, so that its last epilogue -- an HBM burst no MFMA work of the same CU
 // can hide -- runs while class 0 still computes, and the epilogues in between fall at different times too.
 // ---------------------------------------------------------------------------------------------------------------
-static int rc_cover(int units) { return 64 * units - 4 * ((units + 3) / 4); }    // rows `units` 64-row units yield in ceil(units / 4) tiles
+static int rc_cover(int units) { return 32 * units - 4 * ((units + 7) / 8); }    // rows `units` half units yield in ceil(units / 8) tiles
 
 static void rc_split(int units, bool descending, unsigned char* ni, int* ntile) {
-    const int t = (units + 3) / 4;
+    const int t = (units + 7) / 8;
     for (int i = 0; i < t; ++i) {
         const int v = units / t + (i < units % t ? 1 : 0);      // as even as possible, larger first
         ni[descending ? i : t - 1 - i] = (unsigned char)v;
@@ -499,11 +507,13 @@ static void rc_split(int units, bool descending, unsigned char* ni, int* ntile) 
 
 static void rc_schedule(int m, int slots, RcSched* s, int* groups) {
     // slots = workgroup groups that can run at once (CUs / column tiles)
-    int units = 1;
-    while (rc_cover(units) * (long)slots < m) ++units;           // every group `units` units: covers m
-    if (units > 4 * RC_MAXTILES) units = 4 * RC_MAXTILES;        // (beyond: more groups than slots, several rounds)
+    int units = 2;                                               // half units; the smallest tile has two
+    while (rc_cover(units) * (long)slots < m) ++units;           // every group `units` half units: covers m
+    if (units > 8 * RC_MAXTILES) units = 8 * RC_MAXTILES;        // (beyond: more groups than slots, several rounds)
     s->ncls = 2;
-    const bool uneven = units >= 2 && slots >= 2 && (long)(rc_cover(units) + rc_cover(units - 1)) * (slots / 2) >= m;
+    // (short tiles run at the LDS-DMA rate, where a class of even shorter ones only adds workgroups that stream the weights:
+    //  measured 47.6 vs 49.3 us at 16 x 800 frames for heights 4|4 against 4|3, a tie from 7|6 upwards)
+    const bool uneven = units >= 6 && slots >= 2 && (long)(rc_cover(units) + rc_cover(units - 1)) * (slots / 2) >= m;
     s->rows[0] = rc_cover(units);
     rc_split(units, true, s->ni[0], &s->ntile[0]);
     if (uneven) {
@@ -545,11 +555,11 @@ static const char* rc_plan_read(const int32_t* plan, int m, RcSched* s, int* gro
         if (q[1] < 1 || q[1] > RC_MAXTILES) return "plan: 1..8 tiles per class";
         int rows = 0;
         for (int t = 0; t < q[1]; ++t) {
-            if (q[2 + t] < 1 || q[2 + t] > 4) return "plan: tile heights must be 1..4 (units of 64 window rows)";
+            if (q[2 + t] < 2 || q[2 + t] > 8) return "plan: tile heights must be 2..8 (half units of 32 window rows)";
             s->ni[c][t] = (unsigned char)q[2 + t];
-            rows += 64 * q[2 + t] - 4;
+            rows += 32 * q[2 + t] - 4;
         }
-        if (rows != q[0]) return "plan: a class's rows must equal the sum of 64 * ni - 4 over its tiles";
+        if (rows != q[0]) return "plan: a class's rows must equal the sum of 32 * h - 4 over its tiles";
         sum += rows;
     }
     long covered = (*groups / s->ncls) * sum;

@@ -194,9 +194,10 @@ def resconv5_plan(m: int, n: int, cus: int = 0):
 
 
 def make_plan(m: int, classes):
-    """explicit schedule for efts_resconv5: classes = [[ni, ...], ...] (tile heights per class, 1..4); enough groups to cover m"""
+    """explicit schedule for efts_resconv5: classes = [[h, ...], ...] (tile heights per class in half units of 32 window rows,
+    2..8; a tile yields 32 h - 4 rows); enough groups to cover m"""
     buf = (C.c_int32 * L.RC_PLAN_INTS)()
-    rows = [sum(64 * ni - 4 for ni in cl) for cl in classes]
+    rows = [sum(32 * ni - 4 for ni in cl) for cl in classes]
     full, rem, groups = m // sum(rows), m % sum(rows), 0
     groups = full * len(classes)
     for r in rows:

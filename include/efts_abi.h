@@ -174,8 +174,9 @@ int efts_resconv5(const efts_resconv5_args* a, void* stream);
 
 /* The static tile schedule of efts_resconv5 for m rows x n columns on `cus` compute units (0: the current device).
  * One persistent workgroup per CU; the workgroups form groups (one workgroup per 256-column tile); group g belongs to
- * class g % classes and owns `rows` consecutive output rows, cut into `ntile` tiles of 64 * ni - 4 rows (ni = 1..4).
- * plan (host memory, >= EFTS_RC_PLAN_INTS int32) = [groups, classes, then for each of 4 classes: rows, ntile, ni[8]].
+ * class g % classes and owns `rows` consecutive output rows, cut into `ntile` tiles of 32 * h - 4 rows, h = 2..8 half
+ * units of 32 window rows (odd heights: the two wave rows of the workgroup take ceil(h/2) and floor(h/2) 32-row blocks).
+ * plan (host memory, >= EFTS_RC_PLAN_INTS int32) = [groups, classes, then for each of 4 classes: rows, ntile, h[8]].
  * Returns the number of int32 written, or a negative EFTS_E* code.  No device work. */
 #define EFTS_RC_PLAN_INTS 42
 int efts_resconv5_plan(int32_t m, int32_t n, int32_t cus, int32_t* plan, int32_t cap);

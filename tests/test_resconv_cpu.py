@@ -16,8 +16,8 @@ def lib():
     return L.load()
 
 
-def cover(units):          # rows `units` 64-row units yield in ceil(units / 4) tiles
-    return 64 * units - 4 * ((units + 3) // 4)
+def cover(units):          # rows `units` half units (32 window rows) yield in ceil(units / 8) tiles
+    return 32 * units - 4 * ((units + 7) // 8)
 
 
 def check_plan(m, n, cus):
@@ -27,8 +27,9 @@ def check_plan(m, n, cus):
     assert 1 <= len(classes) <= 4 and groups >= 1
     units = []
     for rows, tiles in classes:
-        assert 1 <= len(tiles) <= 8 and all(1 <= t <= 4 for t in tiles)
-        assert rows == sum(64 * t - 4 for t in tiles)                     # every row of the class is in exactly one tile
+        assert 1 <= len(tiles) <= 8 and all(2 <= t <= 8 for t in tiles)
+        assert rows == sum(32 * t - 4 for t in tiles)                     # every row of the class is in exactly one tile
+        assert max(tiles) - min(tiles) <= 1                               # as even as possible: no short, LDS-DMA-bound tile beside a tall one
         units.append(sum(tiles))
     # coverage: group g belongs to class g % len(classes) and owns `rows` consecutive rows
     per_round = sum(r for r, _ in classes)
@@ -36,10 +37,10 @@ def check_plan(m, n, cus):
     assert covered >= m
     assert covered - m < max(r for r, _ in classes) + min(r for r, _ in classes)      # no group without rows
     # one round: never more workgroups than CUs, and the longest group is as short as the row count allows
-    u_min = 1
+    u_min = 2
     while cover(u_min) * slots < m:
         u_min += 1
-    if u_min <= 32:
+    if u_min <= 64:
         assert groups <= slots
         assert max(units) == u_min
         assert min(units) >= u_min - 1
@@ -49,9 +50,9 @@ def check_plan(m, n, cus):
 def test_plans_of_the_baseline_shapes():
     # (rows, expected classes): B x (T2 + 2) rows of BASELINE configs 2 / 3 / 5 on 256 CUs, 512 channels
     g, c = check_plan(64 * 802, 512, 256)
-    assert [t for _, t in c] == [[4, 3], [3, 3]] and g <= 128            # two epilogue bursts per class, all at different times
+    assert [t for _, t in c] == [[7, 6], [6, 7]] and g <= 128            # 13 half units each (6.5 x 64 rows; 64-row units needed 7)
     g, c = check_plan(32 * 802, 512, 256)
-    assert [t for _, t in c] == [[4], [3]]
+    assert [t for _, t in c] == [[7], [6]]
     check_plan(16 * 1202, 512, 256)
     check_plan(16 * 1502, 512, 256)
     check_plan(1 * 802, 512, 256)
@@ -94,21 +95,24 @@ def test_resconv5_rejects_bad_arguments_before_launching(lib):
     g = _args(); g.split, g.x_lo = 2, 0x4000
     assert lib.efts_resconv5(C.byref(g), None) == -1
     # explicit plans are validated on the host
-    short = P.make_plan(500, [[2], [1]])                                             # covers 500 rows, not 1000
+    short = P.make_plan(500, [[4], [2]])                                             # covers 500 rows, not 1000
     g = _args(1000, short)
     assert lib.efts_resconv5(C.byref(g), None) == -1 and b"cover" in lib.efts_last_error()
-    bad = P.make_plan(1000, [[4, 3]]); bad[2] += 1                                   # rows != sum of the tiles
+    bad = P.make_plan(1000, [[8, 6]]); bad[2] += 1                                   # rows != sum of the tiles
     g = _args(1000, bad)
     assert lib.efts_resconv5(C.byref(g), None) == -1 and b"sum" in lib.efts_last_error()
-    bad = P.make_plan(1000, [[4, 3]]); bad[4] = 5                                    # a tile height of 5
+    bad = P.make_plan(1000, [[8, 6]]); bad[4] = 9                                    # a tile height of 9 half units
+    g = _args(1000, bad)
+    assert lib.efts_resconv5(C.byref(g), None) == -1
+    bad = P.make_plan(1000, [[8, 6]]); bad[4] = 1                                    # ... and of 1
     g = _args(1000, bad)
     assert lib.efts_resconv5(C.byref(g), None) == -1
 
 
 def test_make_plan_round_trip():
-    for m, classes in ((51328, [[4, 3], [3, 3]]), (1000, [[1]]), (25664, [[4], [3], [2, 1]])):
+    for m, classes in ((51328, [[7, 6], [6, 7]]), (1000, [[2]]), (25664, [[8], [7], [4, 3]])):
         buf = P.make_plan(m, classes)
-        rows = [sum(64 * t - 4 for t in cl) for cl in classes]
+        rows = [sum(32 * t - 4 for t in cl) for cl in classes]
         assert buf[1] == len(classes)
         covered = (buf[0] // len(classes)) * sum(rows) + sum(rows[:buf[0] % len(classes)])
         assert covered >= m and covered - m < max(rows) + min(rows)

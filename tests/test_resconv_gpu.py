@@ -88,10 +88,12 @@ def test_resconv5_equals_gemm_automatic_schedule(split, B, T, mode):
 
 
 @pytest.mark.parametrize("split", [1, 2])
-@pytest.mark.parametrize("classes", [[[1]], [[2]], [[3]], [[4]], [[2], [1]], [[3, 1]], [[4, 3], [3, 3]], [[1, 2, 3, 4]], [[4], [3], [2], [1]]])
+@pytest.mark.parametrize("classes", [[[2]], [[3]], [[4]], [[5]], [[6]], [[7]], [[8]], [[4], [2]], [[6, 2]], [[7, 6], [6, 7]], [[2, 3, 4, 5]],
+                                     [[8, 3, 7]], [[8], [6], [4], [2]], [[5], [3], [7]]])
 def test_resconv5_every_tile_height_and_multi_tile_schedules(split, classes):
-    """explicit plans: every tile height, tiles of different heights in one workgroup (window buffers / ring slots carried
-    across tiles, the next tile's first operands requested before the epilogue), 1 .. 4 classes"""
+    """explicit plans: every tile height in half units (odd ones split 4+3, 3+2, 2+1 blocks over the two wave rows), tiles of
+    different heights in one workgroup (window buffers / ring slots carried across tiles, the next tile's first operands
+    requested before the epilogue), 1 .. 4 classes"""
     c = Case(5, 300, split, seed=7)
     plan = c.P.make_plan(c.rs.rows, classes)
     c.check("planes", plan)

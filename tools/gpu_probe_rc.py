@@ -1,5 +1,5 @@
 """efts_resconv5 (persistent 8-wave k5 residual layer on hi/lo planes) vs efts_gemm: bit equality and time.
-  PB, PT: batch / frames; PSPLIT: 1 | 2; EFTS_RC_SCHED: tile schedule override"""
+  PSHAPES: "BxT,..."; PSPLIT: 1 | 2; PPLAN: explicit tile schedule, classes of tile heights in half units, e.g. "7,6|6,7" """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -59,7 +59,10 @@ def case(B, T, split, check=True, time=True):
             ys = 2 if split == 2 else 1
             y = P.Plane.for_rows(rs, C, ys, dev)
             yl = P.Plane.for_rows(rs, C, 1, dev) if ys == 1 else None
-            return o, y, yl, lambda: P.resconv5(x=a, x_lo=a_lo, w=pw, m=rs.rows, n=C, bias=bias, rowmask_ptr=gap.data_ptr(), y=y, y_lo=yl)
+            plan = None
+            if os.environ.get("PPLAN"):
+                plan = P.make_plan(rs.rows, [[int(v) for v in cl.split(",")] for cl in os.environ["PPLAN"].split("|")])
+            return o, y, yl, lambda: P.resconv5(x=a, x_lo=a_lo, w=pw, m=rs.rows, n=C, bias=bias, rowmask_ptr=gap.data_ptr(), y=y, y_lo=yl, plan=plan)
     with P.stream_scope():
         ref(); torch.cuda.synchronize()
         ok = True
