@@ -47,6 +47,11 @@
 #ifndef RC_SGB
 #define RC_SGB 1
 #endif
+// lab builds only (-DRC_STAMP): every workgroup stamps its start and end with the 100 MHz constant clock into the buffer whose
+// address EFTS_RC_STAMP (hex) names, 64 launches deep: dispatch skew, kernel span and the idle gap between dependent launches
+#ifndef RC_STAMP
+#define RC_STAMP 0
+#endif
 
 namespace efts {
 
@@ -79,6 +84,7 @@ struct RcArgs {
     float slope;
     int out_split;
     RcSched s;
+    unsigned long long* stamp;
 };
 
 __device__ __forceinline__ void rc_wait(int n) {
@@ -408,6 +414,7 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
     c.smem = smem;
     c.lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem));
     const int tid = threadIdx.x;
+    if (RC_STAMP && p.stamp && tid == 0) p.stamp[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
     c.lane = tid & 63;
     c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     c.wm = c.wave >> 2; c.wn = c.wave & 3;
@@ -482,6 +489,7 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
     }
     // the last tile's wrapped weight requests may still be landing: LDS must not be handed to another workgroup under them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (RC_STAMP && p.stamp && tid == 0) p.stamp[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 }  // namespace efts
@@ -617,6 +625,15 @@ extern "C" int efts_resconv5(const efts_resconv5_args* a, void* stream) {
         attr = true;
     }
     const dim3 grid(groups * k.ntn);
+    k.stamp = nullptr;
+#if RC_STAMP
+    {
+        static unsigned long long* base = nullptr;
+        static int launch = 0;
+        if (!base) { const char* e = getenv("EFTS_RC_STAMP"); if (e) base = (unsigned long long*)strtoull(e, nullptr, 16); }
+        if (base) { k.stamp = base + (size_t)(launch % 64) * 1024; ++launch; }
+    }
+#endif
     if (a->split == 1) hipLaunchKernelGGL(resconv5_kernel<1>, grid, dim3(512), RC_LDS, (hipStream_t)stream, k);
     else hipLaunchKernelGGL(resconv5_kernel<2>, grid, dim3(512), RC_LDS, (hipStream_t)stream, k);
     return efts_check_launch("efts_resconv5");
