@@ -47,6 +47,16 @@
 #ifndef RC_SGB
 #define RC_SGB 1
 #endif
+// RC_PP 1: ping-pong main loop.  The two waves of a SIMD (one of each wave row) alternate: while one issues the MFMAs of a half
+// step from fragments it already holds, the other reads its next fragments and issues its LDS-DMA pieces; four barriers per
+// step keep them a quarter step apart, s_setprio(1) covers the MFMA phase.  RC_PP 0: both rows run the step in phase, fragment
+// reads interleaved with their own MFMAs (RC_SGB).
+#ifndef RC_PP
+#define RC_PP 1
+#endif
+#ifndef RC_PP_PRIO
+#define RC_PP_PRIO 1
+#endif
 // lab builds only (-DRC_STAMP): every workgroup stamps its start and end with the 100 MHz constant clock into the buffer whose
 // address EFTS_RC_STAMP (hex) names, 64 launches deep: dispatch skew, kernel span and the idle gap between dependent launches
 #ifndef RC_STAMP
@@ -97,6 +107,8 @@ __device__ __forceinline__ void rc_wait(int n) {
         default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
     }
 }
+
+template <int V> struct RcRow { static constexpr int value = V; };
 
 struct RcCtx {
     char* smem;
@@ -251,6 +263,130 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int h
     __builtin_amdgcn_s_barrier();
 
     int ws = c.ws;
+#if RC_PP
+    // ---- ping-pong form.  Row 0: [L0] B [M0] B [L1] B [M1, wait] B.  Row 1: B [L0] B [M0] B [L1, wait] B [M1].  (L = fragment reads
+    // of a half step + its LDS-DMA pieces, M = its MFMAs, B = s_barrier of all 8 waves.)  Between two barriers exactly one wave of
+    // every SIMD issues MFMAs.  Ordering: every wave counts its own requests down (rc_wait) before the step's 4th barrier, so
+    // the next step's weights / window are readable right behind it (row 0) or one barrier later (row 1); every fragment read of a
+    // step is retired (lgkmcnt 0) before that same barrier, so the requests issued behind it may overwrite what the step read.
+    bf16x8 fa[2][NI], fa2[SPLIT == 2 ? NI : 1], fb[2][2], fb2[SPLIT == 2 ? 2 : 1];
+    (void)fa2; (void)fb2;
+    const int brow_pp = wn * 64 + lrow;
+    auto loadH = [&](const char* at, const char* wt, int arow, int hs) {
+        if (RC_EXP & 4) return;
+        if constexpr (SPLIT == 1) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int slot16 = (2 * hs + s2) * 2 + lhalf;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[s2][j] = *(const bf16x8*)(wt + lds_off(brow_pp + j * 32, slot16));
+#pragma unroll
+                for (int i = 0; i < NI; ++i) fa[s2][i] = *(const bf16x8*)(at + lds_off(arow + i * 32, slot16));
+            }
+        } else {
+            const int slot16 = hs * 2 + lhalf;              // fa[0] / fb[0] = hi, fa2 / fb2 = lo of k-slice hs
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                fb[0][j] = *(const bf16x8*)(wt + lds_off(brow_pp + j * 32, slot16));
+                fb2[j] = *(const bf16x8*)(wt + lds_off(brow_pp + j * 32, slot16 + 4));
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                fa[0][i] = *(const bf16x8*)(at + lds_off(arow + i * 32, slot16));
+                fa2[i] = *(const bf16x8*)(at + lds_off(arow + i * 32, slot16 + 4));
+            }
+        }
+    };
+    auto mmaH = [&]() {
+        if (RC_EXP & 4) return;
+        __builtin_amdgcn_sched_barrier(0);
+        if (RC_PP_PRIO) __builtin_amdgcn_s_setprio(1);
+        if constexpr (SPLIT == 1) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][i], fb[s2][j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2[i], fb[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb2[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (RC_PP_PRIO) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto bar_reads = [&]() {                                // the fragment reads issued so far are retired first
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // (the two rows are two separate loop nests: one nest with a row branch inside every step made the register allocator spill
+    // ~1 000 VGPRs)
+    auto steps = [&](auto rowc) {
+    constexpr int ROW = decltype(rowc)::value;
+    for (int ch = 0; ch < p.nchunk; ++ch) {
+        const int wbuf = (c.wpar + ch) & 1;
+        const bool lastc = ch + 1 == p.nchunk;
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) {
+            const int kn = (k + 2) % TAPS;
+            int cn = ch + (k + 2) / TAPS;
+            cn = cn == p.nchunk ? 0 : cn;
+            const char* wsrc = c.w_base + (long)kn * p.w_tap_stride + (long)cn * 128;
+            const unsigned wdst = c.lds0 + RC_RING + (ws == 0 ? 2 : ws - 1) * RC_W_BYTES + wave * 1024;
+            int nwin = 0;
+            auto window = [&]() {                          // next window into the idle buffer: next chunk, or the next tile's chunk 0
+                if (k == 0 && !(RC_EXP & 1)) {
+                    if (!lastc) { issue_a(ch + 1, wbuf ^ 1); nwin = nq; }
+                    else if (h1 > 0) { issue_a_next(wbuf ^ 1); nwin = nq1; }
+                }
+            };
+            auto dma_w = [&](int g) { if (!(RC_EXP & 1)) dma16(wdst + g * 8192, c.vow[g], wsrc); };
+            int kv = k;
+            asm volatile("" : "+s"(kv));
+            const char* at = smem + wbuf * RC_WIN_BYTES;
+            const char* wt = smem + RC_RING + ws * RC_W_BYTES;
+            const int arow = row0w + lrow + kv;
+            if constexpr (ROW == 0) {
+                window();
+                loadH(at, wt, arow, 0); dma_w(0); dma_w(1);
+                bar_reads();
+                mmaH();
+                bar();
+                loadH(at, wt, arow, 1); dma_w(2); dma_w(3);
+                bar_reads();
+                mmaH();
+                if (RC_EXP & 1) rc_wait(0); else rc_wait(4 + nwin);
+                bar();
+            } else {
+                bar();
+                window();
+                loadH(at, wt, arow, 0); dma_w(0); dma_w(1);
+                bar_reads();
+                mmaH();
+                bar();
+                loadH(at, wt, arow, 1); dma_w(2); dma_w(3);
+                if (RC_EXP & 1) rc_wait(0); else rc_wait(4 + nwin);
+                bar_reads();
+                mmaH();
+            }
+            ws = (ws == 2) ? 0 : ws + 1;
+        }
+    }
+    };
+    if (wm == 0) steps(RcRow<0>{}); else steps(RcRow<1>{});
+#else
     for (int ch = 0; ch < p.nchunk; ++ch) {
         const int wbuf = (c.wpar + ch) & 1;
         const bool lastc = ch + 1 == p.nchunk;
@@ -283,6 +419,7 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int h
             ws = (ws == 2) ? 0 : ws + 1;
         }
     }
+#endif
     c.ws = ws;
     c.wpar = (c.wpar + p.nchunk) & 1;
 
