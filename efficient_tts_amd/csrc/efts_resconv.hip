@@ -57,8 +57,9 @@
 #ifndef RC_PP_PRIO
 #define RC_PP_PRIO 1
 #endif
-// lab builds only (-DRC_STAMP): every workgroup stamps its start and end with the 100 MHz constant clock into the buffer whose
-// address EFTS_RC_STAMP (hex) names, 64 launches deep: dispatch skew, kernel span and the idle gap between dependent launches
+// lab builds only (-DRC_STAMP=1): every workgroup stamps its start and end with the 100 MHz constant clock into the buffer whose
+// address EFTS_RC_STAMP (hex) names, 64 launches deep: dispatch skew, kernel span and the idle gap between dependent launches.
+// -DRC_STAMP=2: every wave sums the shader-clock cycles of its read phases, MFMA phases and the waits at their barriers
 #ifndef RC_STAMP
 #define RC_STAMP 0
 #endif
@@ -120,6 +121,7 @@ struct RcCtx {
     float bv[2];            // bias of this lane's two accumulator columns
     int ws;                 // ring slot of the next step
     int wpar;               // window buffer of the next tile's chunk 0
+    unsigned long long tph[4];   // RC_STAMP 2: shader-clock cycles in read phases / their barrier / MFMA phases / their barrier
 };
 
 // window pieces of one tile of h half units: piece P = q * 8 + wave, P < 4 h, covers window rows 8P .. 8P+7 (lane l: row 8P + l/8,
@@ -321,14 +323,28 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int h
         if (RC_PP_PRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto bar = [&]() {
+    unsigned long long tmark = RC_STAMP == 2 ? __builtin_readcyclecounter() : 0ull;
+    auto lap = [&](int which) {                            // RC_STAMP 2: cycles since the last mark go to phase counter `which`
+        if (RC_STAMP == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t = __builtin_readcyclecounter();
+            c.tph[which] += t - tmark;
+            tmark = t;
+        }
+    };
+    auto bar = [&]() {                                      // ends an MFMA phase
         __builtin_amdgcn_sched_barrier(0);
+        lap(2);
         __builtin_amdgcn_s_barrier();
+        lap(3);
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto bar_reads = [&]() {                                // the fragment reads issued so far are retired first
+    auto bar_reads = [&]() {                                // ends a read phase: the fragment reads issued so far are retired first
         __builtin_amdgcn_sched_barrier(0);
-        lds_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lap(0);
+        __builtin_amdgcn_s_barrier();
+        lap(1);
         __builtin_amdgcn_sched_barrier(0);
     };
     // (the two rows are two separate loop nests: one nest with a row branch inside every step made the register allocator spill
@@ -551,7 +567,8 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
     c.smem = smem;
     c.lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem));
     const int tid = threadIdx.x;
-    if (RC_STAMP && p.stamp && tid == 0) p.stamp[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
+    if (RC_STAMP == 1 && p.stamp && tid == 0) p.stamp[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
+    c.tph[0] = c.tph[1] = c.tph[2] = c.tph[3] = 0;
     c.lane = tid & 63;
     c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     c.wm = c.wave >> 2; c.wn = c.wave & 3;
@@ -626,7 +643,11 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
     }
     // the last tile's wrapped weight requests may still be landing: LDS must not be handed to another workgroup under them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (RC_STAMP && p.stamp && tid == 0) p.stamp[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+    if (RC_STAMP == 1 && p.stamp && tid == 0) p.stamp[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+    if (RC_STAMP == 2 && p.stamp && blockIdx.x < 32 && c.lane == 0) {          // [workgroup < 32][wave][4 phase counters]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) p.stamp[(blockIdx.x * 8 + c.wave) * 4 + q] = c.tph[q];
+    }
 }
 
 }  // namespace efts
