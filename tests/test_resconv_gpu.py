@@ -135,3 +135,32 @@ def test_gemm_writes_the_remainder_plane():
     rh, rl = bf16_split(o.buf)
     assert torch.equal(y.buf.view(torch.bfloat16).view(rs.alloc, -1)[:, :C], rh)
     assert torch.equal(yl.buf.view(torch.bfloat16).view(rs.alloc, -1)[:, :C], rl)
+
+
+@pytest.mark.parametrize("split", [1, 2])
+def test_resconv5_race_screen(split):
+    """The ping-pong loop orders its LDS-DMA writes and fragment reads by counted waits and barriers alone; a misplaced one shows
+    up as a rare wrong tile, not as a steady failure.  120 launches at the full size (30 240 tiles, 1.2 M (chunk, tap) steps per
+    workgroup row), back to back and beside a second stream that keeps the fabric busy with copies, every result compared bit
+    for bit with efts_gemm's; then the same under an odd-height multi-tile plan."""
+    c = Case(64, 800, split, seed=21)
+    P, rs, dev = c.P, c.rs, _dev()
+    y = P.Plane.for_rows(rs, C, split, dev)
+    yl = P.Plane.for_rows(rs, C, 1, dev) if split == 1 else None
+    o = P.F32Rows(rs, C, dev)
+    side = torch.cuda.Stream(device=dev)
+    junk_a, junk_b = torch.empty(64 << 20, dtype=torch.uint8, device=dev), torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    bad = 0
+    for plan in (None, P.make_plan(rs.rows, [[5, 3, 5], [3, 7, 3]])):
+        for it in range(60):
+            if it % 3 == 0:
+                with torch.cuda.stream(side):
+                    junk_b.copy_(junk_a)                      # 128 MB of unrelated traffic beside the launch
+            o.buf.zero_(); y.buf.zero_()
+            P.resconv5(x=c.a, x_lo=c.a_lo, w=c.pw, m=rs.rows, n=C, bias=c.bias, rowmask_ptr=c.mask.data_ptr(), y_f32_ptr=o.ptr, ldo=C,
+                       y=y, y_lo=yl, plan=plan)
+            bad += int(not torch.equal(o.buf, c.o_ref.buf))
+            if split == 2:
+                bad += int(not torch.equal(y.buf, c.p_ref.buf))
+        torch.cuda.synchronize()
+    assert bad == 0, f"{bad} of 120 launches differ from efts_gemm"
