@@ -22,4 +22,7 @@ python bench.py --workload infer_lj --no-cpu-baseline > $O/bench_infer_lj_bf16_r
 if [ -f lab/rc_stamp.so ]; then
   for sp in 1 2; do PSPLIT=$sp EFTS_LIB=$R/lab/rc_stamp.so timeout 200 python tools/gpu_probe_rc_stamp.py; done > $O/rc_stamps_r02.txt 2>&1
 fi
+if [ -f lab/rc_phase.so ]; then
+  EFTS_LIB=$R/lab/rc_phase.so timeout 200 python tools/gpu_probe_rc_phases.py > $O/rc_phases_r02.txt 2>&1
+fi
 ls -la $O
