@@ -480,10 +480,7 @@ class EfficientTTSCNN(torch.nn.Module):
         rs1, rs2 = Rows(B, T1), Rows(B, T2)
         gap1, len1 = ws.tensor("gap1", (rs1.rows,)), ws.tensor("len1", (rs1.rows,))
         gap2, len2 = ws.tensor("gap2", (rs2.rows,)), ws.tensor("len2", (rs2.rows,))
-        O.row_masks(tl, rs1, gap1, len1)                                          # :137
-        O.row_masks(ml, rs2, gap2, len2)                                          # :139
-
-        # The text side (embed, 5 convs, K/V) and the duration predictor do not depend on the mel side
+        # The text side (masks, embed, 5 convs, K/V) and the duration predictor do not depend on the mel side
         # (prenet, 3 convs): they run on a second HIP stream so their small grids fill the tail rounds
         # of the mel-length kernels instead of serialising behind them.
         main = torch.cuda.current_stream(dev)
@@ -491,7 +488,9 @@ class EfficientTTSCNN(torch.nn.Module):
         side.wait_stream(main)
         k_ready, v_ready = torch.cuda.Event(), torch.cuda.Event()
         vt = ws.raw_plane("vt", B * C, T1, 2)
+        O.row_masks(ml, rs2, gap2, len2)                                          # :139
         with O.on_stream(side):
+            O.row_masks(tl, rs1, gap1, len1)                                      # :137
             key_p, val_f, val_p = self._text_side(ws, pk, text, rs1, gap1, len1, on_key=lambda: k_ready.record(side), vt=vt)  # :144-157
             v_ready.record(side)
             dur = self._duration(ws, pk, rs1, val_p, gap1, len1.data_ptr(), 0)    # :219
