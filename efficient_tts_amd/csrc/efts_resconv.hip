@@ -14,7 +14,10 @@
 //     waves, so the LDS-DMA line requests per MFMA are half those of a 128-column tile.
 //   * LDS = two 256-row windows (double-buffered: the next K chunk's window lands while the current one is read at its
 //     5 tap shifts) + a 3-stage ring of 32 KiB weight tiles = exactly 160 KiB.  All operands arrive by LDS-DMA issued
-//     from inline asm with counted s_waitcnt vmcnt(N); one s_barrier per (chunk, tap) step.
+//     from inline asm with counted s_waitcnt vmcnt(N).
+//   * ping-pong main loop: the two waves of a SIMD (one of each wave row) alternate -- while one issues the MFMAs of a half
+//     (chunk, tap) step from fragments it already holds, the other reads its next fragments and issues its LDS-DMA pieces;
+//     four s_barrier per step keep the rows a quarter step apart.
 //   * the residual stream travels as bf16 hi/lo planes (x = hi + lo, 16 mantissa bits) instead of an fp32 copy
 //     beside the bf16 operand plane: the epilogue reads 4 B and writes 4 B per element instead of 4 + 6..8 B.
 //   * the epilogue is wave-private (no barriers): each wave drops one 32 x 32 accumulator block at a time into its own
@@ -31,31 +34,9 @@
 #include "efts_mma.h"
 
 // lab builds only (-DRC_EXP=...): ablation bits 1 no LDS-DMA in the loop, 4 no MFMA + fragment reads, 8 no epilogue loads / stores,
-// 16 no epilogue at all.  RC_ILV 0: the step's weight pieces go out as a burst at step start (A/B of the interleave).
+// 16 no epilogue at all (tools/rc_ab.sh)
 #ifndef RC_EXP
 #define RC_EXP 0
-#endif
-#ifndef RC_ILV
-#define RC_ILV 1
-#endif
-#ifndef RC_PRIO
-#define RC_PRIO 0
-#endif
-// RC_SGB 1 (bf16 planes): the ds_reads of k-slice kk+1 are interleaved 1:1 with the MFMAs of slice kk (sched_group_barrier)
-// instead of being issued as a block in front of them: both waves of a SIMD run the same stream in phase, so a block of
-// non-MFMA instructions in one wave coincides with the same block in the other and the matrix pipe idles under it
-#ifndef RC_SGB
-#define RC_SGB 1
-#endif
-// RC_PP 1: ping-pong main loop.  The two waves of a SIMD (one of each wave row) alternate: while one issues the MFMAs of a half
-// step from fragments it already holds, the other reads its next fragments and issues its LDS-DMA pieces; four barriers per
-// step keep them a quarter step apart, s_setprio(1) covers the MFMA phase.  RC_PP 0: both rows run the step in phase, fragment
-// reads interleaved with their own MFMAs (RC_SGB).
-#ifndef RC_PP
-#define RC_PP 1
-#endif
-#ifndef RC_PP_PRIO
-#define RC_PP_PRIO 1
 #endif
 // lab builds only (-DRC_STAMP=1): every workgroup stamps its start and end with the 100 MHz constant clock into the buffer whose
 // address EFTS_RC_STAMP (hex) names, 64 launches deep: dispatch skew, kernel span and the idle gap between dependent launches.
@@ -180,93 +161,13 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int h
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // MFMAs of one (chunk, tap) step.  `hook(g)`, g = 0..3, runs between the MFMA groups: the step's four weight pieces
-    // are issued there one at a time, in the shadow of the MFMAs already queued, instead of as a burst that idles the pipe
-    auto compute = [&](int wbuf, int slot, int k, auto&& hook) {
-        const char* at = smem + wbuf * RC_WIN_BYTES;
-        const char* wt = smem + RC_RING + slot * RC_W_BYTES;
-        const int arow = row0w + lrow + k;
-        const int brow = wn * 64 + lrow;
-        if constexpr (SPLIT == 1) {
-            bf16x8 af[2][NI], bfr[2][2];
-            auto ld = [&](int kk, int b) {
-                const int slot16 = kk * 2 + lhalf;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) bfr[b][j] = *(const bf16x8*)(wt + lds_off(brow + j * 32, slot16));
-#pragma unroll
-                for (int i = 0; i < NI; ++i) af[b][i] = *(const bf16x8*)(at + lds_off(arow + i * 32, slot16));
-            };
-            ld(0, 0);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (kk + 1 < 4) ld(kk + 1, (kk + 1) & 1);
-                if (!RC_SGB) __builtin_amdgcn_sched_barrier(0);
-                if (RC_PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j], 0, 0, 0);
-                if (RC_PRIO) __builtin_amdgcn_s_setprio(0);
-                if (RC_SGB && kk + 1 < 4) {
-                    // 2 NI MFMAs and NI + 2 fragment reads of the next slice: MFMA, read, MFMA, read, ... (the reads' address
-                    // VALU goes wherever the scheduler likes)
-#pragma unroll
-                    for (int q = 0; q < 2 * NI; ++q) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (q < NI + 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    }
-                    if (NI + 2 > 2 * NI) __builtin_amdgcn_sched_group_barrier(0x100, NI + 2 - 2 * NI, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                hook(kk);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int slot16 = kk * 2 + lhalf;
-                bf16x8 bh[2], bl[2], ah[2], al[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    bh[j] = *(const bf16x8*)(wt + lds_off(brow + j * 32, slot16));
-                    bl[j] = *(const bf16x8*)(wt + lds_off(brow + j * 32, slot16 + 4));
-                }
-                ah[0] = *(const bf16x8*)(at + lds_off(arow, slot16));
-                al[0] = *(const bf16x8*)(at + lds_off(arow, slot16 + 4));
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    if (i + 1 < NI) {
-                        ah[(i + 1) & 1] = *(const bf16x8*)(at + lds_off(arow + (i + 1) * 32, slot16));
-                        al[(i + 1) & 1] = *(const bf16x8*)(at + lds_off(arow + (i + 1) * 32, slot16 + 4));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (RC_PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i & 1], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bh[j], acc[i][j], 0, 0, 0);
-                    }
-                    if (RC_PRIO) __builtin_amdgcn_s_setprio(0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (i == 0) hook(kk * 2);
-                    if (i == NI - 1) hook(kk * 2 + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-    };
-
     // ---- the tile's first operands were requested earlier (kernel start / previous tile); the previous epilogue's loads
     // and stores share the counter, so everything is waited for once here
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     int ws = c.ws;
-#if RC_PP
-    // ---- ping-pong form.  Row 0: [L0] B [M0] B [L1] B [M1, wait] B.  Row 1: B [L0] B [M0] B [L1, wait] B [M1].  (L = fragment reads
+    // ---- ping-pong main loop.  Row 0: [L0] B [M0] B [L1] B [M1, wait] B.  Row 1: B [L0] B [M0] B [L1, wait] B [M1].  (L = fragment reads
     // of a half step + its LDS-DMA pieces, M = its MFMAs, B = s_barrier of all 8 waves.)  Between two barriers exactly one wave of
     // every SIMD issues MFMAs.  Ordering: every wave counts its own requests down (rc_wait) before the step's 4th barrier, so
     // the next step's weights / window are readable right behind it (row 0) or one barrier later (row 1); every fragment read of a
@@ -302,7 +203,7 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int h
     auto mmaH = [&]() {
         if (RC_EXP & 4) return;
         __builtin_amdgcn_sched_barrier(0);
-        if (RC_PP_PRIO) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
         if constexpr (SPLIT == 1) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
@@ -320,7 +221,7 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int h
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
                 }
         }
-        if (RC_PP_PRIO) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
     unsigned long long tmark = RC_STAMP == 2 ? __builtin_readcyclecounter() : 0ull;
@@ -402,40 +303,6 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int h
     }
     };
     if (wm == 0) steps(RcRow<0>{}); else steps(RcRow<1>{});
-#else
-    for (int ch = 0; ch < p.nchunk; ++ch) {
-        const int wbuf = (c.wpar + ch) & 1;
-        const bool lastc = ch + 1 == p.nchunk;
-#pragma unroll
-        for (int k = 0; k < TAPS; ++k) {
-            // weights of the step two ahead -> ring slot (ws + 2) % 3, wrapping into the next tile at the end of this one
-            const int kn = (k + 2) % TAPS;
-            int cn = ch + (k + 2) / TAPS;
-            cn = cn == p.nchunk ? 0 : cn;
-            const char* wsrc = c.w_base + (long)kn * p.w_tap_stride + (long)cn * 128;
-            const unsigned wdst = c.lds0 + RC_RING + (ws == 0 ? 2 : ws - 1) * RC_W_BYTES + wave * 1024;
-            int nwin = 0;
-            if (k == 0 && !(RC_EXP & 1)) {                 // next window into the idle buffer: next chunk, or the next tile's chunk 0
-                if (!lastc) { issue_a(ch + 1, wbuf ^ 1); nwin = nq; }
-                else if (h1 > 0) { issue_a_next(wbuf ^ 1); nwin = nq1; }
-            }
-            if (!RC_ILV && !(RC_EXP & 1)) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) dma16(wdst + q * 8192, c.vow[q], wsrc);
-            }
-            auto hook = [&](int g) { if (RC_ILV && !(RC_EXP & 1)) dma16(wdst + g * 8192, c.vow[g], wsrc); };
-            int kv = k;                                     // opaque: the taps' LDS addresses are recomputed per step, not hoisted
-            asm volatile("" : "+s"(kv));                    // out of the chunk loop into 5 x (NI + 2) live registers
-            if (!(RC_EXP & 4)) compute(wbuf, ws, kv, hook);
-            else { hook(0); hook(1); hook(2); hook(3); }
-            // step end: the weights of the next step (requested one step ago) and anything older must have landed; LDS-DMA
-            // completes in issue order, so it is enough to bound what may still be in flight: this step's own requests
-            if (RC_EXP & 1) rc_wait(0); else rc_wait(4 + nwin);
-            lds_barrier();
-            ws = (ws == 2) ? 0 : ws + 1;
-        }
-    }
-#endif
     c.ws = ws;
     c.wpar = (c.wpar + p.nchunk) & 1;
 
