@@ -291,6 +291,34 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
         }
     }
     lds_barrier();
+    if (p.sidx) {
+        // softmax over the valid columns of every row + its expected column index, from the staged tile (32 threads per row, 4
+        // columns each; the three reductions run over the 32 lanes of a half wave).  ntiles == 1: the tile holds whole rows.
+        const int kl = min(p.klen[z], p.n), ql = min(p.qlen[z], p.m);
+        float* so = p.sidx + (long)z * p.m;
+#pragma unroll 4
+        for (int ps = 0; ps < NPS; ++ps) {
+            const int rl = ps * RPP + (int)trow;
+            const int row = m0 + rl;
+            const float4 v = *(const float4*)(cs + rl * 128 + c4);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            float mx = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) mx = (c4 + u < kl) ? fmaxf(mx, vv[u]) : mx;
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 32));
+            float se = 0.f, si = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float e = (c4 + u < kl) ? __expf(vv[u] - mx) : 0.f;
+                se += e;
+                si += e * (float)(c4 + u);
+            }
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) { se += __shfl_xor(se, off, 32); si += __shfl_xor(si, off, 32); }
+            if ((tid & 31) == 0 && rl < BM && row < p.m) so[row] = row < ql ? si / se : 0.f;
+        }
+    }
     if (pre) {
         const __amdgpu_buffer_rsrc_t ro = make_rsrc(of ? of + (long)m0 * p.ldo : nullptr, of ? (long)rows_out * p.ldo * 4 : 0);
         const __amdgpu_buffer_rsrc_t rb = make_rsrc(ob ? ob + (long)m0 * p.ldob : nullptr, ob ? (long)rows_out * p.ldob : 0);
@@ -446,12 +474,13 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
         return efts_fail(EFTS_ESHAPE, "efts_gemm: row stride smaller than nchunk*128 bytes");
     if (a->lda > (1 << 23) || a->ldb > (1 << 23)) return efts_fail(EFTS_ESHAPE, "efts_gemm: row stride above 8 MiB");
     if (a->out_bf16 && !(a->out_split == 1 || a->out_split == 2)) return efts_fail(EFTS_EINVAL, "efts_gemm: out_split must be 1 or 2");
-    if (!a->out_f32 && !a->out_bf16) return efts_fail(EFTS_EINVAL, "efts_gemm: no output");
+    if (!a->out_f32 && !a->out_bf16 && !a->soft_index) return efts_fail(EFTS_EINVAL, "efts_gemm: no output");
 
     GemmKernelArgs k;
     k.a = (const char*)a->a; k.b = (const char*)a->b;
     k.bias = a->bias; k.resid = a->resid; k.rowmask = a->rowmask;
     k.out_f32 = a->out_f32; k.out_bf16 = (char*)a->out_bf16; k.out_lo = (char*)a->out_bf16_lo; k.sign = (char*)a->sign_mask;
+    k.sidx = a->soft_index; k.klen = a->key_len; k.qlen = a->query_len;
     if (a->out_bf16_lo && (!a->out_bf16 || a->out_split != 1 || a->plane_act || ((uintptr_t)a->out_bf16_lo & 7)))
         return efts_fail(EFTS_EINVAL, "efts_gemm: out_bf16_lo goes with an un-activated split-1 out_bf16 plane (8-byte aligned)");
     k.lda = a->lda; k.ldb = a->ldb; k.b_tap_stride = a->b_tap_stride; k.ldr = a->ldr; k.ldo = a->ldo; k.ldob = a->ldob;
@@ -470,6 +499,8 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
                (!a->resid || ((a->ldr & 3) == 0 && ((uintptr_t)a->resid & 15) == 0 && (a->resid_batch_stride & 3) == 0)) &&
                (!a->out_bf16 || ((a->ldob & 7) == 0 && ((uintptr_t)a->out_bf16 & 7) == 0 && (a->outb_batch_stride & 7) == 0));
     k.prof = nullptr; k.dbg = 0;
+    if (a->soft_index && (!a->key_len || !a->query_len || a->n > BN || nb2 > 1 || a->resid || a->out_bf16 || a->taps != 1 || a->act != EFTS_ACT_NONE))
+        return efts_fail(EFTS_EINVAL, "efts_gemm: soft_index needs key_len / query_len, n <= 128, one tap, no activation, residual, plane output or batch2");
     if (a->sign_mask && (a->n % 128 || a->batch > 1 || nb2 > 1 || !k.vec_ok || ((uintptr_t)a->sign_mask & 15)))
         return efts_fail(EFTS_EINVAL, "efts_gemm: sign_mask needs n %% 128 == 0, batch 1, 16-byte aligned output rows and mask");
     hipStream_t st = (hipStream_t)stream;
@@ -478,7 +509,7 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     // for the bit-equality tests between the kernels (they all compute identical results).
     const int tiling = a->tiling;
     if (tiling < EFTS_TILING_AUTO || tiling > EFTS_TILING_RESIDENT) return efts_fail(EFTS_EINVAL, "efts_gemm: unknown tiling %d", tiling);
-    const bool generic_only = a->out_bf16_lo != nullptr || nb2 > 1;      // the remainder plane / the outer batch: gemm_kernel only
+    const bool generic_only = a->out_bf16_lo != nullptr || nb2 > 1 || a->soft_index != nullptr;      // the remainder plane / the outer batch / the soft index: gemm_kernel only
     const bool no_narrow = generic_only || a->sign_mask != nullptr;      // the sign words: gemm_kernel and conv5_kernel write them
     if (generic_only && tiling > EFTS_TILING_GENERIC) return efts_fail(EFTS_EINVAL, "efts_gemm: out_bf16_lo / batch2 need the generic tiling");
     const dim3 grid(k.mtiles * k.ntiles, a->batch, nb2);                  // one workgroup per 124 x 128 tile, 2 resident per CU

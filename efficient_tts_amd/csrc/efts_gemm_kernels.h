@@ -27,6 +27,9 @@ struct GemmKernelArgs {
     char* out_bf16;
     char* out_lo;               // out_split 1 only: separate plane for the bf16 remainder (generic gemm_kernel only)
     char* sign;                 // sign words of the activated outputs (efts_abi.h `sign_mask`), row stride n / 8 bytes, or null
+    float* sidx;                // soft index of the softmax over each output row (efts_abi.h `soft_index`), [batch][m], or null
+    const int* klen;            // valid columns per batch item
+    const int* qlen;            // valid rows per batch item
     long lda, ldb, b_tap_stride, ldr, ldo, ldob;
     long a_bs, b_bs, r_bs, m_bs, o_bs, ob_bs;
     long a_bs2, b_bs2, o_bs2;   // outer batch (blockIdx.z)

@@ -38,7 +38,7 @@ class GemmArgs(C.Structure):
         ("out_split", i32), ("batch2", i32),
         ("a_batch2_stride", i64), ("b_batch2_stride", i64), ("out_batch2_stride", i64),
         ("dilation", i32), ("plane_act", i32), ("plane_slope", f32),
-        ("out_bf16_lo", vp), ("tiling", i32), ("sign_mask", vp),
+        ("out_bf16_lo", vp), ("tiling", i32), ("sign_mask", vp), ("soft_index", vp), ("key_len", vp), ("query_len", vp),
     ]
 
 

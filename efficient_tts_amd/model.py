@@ -194,6 +194,7 @@ class EfficientTTSCNN(torch.nn.Module):
         self.decoder = _ResConvBlock(n_decoder_layer, n_channels, k_size, a, ap, dropout_rate, use_weight_norm)
         self.mel_output_layer = torch.nn.Linear(n_channels, odim)
         self.duration_predictor = _DurationPredictor(n_channels, n_duration_layer, n_channels, offset=duration_offset)
+        self.fuse_soft_index = True         # T1 <= 128: q.k^T, softmax and soft index in one launch (False: scores stored, efts_attn_soft_index)
         self.graphs = True                  # plain eval calls replay a per-shape hipGraph (False: every kernel launched eagerly)
         self._graph_cache = GraphCache()
         self._infer_cache = GraphCache(capacity=64)      # free-running inference: two phases per (bucketed) shape
@@ -453,7 +454,7 @@ class EfficientTTSCNN(torch.nn.Module):
         key = ("fwd", tuple(text.shape), tuple(speech.shape), text.dtype, speech.dtype, text_lengths.dtype, speech_lengths.dtype)
         ws = self._workspace(("fwd", text.shape[0], text.shape[1], speech.shape[1]), dev)
         # the graph is valid while the buffers its launches point at live: this workspace, the packed planes, the parameters
-        tag = (ws.serial, self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.side_stream, self.RESCONV_MIN_ROWS)
+        tag = (ws.serial, self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.side_stream, self.RESCONV_MIN_ROWS, self.fuse_soft_index)
 
         def body(t, tl, sp, sl):
             (_, stats, imv, ralpha, mel_pred, _), _ = self._forward_impl(t, tl, sp, sl)
@@ -504,14 +505,20 @@ class EfficientTTSCNN(torch.nn.Module):
         _, q_p = self._res_stack(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2, False, x_lo=pre_l)   # :162
         main.wait_event(k_ready)
 
-        scores = ws.tensor("scores", (B, T2, T1))                                 # :390 q.k/sqrt(D)
-        O.gemm(a=q_p, b_ptr=key_p.ptr, ldb=key_p.ld, m=T2, n=T1, batch=B, a_batch_stride=rs2.Tp * q_p.ld,
-               b_batch_stride=rs1.Tp * key_p.ld, alpha=O.INV_SQRT(C), out_f32_ptr=scores.data_ptr(), ldo=T1,
-               out_batch_stride=T2 * T1)
         sidx = ws.tensor("sidx", (B, T2))
         imv = torch.empty(B, T2, dtype=torch.float32, device=dev)              # returned to the caller: written in place, no copy
         alpha = ws.tensor("alpha", (B, T1, T2)) if keep else None
-        O.attn_soft_index(scores, T1, tl, ml, sidx, alpha, B, T1, T2)             # :391-398, :168, :312
+        if T1 <= 128 and not keep and self.fuse_soft_index:
+            # :390-398, :168, :312 in one launch: a 128-column tile holds whole score rows, so the softmax over the keys and its
+            # expected index are taken from the staged tile and the 4 B T2 T1 bytes of scores are neither written nor re-read
+            O.gemm(a=q_p, b_ptr=key_p.ptr, ldb=key_p.ld, m=T2, n=T1, batch=B, a_batch_stride=rs2.Tp * q_p.ld,
+                   b_batch_stride=rs1.Tp * key_p.ld, alpha=O.INV_SQRT(C), soft_index=sidx, key_len=tl, query_len=ml)
+        else:
+            scores = ws.tensor("scores", (B, T2, T1))                             # :390 q.k/sqrt(D)
+            O.gemm(a=q_p, b_ptr=key_p.ptr, ldb=key_p.ld, m=T2, n=T1, batch=B, a_batch_stride=rs2.Tp * q_p.ld,
+                   b_batch_stride=rs1.Tp * key_p.ld, alpha=O.INV_SQRT(C), out_f32_ptr=scores.data_ptr(), ldo=T1,
+                   out_batch_stride=T2 * T1)
+            O.attn_soft_index(scores, T1, tl, ml, sidx, alpha, B, T1, T2)         # :391-398, :168, :312
         O.imv_scan(sidx, tl, ml, imv, B, T2)                                      # :314-323
         e, lde = ws.tensor("e", (B, T1)), ws.tensor("lde", (B, T1))
         O.aligned_positions(imv, tl, ml, float(self.sigma_e), float(self.duration_offset), e, lde, B, T1, T2)  # :178-180, :203-216

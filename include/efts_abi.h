@@ -123,6 +123,14 @@ typedef struct efts_gemm_args {
      * 128 * group + 4 * q + u is positive.  Needs n % 128 == 0, batch 1, 16-byte aligned fp32 / plane rows (the vector epilogue),
      * and runs on the generic or wide tiling only.  NULL: not written. */
     void* sign_mask;
+    /* attention scores -> expected key index in the epilogue (scaled_dot_product_attention + the soft index of imv_generator,
+     * nntts/models/efficient_tts.py:391-398, :312): soft_index[b][row] = sum_i i * softmax_i(out[b][row][i < key_len[b]]) for
+     * row < query_len[b], 0 beyond -- what efts_attn_soft_index computes from the stored scores, without storing them
+     * (out_f32 may be NULL then).  Needs n <= 128 (one column tile holds a whole row), generic tiling, no residual / plane
+     * outputs.  soft_index: fp32 [batch][m]; key_len, query_len: int32 [batch].  NULL: not computed. */
+    float* soft_index;
+    const int32_t* key_len;
+    const int32_t* query_len;
 } efts_gemm_args;
 
 #define EFTS_TILING_AUTO 0

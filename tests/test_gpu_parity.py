@@ -363,3 +363,44 @@ def test_inference_graph_path_equals_exact_path(golden_dir, model):
             assert float((ra - ra_exact).abs().max()) <= 1e-5
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[1][0], outs[2][0])
         assert float((outs[2][0][0, ::2].cpu() - torch.from_numpy(g[f"mel_pred{n}"])[0]).abs().max()) <= MEL_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 37, 211), (2, 128, 800), (4, 100, 124)])
+def test_soft_index_in_the_gemm_epilogue_equals_the_two_kernel_path(shape):
+    """efts_gemm(soft_index=...) -- q.k^T, softmax over the valid keys and its expected key index in one launch
+    (efficient_tts.py:390-398, :312) -- against efts_gemm + efts_attn_soft_index on the stored scores, ragged key / query
+    lengths; the reductions associate differently (32 lanes x 4 columns against 64 lanes, stride 64), so equal to rounding; and the
+    model with the fused launch against the model without it."""
+    from efficient_tts_amd import lib as L, ops as P
+    B, T1, T2 = shape
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    C = 512
+    rs1, rs2 = P.Rows(B, T1), P.Rows(B, T2)
+    q = P.Plane.for_rows(rs2, C, 2, dev); P.pack_rows(torch.randn(B, T2, C, device=dev), None, q, rs2)
+    k = P.Plane.for_rows(rs1, C, 2, dev); P.pack_rows(torch.randn(B, T1, C, device=dev), None, k, rs1)
+    tl = torch.randint(max(1, T1 // 2), T1 + 1, (B,), dtype=torch.int32, device=dev); tl[0] = T1
+    ml = torch.randint(max(1, T2 // 2), T2 + 1, (B,), dtype=torch.int32, device=dev); ml[0] = T2
+    scores = torch.empty(B, T2, T1, device=dev)
+    s_ref, s_fused = torch.empty(B, T2, device=dev), torch.full((B, T2), -1.0, device=dev)
+    common = dict(a=q, b_ptr=k.ptr, ldb=k.ld, m=T2, n=T1, batch=B, a_batch_stride=rs2.Tp * q.ld, b_batch_stride=rs1.Tp * k.ld, alpha=P.INV_SQRT(C))
+    with P.stream_scope():
+        P.gemm(out_f32_ptr=scores.data_ptr(), ldo=T1, out_batch_stride=T2 * T1, **common)
+        P.attn_soft_index(scores, T1, tl, ml, s_ref, None, B, T1, T2)
+        P.gemm(soft_index=s_fused, key_len=tl, query_len=ml, **common)
+        torch.cuda.synchronize()
+    assert torch.isfinite(s_fused).all()
+    assert (s_fused - s_ref).abs().max().item() <= 2e-4 * T1, (s_fused - s_ref).abs().max().item()
+    for b in range(B):
+        assert (s_fused[b, int(ml[b]):] == 0).all()
+    # fp64 restatement on the stored scores
+    want = torch.zeros(B, T2, dtype=torch.float64, device=dev)
+    for b in range(B):
+        p = torch.softmax(scores[b, :, :int(tl[b])].double(), dim=-1)
+        want[b] = (p * torch.arange(int(tl[b]), device=dev, dtype=torch.float64)).sum(-1)
+        want[b, int(ml[b]):] = 0
+    assert (s_fused.double() - want).abs().max().item() <= 1e-4 * T1
+    with pytest.raises(Exception):                                  # more than one column tile: not in the epilogue
+        P.gemm(a=q, b_ptr=q.ptr, ldb=q.ld, m=T2, n=T2 if T2 > 128 else 129, batch=B, a_batch_stride=rs2.Tp * q.ld, b_batch_stride=rs2.Tp * q.ld,
+               soft_index=s_fused, key_len=tl, query_len=ml)
