@@ -262,6 +262,8 @@ class TrainEngine:
         main = torch.cuda.current_stream(dev)
         side = m._side_stream(dev)
         side.wait_stream(main)
+        if self.mark is not None:
+            self.mark("step_start")
         dp = m.duration_predictor
         ln0, ln1 = dp.conv[0][2], dp.conv[1][2]
         # Dropout(0.1) of the duration predictor is active in train() mode like the reference's
@@ -309,6 +311,8 @@ class TrainEngine:
         O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, act=L.ACT_LEAKY, slope=m.slope, bias=m.mel_prenet[0].bias,
                rowmask_ptr=gap2.data_ptr(), out_f32_ptr=pre_f.ptr, ldo=C, out_plane=pre_p)
         q_f, q_p, me_saved = self._stack_fwd(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2)
+        if self.mark is not None:
+            self.mark("fwd_mel_encoder_done")
 
         main.wait_event(ev_kv)                                      # K, V from the side stream
         scale = O.INV_SQRT(C)
@@ -323,6 +327,8 @@ class TrainEngine:
         ralpha = ws.tensor("Tralpha", (B, T1, T2))
         ra_p = ws.plane("Tra_p", rs2, T1, 2)
         O.reconst_alpha(e, tl, ml, float(m.sigma), ralpha, ra_p, B, T1, T2, rs2.Tp)
+        if self.mark is not None:
+            self.mark("fwd_alignment_done")
 
         vt = ws.raw_plane("Tvt", B * C + 136, T1, 2)
         O.pack_vt(val_f, vt, B, T1, rs1.Tp, C)
@@ -331,6 +337,8 @@ class TrainEngine:
                rowmask_ptr=len2.data_ptr(), rowmask_batch_stride=rs2.Tp, out_f32_ptr=h_f.ptr, ldo=C, out_batch_stride=rs2.Tp * C,
                out_plane=h_p, outb_batch_stride=rs2.Tp * h_p.ld)
         d_f, d_p, dec_saved = self._stack_fwd(ws, "dec", "decoder", pk, rs2, h_f, h_p, gap2.data_ptr(), split)
+        if self.mark is not None:
+            self.mark("fwd_decoder_done")
         mel = ws.f32("Tmel_pred", rs2, odim)
         wh = pk["head"]
         O.gemm(a=d_p, b_ptr=wh.ptr, ldb=wh.ld, m=rs2.rows, n=odim, bias=m.mel_output_layer.bias, rowmask_ptr=len2.data_ptr(),
@@ -391,6 +399,8 @@ class TrainEngine:
         # decoder; its input gradient dH is masked like H (efficient_tts.py:193-194) and also emitted as a split-2 plane
         dH_p = ws.plane("BdH_p", rs2, C, 2)
         dH = self._stack_bwd(ws, "dec", "decoder", rs2, G, dec_saved, gap2.data_ptr(), len2.data_ptr(), dH_p)
+        if self.mark is not None:
+            self.mark("bwd_decoder_done")
         if self.bucket_hook:
             self.bucket_hook(0)
 
@@ -441,16 +451,23 @@ class TrainEngine:
 
         ev_gk = torch.cuda.Event()
         ev_gk.record(main)
+        if self.mark is not None:
+            self.mark("bwd_alignment_done")
         side.wait_event(ev_gk)                                      # dK, dV are ready
-        with O.on_stream(side):
-            self._ws_tag = "s"
-            # ---- value / key Linears -> text encoder -> embedding
-            L.check(_lib().efts_act_bwd(GV.ptr, None, None, None, 0.0, 0, ws.f32("Bscratch1", rs1, C).ptr, None, 0, 1,
+
+        def kv_param_grads():                                        # bias + weight gradients of the value / key Linears
+            sc = ws.f32("Bscratch1" + self._ws_tag, rs1, C)
+            L.check(_lib().efts_act_bwd(GV.ptr, None, None, None, 0.0, 0, sc.ptr, None, 0, 1,
                                         g["text_encoder_value.bias"].data_ptr(), rs1.rows, C, O._stream()), "efts_act_bwd")
-            L.check(_lib().efts_act_bwd(GK.ptr, None, None, None, 0.0, 0, ws.f32("Bscratch1", rs1, C).ptr, None, 0, 1,
+            L.check(_lib().efts_act_bwd(GK.ptr, None, None, None, 0.0, 0, sc.ptr, None, 0, 1,
                                         g["text_encoder_key.bias"].data_ptr(), rs1.rows, C, O._stream()), "efts_act_bwd")
             self._wgrad(ws, GV.ptr, C, te_f.ptr, C, C, 1, rs1.rows, None, None, g["text_encoder_value.weight"], None)
             self._wgrad(ws, GK.ptr, C, te_f.ptr, C, C, 1, rs1.rows, None, None, g["text_encoder_key.weight"], None)
+
+        with O.on_stream(side):
+            self._ws_tag = "s"
+            # ---- value / key Linears -> text encoder -> embedding
+            kv_param_grads()
             Gt0, Gt = ws.f32("Bte_G0", rs1, C), ws.f32("Bte_G1x", rs1, C)
             wtv, wtk = self.wt["value"], self.wt["key"]
             O.gemm(a=GV_p, b_ptr=wtv.ptr, ldb=wtv.ld, m=rs1.rows, n=C, rowmask_ptr=gap1.data_ptr(), out_f32_ptr=Gt0.ptr, ldo=C)
@@ -463,6 +480,8 @@ class TrainEngine:
 
         # ---- mel encoder + prenet
         Gm = self._stack_bwd(ws, "me", "mel_encoder", rs2, GQ, me_saved, gap2.data_ptr(), gap2.data_ptr(), None)
+        if self.mark is not None:
+            self.mark("bwd_mel_encoder_done")
         dzp_f = ws.f32("Bpre_dz", rs2, C)
         self._act_bwd(Gm.ptr, pre_f.ptr, None, gap2.data_ptr(), 3, dzp_f, None, g["mel_prenet.0.bias"], rs2.rows, C)
         self._wgrad(ws, dzp_f.ptr, C, mel_in_f.ptr, odim, odim, 1, rs2.rows, None, None, g["mel_prenet.0.weight"], None)
