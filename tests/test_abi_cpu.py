@@ -36,15 +36,22 @@ def test_version_and_argument_errors(lib):
         L.check(lib.efts_gemm(g, None), "efts_gemm")
 
 
-def test_gemm_args_layout_matches_header():
-    """sizeof(struct efts_gemm_args) as compiled by gcc == the ctypes mirror."""
+def test_args_layouts_match_header():
+    """sizeof and the offsets of the round-2 fields of efts_gemm_args / efts_resconv5_args as compiled by gcc == the ctypes mirrors."""
     import subprocess, tempfile, ctypes
-    src = '#include <stdio.h>\n#include "efts_abi.h"\nint main(){printf("%zu",sizeof(efts_gemm_args));return 0;}\n'
+    fields_g = ["out_bf16_lo", "tiling", "sign_mask", "soft_index", "key_len", "query_len"]
+    fields_r = ["x", "x_lo", "x_f32", "w", "split", "rowmask", "y_f32", "y", "y_lo", "y_split", "plan"]
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "efts_abi.h"\nint main(){printf("%zu %zu", sizeof(efts_gemm_args), sizeof(efts_resconv5_args));\n'
+    src += "".join(f'printf(" %zu", offsetof(efts_gemm_args, {f}));' for f in fields_g)
+    src += "".join(f'printf(" %zu", offsetof(efts_resconv5_args, {f}));' for f in fields_r)
+    src += "return 0;}\n"
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
-        size = int(subprocess.check_output([os.path.join(d, "s")]))
-    assert size == ctypes.sizeof(L.GemmArgs)
+        got = [int(v) for v in subprocess.check_output([os.path.join(d, "s")]).split()]
+    want = [ctypes.sizeof(L.GemmArgs), ctypes.sizeof(L.ResConv5Args)]
+    want += [getattr(L.GemmArgs, f).offset for f in fields_g] + [getattr(L.ResConv5Args, f).offset for f in fields_r]
+    assert got == want
 
 
 def test_model_state_dict_keys_match_reference_layout():
