@@ -166,10 +166,10 @@ class EfficientTTSCNN(torch.nn.Module):
             raise ValueError("symbol_embedding_dim must equal n_channels (the reference adds them residually)")
         if k_size != 5:
             raise NotImplementedError("k_size must be 5 (row-space gap = 2)")
-        if not delta_e_method_1 or share_text_encoder_key_value or use_mel_query_fc:
-            raise NotImplementedError("only the shipped configuration (delta_e_method_1, separate K/V, no mel_query_fc) is implemented")
-        if not use_masking or use_weighted_masking:
-            raise NotImplementedError("FastSpeechLoss is implemented for use_masking=True (the egs/lj YAML)")
+        if not delta_e_method_1:
+            raise NotImplementedError("delta_e_method_1=False (efficient_tts.py:205-213) is not implemented (no shipped config selects it)")
+        if use_weighted_masking:
+            raise NotImplementedError("FastSpeechLoss(use_weighted_masking=True) is not implemented (no shipped config selects it)")
         if n_channels % 256 or odim > 128:
             raise NotImplementedError("n_channels must be a multiple of 256 and odim <= 128")
         self.precision = precision
@@ -178,6 +178,7 @@ class EfficientTTSCNN(torch.nn.Module):
         self.duration_offset, self.sigma, self.sigma_e = duration_offset, sigma, sigma_e
         self.delta_e_method_1 = delta_e_method_1
         self.share_text_encoder_key_value = share_text_encoder_key_value
+        self.use_masking = bool(use_masking)        # False (the reference ctor default): the two losses are means over the padded tensors
         self.slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
         self.dropout_rate = dropout_rate
         a, ap = nonlinear_activation, nonlinear_activation_params
@@ -186,11 +187,12 @@ class EfficientTTSCNN(torch.nn.Module):
         self.text_embedding_table = torch.nn.Embedding(num_symbols, symbol_embedding_dim)
         self.text_encoder = _ResConvBlock(n_text_encoder_layer, n_channels, k_size, a, ap, dropout_rate, use_weight_norm)
         self.text_encoder_key = torch.nn.Linear(n_channels, n_channels)
-        self.text_encoder_value = torch.nn.Linear(n_channels, n_channels)
+        if not share_text_encoder_key_value:        # (:72-75) shared: the value IS the key projection
+            self.text_encoder_value = torch.nn.Linear(n_channels, n_channels)
         self.mel_prenet = torch.nn.Sequential(torch.nn.Linear(odim, n_channels), getattr(torch.nn, a)(**ap),
                                               torch.nn.Dropout(dropout_rate))
         self.mel_encoder = _ResConvBlock(n_mel_encoder_layer, n_channels, k_size, a, ap, dropout_rate, use_weight_norm)
-        self.mel_query_fc = None
+        self.mel_query_fc = torch.nn.Linear(n_channels, n_channels) if use_mel_query_fc else None      # (:90-95)
         self.decoder = _ResConvBlock(n_decoder_layer, n_channels, k_size, a, ap, dropout_rate, use_weight_norm)
         self.mel_output_layer = torch.nn.Linear(n_channels, odim)
         self.duration_predictor = _DurationPredictor(n_channels, n_duration_layer, n_channels, offset=duration_offset)
@@ -251,8 +253,12 @@ class EfficientTTSCNN(torch.nn.Module):
         folded = folded or {}
         wt = wt or {}
         mods = [(name, conv, conv.kernel_size[0]) for name, conv in self._conv_modules()]
-        mods += [(name, lin, 1) for name, lin in (("key", self.text_encoder_key), ("value", self.text_encoder_value),
-                                                    ("prenet", self.mel_prenet[0]), ("head", self.mel_output_layer))]
+        lins = [("key", self.text_encoder_key), ("prenet", self.mel_prenet[0]), ("head", self.mel_output_layer)]
+        if not self.share_text_encoder_key_value:
+            lins.append(("value", self.text_encoder_value))
+        if self.mel_query_fc is not None:
+            lins.append(("qfc", self.mel_query_fc))
+        mods += [(name, lin, 1) for name, lin in lins]
         groups: Dict[Tuple, list] = {}
         for name, mod, taps in mods:
             cout, cin = mod.weight_v.shape[:2] if hasattr(mod, "weight_g") else mod.weight.shape[:2]
@@ -373,12 +379,15 @@ class EfficientTTSCNN(torch.nn.Module):
         val_f = ws.f32("val_f", rs1, C)
         val_p = ws.plane("val_p", rs1, C, self.split)
         lm = None if len1 is None else len1.data_ptr()
-        wk, wv = pk["key"], pk["value"]
+        shared = self.share_text_encoder_key_value            # (:150-153) the value is the key projection: same weights, the
+        wk = pk["key"]                                        # second launch only writes it in the value's formats
+        wv = wk if shared else pk["value"]
+        vbias = self.text_encoder_key.bias if shared else self.text_encoder_value.bias
         O.gemm(a=h_p, b_ptr=wk.ptr, ldb=wk.ld, m=rs1.rows, n=C, bias=self.text_encoder_key.bias,
                rowmask_ptr=lm if lm is not None else gap1.data_ptr(), out_plane=key_p)
         if on_key is not None:
             on_key()
-        O.gemm(a=h_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=self.text_encoder_value.bias,
+        O.gemm(a=h_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=vbias,
                rowmask_ptr=lm if lm is not None else gap1.data_ptr(), out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p)
         if vt is not None:
             O.pack_vt(val_f, vt, rs1.B, rs1.T, rs1.Tp, C)
@@ -502,7 +511,13 @@ class EfficientTTSCNN(torch.nn.Module):
         O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, act=L.ACT_LEAKY, slope=self.slope,
                bias=self.mel_prenet[0].bias, rowmask_ptr=gap2.data_ptr(), out_f32_ptr=None if pre_f is None else pre_f.ptr,
                ldo=C, out_plane=pre_p, out_plane_lo=pre_l)
-        _, q_p = self._res_stack(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2, False, x_lo=pre_l)   # :162
+        if self.mel_query_fc is None:
+            _, q_p = self._res_stack(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2, False, x_lo=pre_l)   # :162
+        else:                                                                      # :163-164 Linear(C, C) in front of the attention
+            _, mh_p = self._res_stack(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), self.split, False, x_lo=pre_l)
+            q_p = ws.plane("q_p", rs2, C, 2)
+            wq = pk["qfc"]
+            O.gemm(a=mh_p, b_ptr=wq.ptr, ldb=wq.ld, m=rs2.rows, n=C, bias=self.mel_query_fc.bias, rowmask_ptr=gap2.data_ptr(), out_plane=q_p)
         main.wait_event(k_ready)
 
         sidx = ws.tensor("sidx", (B, T2))
@@ -531,7 +546,11 @@ class EfficientTTSCNN(torch.nn.Module):
         main.wait_stream(side)                                                     # duration predictor done
 
         out3 = torch.empty(3, dtype=torch.float32, device=dev)                     # :220-227
-        O.masked_losses(mel.ptr, self.odim, speech, ml, dur, lde, tl, out3, ws.tensor("loss_ws", (1024,)), B, T1,
+        # use_masking=False (fastspeech_loss.py:63-67): plain means over the padded tensors = the masked sums taken with full lengths
+        # (mel_pred, dur_pred and log_delta_e are zero beyond each item's length, speech is whatever the caller padded with)
+        ml_loss = ml if self.use_masking else torch.full_like(ml, T2)
+        tl_loss = tl if self.use_masking else torch.full_like(tl, T1)
+        O.masked_losses(mel.ptr, self.odim, speech, ml_loss, dur, lde, tl_loss, out3, ws.tensor("loss_ws", (1024,)), B, T1,
                         rs1.Tp, T2, rs2.Tp, self.odim)
         mel_pred = mel.view().clone()
         ret = (out3[0], LazyStats(out3), imv, ralpha, mel_pred, speech)
@@ -598,8 +617,9 @@ class EfficientTTSCNN(torch.nn.Module):
         O.mask_rows(e_f.ptr, len1.data_ptr(), x_f, x_p, rs1.rows, C)
         _, h_p = self._res_stack(ws, "te", "text_encoder", pk, rs1, x_f, x_p, len1.data_ptr(), self.split, False)
         val_f, val_p = ws.f32("val_f", rs1, C), ws.plane("val_p", rs1, C, self.split)
-        wv = pk["value"]
-        O.gemm(a=h_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=self.text_encoder_value.bias,
+        shared = self.share_text_encoder_key_value            # (:252-253)
+        wv = pk["key"] if shared else pk["value"]
+        O.gemm(a=h_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=(self.text_encoder_key if shared else self.text_encoder_value).bias,
                rowmask_ptr=len1.data_ptr(), out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p)
         delta = self._duration(ws, pk, rs1, val_p, len1, len1.data_ptr(), 1)          # zero beyond each length
         d2 = delta.view(B, rs1.Tp)[:, :T1].contiguous()

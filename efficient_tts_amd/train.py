@@ -66,6 +66,7 @@ def grad_layout(model) -> List[Tuple[str, torch.nn.Parameter]]:
     for i in reversed(range(len(model.decoder.layers))):
         order += conv(f"decoder.layers.{i}.")
     order += conv("duration_predictor.")
+    order += conv("mel_query_fc.")                       # (use_mel_query_fc: its gradient is ready in front of the mel encoder's)
     for i in reversed(range(len(model.mel_encoder.layers))):
         order += conv(f"mel_encoder.layers.{i}.")
     order += conv("mel_prenet.")
@@ -125,7 +126,12 @@ class TrainEngine:
                 if hasattr(conv, "weight_g") and (conv.out_channels % 64 or conv.in_channels % 64 or taps > 5):
                     self.folded[name] = torch.empty(conv.out_channels, conv.in_channels, taps, device=dev)   # row-kernel shapes only
                 self.wt[name] = PackedWeight(conv.in_channels, conv.out_channels, taps, m.split, dev)
-        for name, lin in (("key", m.text_encoder_key), ("value", m.text_encoder_value), ("head", m.mel_output_layer)):
+        lins = [("key", m.text_encoder_key), ("head", m.mel_output_layer)]
+        if not m.share_text_encoder_key_value:
+            lins.append(("value", m.text_encoder_value))
+        if m.mel_query_fc is not None:
+            lins.append(("qfc", m.mel_query_fc))
+        for name, lin in lins:
             if name not in self.wt:
                 self.wt[name] = PackedWeight(lin.in_features, lin.out_features, 1, m.split, dev)
         pk = m._weights(self.folded, self.wt)
@@ -280,11 +286,13 @@ class TrainEngine:
             te_f, te_p, te_saved = self._stack_fwd(ws, "te", "text_encoder", pk, rs1, emb_f, emb_p, gap1.data_ptr(), split)
             key_f, key_p = ws.f32("Tkey_f", rs1, C), ws.plane("Tkey_p", rs1, C, 2)
             val_f, val_p = ws.f32("Tval_f", rs1, C), ws.plane("Tval_p", rs1, C, split)
-            wk, wv = pk["key"], pk["value"]
+            shared = m.share_text_encoder_key_value                 # efficient_tts.py:150-153: the value is the key projection
+            wk = pk["key"]
+            wv = wk if shared else pk["value"]
             O.gemm(a=te_p, b_ptr=wk.ptr, ldb=wk.ld, m=rs1.rows, n=C, bias=m.text_encoder_key.bias, rowmask_ptr=len1.data_ptr(),
                    out_f32_ptr=key_f.ptr, ldo=C, out_plane=key_p)
-            O.gemm(a=te_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=m.text_encoder_value.bias, rowmask_ptr=len1.data_ptr(),
-                   out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p)
+            O.gemm(a=te_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=(m.text_encoder_key if shared else m.text_encoder_value).bias,
+                   rowmask_ptr=len1.data_ptr(), out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p)
             ev_kv = torch.cuda.Event()
             ev_kv.record(side)
             # duration predictor (efficient_tts.py:219): needs V only
@@ -310,7 +318,14 @@ class TrainEngine:
         wp = pk["prenet"]
         O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, act=L.ACT_LEAKY, slope=m.slope, bias=m.mel_prenet[0].bias,
                rowmask_ptr=gap2.data_ptr(), out_f32_ptr=pre_f.ptr, ldo=C, out_plane=pre_p)
-        q_f, q_p, me_saved = self._stack_fwd(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2)
+        if m.mel_query_fc is None:
+            q_f, q_p, me_saved = self._stack_fwd(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2)
+        else:                                                       # efficient_tts.py:163-164: Linear(C, C) in front of the attention
+            mh_f, mh_p, me_saved = self._stack_fwd(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), split)
+            q_f, q_p = ws.f32("Tq_f", rs2, C), ws.plane("Tq_p", rs2, C, 2)
+            wq = pk["qfc"]
+            O.gemm(a=mh_p, b_ptr=wq.ptr, ldb=wq.ld, m=rs2.rows, n=C, bias=m.mel_query_fc.bias, rowmask_ptr=gap2.data_ptr(),
+                   out_f32_ptr=q_f.ptr, ldo=C, out_plane=q_p)
         if self.mark is not None:
             self.mark("fwd_mel_encoder_done")
 
@@ -346,7 +361,10 @@ class TrainEngine:
 
         main.wait_event(ev_dur)                                     # predicted durations from the side stream
         out3 = torch.empty(3, dtype=torch.float32, device=dev)
-        O.masked_losses(mel.ptr, odim, speech, ml, dur, lde, tl, out3, ws.tensor("loss_ws", (1024,)), B, T1, rs1.Tp, T2, rs2.Tp, odim)
+        # use_masking=False (fastspeech_loss.py:63-67): means over the padded tensors = the masked sums taken with full lengths
+        ml_loss = ml if m.use_masking else torch.full_like(ml, T2)
+        tl_loss = tl if m.use_masking else torch.full_like(tl, T1)
+        O.masked_losses(mel.ptr, odim, speech, ml_loss, dur, lde, tl_loss, out3, ws.tensor("loss_ws", (1024,)), B, T1, rs1.Tp, T2, rs2.Tp, odim)
 
         # ============================ backward
         if self.mark is not None:
@@ -355,7 +373,7 @@ class TrainEngine:
         dmel_f = ws.f32("Bdmel_f", rs2, odim)
         dmel_p = ws.plane("Bdmel_p", rs2, odim, split)
         ddur = ws.tensor("Bddur", (rs1.rows,))
-        L.check(_lib().efts_loss_bwd(mel.ptr, odim, speech.data_ptr(), ml.data_ptr(), dur.data_ptr(), lde.data_ptr(), tl.data_ptr(),
+        L.check(_lib().efts_loss_bwd(mel.ptr, odim, speech.data_ptr(), ml_loss.data_ptr(), dur.data_ptr(), lde.data_ptr(), tl_loss.data_ptr(),
                                      _ptr(gscale), dmel_f.ptr, None, 0, split, ddur.data_ptr(), B, T1, rs1.Tp, T2, rs2.Tp, odim,
                                      O._stream()), "efts_loss_bwd")
         ev_loss = torch.cuda.Event()
@@ -391,8 +409,14 @@ class TrainEngine:
             ev_durb.record(side)
             self._ws_tag = ""
         # mel head (Linear 512->80, masked): bias grad + operand plane, wgrad, dgrad
-        self._act_bwd(dmel_f.ptr, None, None, None, 0, None, dmel_p, g["mel_output_layer.bias"], rs2.rows, odim)
-        self._wgrad(ws, dmel_f.ptr, odim, d_f.ptr, C, C, 1, rs2.rows, None, None, g["mel_output_layer.weight"], None)
+        if m.use_masking:
+            dmel_m = dmel_f                                          # already zero beyond each item's length
+            self._act_bwd(dmel_f.ptr, None, None, None, 0, None, dmel_p, g["mel_output_layer.bias"], rs2.rows, odim)
+        else:
+            # the unmasked loss sees (0 - speech) on padded frames; mel_pred = masked_fill(head output) blocks that gradient (:199-200)
+            dmel_m = ws.f32("Bdmel_m", rs2, odim)
+            self._act_bwd(dmel_f.ptr, None, None, len2.data_ptr(), 0, dmel_m, dmel_p, g["mel_output_layer.bias"], rs2.rows, odim)
+        self._wgrad(ws, dmel_m.ptr, odim, d_f.ptr, C, C, 1, rs2.rows, None, None, g["mel_output_layer.weight"], None)
         G = ws.f32("Bdec_Gh", rs2, C)
         wt = self.wt["head"]
         O.gemm(a=dmel_p, b_ptr=wt.ptr, ldb=wt.ld, m=rs2.rows, n=C, rowmask_ptr=gap2.data_ptr(), out_f32_ptr=G.ptr, ldo=C)
@@ -445,7 +469,9 @@ class TrainEngine:
         O.pack_vt(q_f, qt, B, T2, rs2.Tp, C)
         GK = ws.f32("BGK", rs1, C)
         GK_p = ws.plane("BGK_p", rs1, C, split)
+        shared = m.share_text_encoder_key_value                     # value = key projection: its gradient joins dK here (residual)
         O.gemm(a=dSt, b_ptr=qt.ptr, ldb=qt.ld, m=T1, n=C, batch=B, a_batch_stride=T1 * dSt.ld, b_batch_stride=C * qt.ld, alpha=scale,
+               resid_ptr=GV.ptr if shared else None, ldr=C, resid_batch_stride=rs1.Tp * C,
                rowmask_ptr=len1.data_ptr(), rowmask_batch_stride=rs1.Tp, out_f32_ptr=GK.ptr, ldo=C, out_batch_stride=rs1.Tp * C,
                out_plane=GK_p, outb_batch_stride=rs1.Tp * GK_p.ld)
 
@@ -457,11 +483,12 @@ class TrainEngine:
 
         def kv_param_grads():                                        # bias + weight gradients of the value / key Linears
             sc = ws.f32("Bscratch1" + self._ws_tag, rs1, C)
-            L.check(_lib().efts_act_bwd(GV.ptr, None, None, None, 0.0, 0, sc.ptr, None, 0, 1,
-                                        g["text_encoder_value.bias"].data_ptr(), rs1.rows, C, O._stream()), "efts_act_bwd")
+            if not shared:
+                L.check(_lib().efts_act_bwd(GV.ptr, None, None, None, 0.0, 0, sc.ptr, None, 0, 1,
+                                            g["text_encoder_value.bias"].data_ptr(), rs1.rows, C, O._stream()), "efts_act_bwd")
+                self._wgrad(ws, GV.ptr, C, te_f.ptr, C, C, 1, rs1.rows, None, None, g["text_encoder_value.weight"], None)
             L.check(_lib().efts_act_bwd(GK.ptr, None, None, None, 0.0, 0, sc.ptr, None, 0, 1,
                                         g["text_encoder_key.bias"].data_ptr(), rs1.rows, C, O._stream()), "efts_act_bwd")
-            self._wgrad(ws, GV.ptr, C, te_f.ptr, C, C, 1, rs1.rows, None, None, g["text_encoder_value.weight"], None)
             self._wgrad(ws, GK.ptr, C, te_f.ptr, C, C, 1, rs1.rows, None, None, g["text_encoder_key.weight"], None)
 
         with O.on_stream(side):
@@ -469,17 +496,29 @@ class TrainEngine:
             # ---- value / key Linears -> text encoder -> embedding
             kv_param_grads()
             Gt0, Gt = ws.f32("Bte_G0", rs1, C), ws.f32("Bte_G1x", rs1, C)
-            wtv, wtk = self.wt["value"], self.wt["key"]
-            O.gemm(a=GV_p, b_ptr=wtv.ptr, ldb=wtv.ld, m=rs1.rows, n=C, rowmask_ptr=gap1.data_ptr(), out_f32_ptr=Gt0.ptr, ldo=C)
-            O.gemm(a=GK_p, b_ptr=wtk.ptr, ldb=wtk.ld, m=rs1.rows, n=C, resid_ptr=Gt0.ptr, ldr=C, rowmask_ptr=gap1.data_ptr(),
-                   out_f32_ptr=Gt.ptr, ldo=C)
+            wtk = self.wt["key"]
+            if shared:                                               # GK already holds dK + dV
+                O.gemm(a=GK_p, b_ptr=wtk.ptr, ldb=wtk.ld, m=rs1.rows, n=C, rowmask_ptr=gap1.data_ptr(), out_f32_ptr=Gt.ptr, ldo=C)
+            else:
+                wtv = self.wt["value"]
+                O.gemm(a=GV_p, b_ptr=wtv.ptr, ldb=wtv.ld, m=rs1.rows, n=C, rowmask_ptr=gap1.data_ptr(), out_f32_ptr=Gt0.ptr, ldo=C)
+                O.gemm(a=GK_p, b_ptr=wtk.ptr, ldb=wtk.ld, m=rs1.rows, n=C, resid_ptr=Gt0.ptr, ldr=C, rowmask_ptr=gap1.data_ptr(),
+                       out_f32_ptr=Gt.ptr, ldo=C)
             Ge = self._stack_bwd(ws, "te", "text_encoder", rs1, Gt, te_saved, gap1.data_ptr(), gap1.data_ptr(), None)
             L.check(_lib().efts_embed_bwd(text.data_ptr(), Ge.ptr, g["text_embedding_table.weight"].data_ptr(), B, T1, rs1.Tp, C,
                                           m.num_symbols, O._stream()), "efts_embed_bwd")
             self._ws_tag = ""
 
         # ---- mel encoder + prenet
-        Gm = self._stack_bwd(ws, "me", "mel_encoder", rs2, GQ, me_saved, gap2.data_ptr(), gap2.data_ptr(), None)
+        G_me = GQ
+        if m.mel_query_fc is not None:                               # backward of q = Linear(mel_h) (efficient_tts.py:163-164)
+            GQ_p = ws.plane("BGQ_p", rs2, C, split)
+            self._act_bwd(GQ.ptr, None, None, gap2.data_ptr(), 0, None, GQ_p, g["mel_query_fc.bias"], rs2.rows, C)
+            self._wgrad(ws, GQ.ptr, C, mh_f.ptr, C, C, 1, rs2.rows, None, None, g["mel_query_fc.weight"], None)
+            G_me = ws.f32("BG_mh", rs2, C)
+            wtq = self.wt["qfc"]
+            O.gemm(a=GQ_p, b_ptr=wtq.ptr, ldb=wtq.ld, m=rs2.rows, n=C, rowmask_ptr=gap2.data_ptr(), out_f32_ptr=G_me.ptr, ldo=C)
+        Gm = self._stack_bwd(ws, "me", "mel_encoder", rs2, G_me, me_saved, gap2.data_ptr(), gap2.data_ptr(), None)
         if self.mark is not None:
             self.mark("bwd_mel_encoder_done")
         dzp_f = ws.f32("Bpre_dz", rs2, C)

@@ -43,6 +43,10 @@ DEFAULT_HP = dict(
     sigma=0.01,
     sigma_e=0.5,
     ln_eps=1e-12,
+    # ctor options outside the shipped YAML (efficient_tts.py:45-48): the YAML / these defaults select the first value
+    use_masking=True,                      # False: FastSpeechLoss means over the padded tensors (fastspeech_loss.py:54-61 skipped)
+    share_text_encoder_key_value=False,    # True: value = key projection, no text_encoder_value (:72-75, :150-153)
+    use_mel_query_fc=False,                # True: Linear(C, C) on the mel encoder output in front of the attention (:90-95, :163-164)
 )
 
 
@@ -75,9 +79,12 @@ def param_shapes(hp: dict = DEFAULT_HP) -> Dict[str, Tuple[int, ...]]:
     # module registration order of efficient_tts.py:57-112 (= state_dict order)
     block("text_encoder", hp["n_text_encoder_layer"])
     linear("text_encoder_key", C, C)
-    linear("text_encoder_value", C, C)
+    if not hp.get("share_text_encoder_key_value", False):
+        linear("text_encoder_value", C, C)
     linear("mel_prenet.0", C, O)
     block("mel_encoder", hp["n_mel_encoder_layer"])
+    if hp.get("use_mel_query_fc", False):
+        linear("mel_query_fc", C, C)
     block("decoder", hp["n_decoder_layer"])
     linear("mel_output_layer", O, C)
     for i in range(hp["n_duration_layer"]):
@@ -236,7 +243,10 @@ def text_side(P: Params, text: torch.Tensor, hp: dict):
     h = res_conv_block(emb.transpose(1, 2), P, "text_encoder", hp["n_text_encoder_layer"],
                        hp["leaky_slope"]).transpose(1, 2)
     key = F.linear(h, P["text_encoder_key.weight"], P["text_encoder_key.bias"])
-    val = F.linear(h, P["text_encoder_value.weight"], P["text_encoder_value.bias"])
+    if hp.get("share_text_encoder_key_value", False):                             # :150-151 / :252-253
+        val = key
+    else:
+        val = F.linear(h, P["text_encoder_value.weight"], P["text_encoder_value.bias"])
     return h, key, val
 
 
@@ -263,6 +273,8 @@ def forward(P: Params, text: torch.Tensor, text_lengths: torch.Tensor, speech: t
                        hp["leaky_slope"])                                       # :161
     mel_h = res_conv_block(pre.transpose(1, 2), P, "mel_encoder", hp["n_mel_encoder_layer"],
                            hp["leaky_slope"]).transpose(1, 2)                   # :162
+    if hp.get("use_mel_query_fc", False):                                        # :163-164
+        mel_h = F.linear(mel_h, P["mel_query_fc.weight"], P["mel_query_fc.bias"])
 
     alpha = scaled_dot_attention(mel_h, key, text_mask).masked_fill(~both, 0.0)  # :167-168
     p = index_vector(text_mask)                                                  # :171
@@ -282,10 +294,15 @@ def forward(P: Params, text: torch.Tensor, text_lengths: torch.Tensor, speech: t
     dur_pred = duration_predictor(val, P, hp["n_duration_layer"], hp["ln_eps"], ~text_mask,
                                   False, hp["duration_offset"])                 # :219
 
-    # FastSpeechLoss, use_masking=True (nntts/losses/fastspeech_loss.py:54-67)
-    n_mel = mel_mask.sum() * speech.shape[2]
-    mel_loss = (((mel_pred - speech) ** 2) * mel_mask[:, :, None]).sum() / n_mel
-    dur_loss = ((dur_pred - log_delta_e).abs() * text_mask).sum() / text_mask.sum()
+    if hp.get("use_masking", True):
+        # FastSpeechLoss, use_masking=True (nntts/losses/fastspeech_loss.py:54-67)
+        n_mel = mel_mask.sum() * speech.shape[2]
+        mel_loss = (((mel_pred - speech) ** 2) * mel_mask[:, :, None]).sum() / n_mel
+        dur_loss = ((dur_pred - log_delta_e).abs() * text_mask).sum() / text_mask.sum()
+    else:
+        # use_masking=False (the ctor default, efficient_tts.py:43): plain means over the padded tensors (:63-67)
+        mel_loss = ((mel_pred - speech) ** 2).mean()
+        dur_loss = (dur_pred - log_delta_e).abs().mean()
     return dict(loss=mel_loss + dur_loss, mel_loss=mel_loss, dur_loss=dur_loss, imv=imv, e=e,
                 reconst_alpha=ralpha, mel_pred=mel_pred, dur_pred=dur_pred,
                 log_delta_e=log_delta_e, alpha=alpha, text_value=val, text_key=key, mel_h=mel_h,

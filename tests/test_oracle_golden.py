@@ -107,3 +107,33 @@ def test_train3_matches_reference(golden_dir, params):
         ref = g["param:" + k]
         flat = p.detach().reshape(-1).numpy()[:: int(g["param_stride:" + k])]
         assert np.abs(flat - ref).max() <= 2e-6 + 1e-4 * np.abs(ref).max(), k
+
+
+VARIANTS = dict(nomask=dict(use_masking=False), sharekv=dict(share_text_encoder_key_value=True), queryfc=dict(use_mel_query_fc=True))
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_ctor_option_variants_match_reference(golden_dir, name):
+    """the oracle's restatement of the ctor options outside the shipped YAML (efficient_tts.py:43-48) against fixtures the
+    reference produced with each of them (tools/gen_golden_variants.py): outputs, losses, parameter gradients, key set"""
+    g = _load(golden_dir, "variant_" + name)
+    hp = dict(O.DEFAULT_HP, **VARIANTS[name])
+    P = {k: v.clone().requires_grad_(True) for k, v in O.fill_params(hp).items()}
+    assert {k for k in g.files if k.startswith("grad:")} == {"grad:" + k for k in P}
+    out = O.forward(P, torch.from_numpy(g["text"]), torch.from_numpy(g["text_lengths"]), torch.from_numpy(g["speech"]),
+                    torch.from_numpy(g["speech_lengths"]), hp)
+    for k, tol in TOL.items():
+        ref = torch.from_numpy(np.asarray(g[k]))
+        scale = max(1.0, float(ref.abs().max())) if k in ("loss", "mel_loss", "dur_loss") else 1.0
+        assert float((out[k].detach() - ref).abs().max()) <= tol * scale, (name, k)
+    out["loss"].backward()
+    for k, p in P.items():
+        ref = g["grad:" + k]
+        flat = p.grad.reshape(-1).numpy()
+        if "grad_stride:" + k in g.files:
+            flat = flat[:: int(g["grad_stride:" + k])]
+        assert np.abs(flat - ref).max() <= 2e-4 * max(float(np.abs(ref).max()), 1e-3), (name, k)
+    if name == "sharekv":
+        o = O.inference(O.fill_params(hp), torch.from_numpy(g["inf_text"]), hp)
+        assert o["mel_pred"].shape[1] == int(g["inf_t2"])
+        assert float((o["mel_pred"] - torch.from_numpy(g["inf_mel_pred"])).abs().max()) <= 5e-4

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Golden fixtures for the ctor options outside the shipped YAML (efficient_tts.py:43-48), produced by the REFERENCE itself
+(build container only):
+
+    PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden_variants.py
+
+use_masking=False (the ctor default), share_text_encoder_key_value=True, use_mel_query_fc=True, each on the ragged
+(2, 16, 64) case of gen_golden.py with parameter gradients (strided samples + norms); share_text_encoder_key_value also on one
+free-running utterance.  Writes tests/golden/variant_<name>.npz; only data is stored."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gen_golden as G  # noqa: E402  (also puts the reference and the oracle on the path)
+from gen_golden import EfficientTTSCNN, O  # noqa: E402
+
+VARIANTS = dict(
+    nomask=dict(use_masking=False),
+    sharekv=dict(share_text_encoder_key_value=True),
+    queryfc=dict(use_mel_query_fc=True),
+)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    for name, opt in VARIANTS.items():
+        hp = dict(O.DEFAULT_HP, **opt)
+        kw = dict(num_symbols=76, dropout_rate=0.0, use_masking=True, use_weighted_masking=False, sigma=0.01)
+        kw.update(opt)
+        m = EfficientTTSCNN(**kw)
+        P = O.fill_params(hp)
+        sd = m.state_dict()
+        assert list(sd.keys()) == list(P.keys()), (name, "state_dict key order/names differ")
+        m.load_state_dict(P)
+        m.eval()
+        text, tl, mel, sl = G.make_inputs(11, 2, 16, 64, [16, 11], [64, 50], True)
+        if name == "nomask":
+            mel = mel + 0.0                                   # zero padding as the collate leaves it
+        m.zero_grad()
+        ref = G.ref_forward(m, text, tl, mel, sl)
+        o = O.forward(P, text, tl, mel, sl, hp)
+        for k in ("loss", "mel_loss", "dur_loss", "imv", "e", "reconst_alpha", "mel_pred", "dur_pred", "log_delta_e"):
+            print(f"  [{name}] oracle vs reference {k:14s} max-abs {G.maxabs(o[k], ref[k]):.3e}")
+        d = dict(text=G.npy(text), text_lengths=G.npy(tl), speech=G.npy(mel), speech_lengths=G.npy(sl))
+        for k in ("loss", "mel_loss", "dur_loss", "imv", "e", "dur_pred", "log_delta_e", "mel_pred", "reconst_alpha"):
+            d[k] = G.npy(ref[k])
+        ref["loss"].backward()
+        Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        O.forward(Pg, text, tl, mel, sl, hp)["loss"].backward()
+        worst = 0.0
+        for k, p in m.named_parameters():
+            g = p.grad
+            worst = max(worst, G.maxabs(g, Pg[k].grad) / (float(g.abs().max()) + 1e-12))
+            flat = G.npy(g).reshape(-1)
+            if flat.size > 1024:
+                step = flat.size // 512
+                d["grad_stride:" + k] = np.int64(step)
+                flat = flat[::step]
+            d["grad:" + k] = flat
+            d["gradnorm:" + k] = np.float64(g.double().norm())
+        print(f"  [{name}] oracle vs reference param-grad worst rel-to-max {worst:.3e}")
+        if name == "sharekv":                                  # free-running path: value = key (:252-253)
+            ids = torch.randint(1, 76, (1, 23), generator=torch.Generator().manual_seed(5))
+            m.remove_weight_norm()
+            with torch.no_grad():
+                mel_pred, ralpha = m.inference(ids)
+                oi = O.inference(P, ids, hp)
+            print(f"  [{name}] inference T2={mel_pred.shape[1]} oracle-vs-ref mel {G.maxabs(oi['mel_pred'], mel_pred):.3e}")
+            d["inf_text"] = G.npy(ids); d["inf_mel_pred"] = G.npy(mel_pred); d["inf_t2"] = np.int64(mel_pred.shape[1])
+        np.savez_compressed(os.path.join(G.OUT, f"variant_{name}.npz"), **d)
+        print(f"wrote variant_{name}.npz loss={float(ref['loss']):.6f}")
+
+
+if __name__ == "__main__":
+    main()
