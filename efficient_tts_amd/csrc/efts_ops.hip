@@ -225,13 +225,18 @@ __global__ __launch_bounds__(256) void aligned_pos_kernel(const float* __restric
     if (lane == 0) e[(long)b * T1 + i] = out;
 }
 
-__global__ void dur_target_kernel(const float* __restrict__ e, const int* __restrict__ tlen, float offset,
-                                  float* __restrict__ lde, int B, int T1) {
+__global__ void dur_target_kernel(const float* __restrict__ e, const int* __restrict__ tlen, const int* __restrict__ mlen, float offset,
+                                  int method1, float* __restrict__ lde, int B, int T1) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * T1) return;
     const int b = idx / T1, i = idx - b * T1;
     float v = 0.f;
-    if (i < tlen[b]) v = logf(e[idx] - (i > 0 ? e[idx - 1] : 0.f) + offset);
+    if (i < tlen[b]) {
+        // method 1 (efficient_tts.py:204): e_i - e_{i-1}, e_{-1} = 0.  Otherwise (:205-213): e_{i+1} - e_i, e_{len} = mel length
+        const float d = method1 ? e[idx] - (i > 0 ? e[idx - 1] : 0.f)
+                                : (i + 1 < tlen[b] ? e[idx + 1] : (float)mlen[b]) - e[idx];
+        v = logf(d + offset);
+    }
     lde[idx] = v;
 }
 
@@ -539,8 +544,15 @@ extern "C" int efts_aligned_positions(const float* imv, const int32_t* text_len,
     if (!imv || !text_len || !mel_len || !e) return efts_fail(EFTS_EINVAL, "efts_aligned_positions: null pointer");
     hipLaunchKernelGGL(aligned_pos_kernel, dim3((T1 + 3) / 4, B), dim3(256), 0, ST, imv, text_len, mel_len, sigma_e, e, T1, T2);
     if (log_delta_e)
-        hipLaunchKernelGGL(dur_target_kernel, dim3((B * T1 + 255) / 256), dim3(256), 0, ST, (const float*)e, text_len, offset, log_delta_e, B, T1);
+        hipLaunchKernelGGL(dur_target_kernel, dim3((B * T1 + 255) / 256), dim3(256), 0, ST, (const float*)e, text_len, mel_len, offset, 1, log_delta_e, B, T1);
     return efts_check_launch("efts_aligned_positions");
+}
+
+extern "C" int efts_duration_target(const float* e, const int32_t* text_len, const int32_t* mel_len, float offset, int32_t method1,
+                                    float* log_delta_e, int32_t B, int32_t T1, void* stream) {
+    if (!e || !text_len || !mel_len || !log_delta_e) return efts_fail(EFTS_EINVAL, "efts_duration_target: null pointer");
+    hipLaunchKernelGGL(dur_target_kernel, dim3((B * T1 + 255) / 256), dim3(256), 0, ST, e, text_len, mel_len, offset, method1 ? 1 : 0, log_delta_e, B, T1);
+    return efts_check_launch("efts_duration_target");
 }
 
 extern "C" int efts_reconst_alpha(const float* e, const int32_t* text_len, const int32_t* mel_len, float sigma, float* alpha_out,

@@ -68,6 +68,7 @@ _SIGS = {
     "efts_attn_soft_index": (i32, [vp, i64, vp, vp, vp, vp, i32, i32, i32, vp]),
     "efts_imv_scan": (i32, [vp, vp, vp, vp, i32, i32, vp]),
     "efts_aligned_positions": (i32, [vp, vp, vp, f32, f32, vp, vp, i32, i32, i32, vp]),
+    "efts_duration_target": (i32, [vp, vp, vp, f32, i32, vp, i32, i32, vp]),
     "efts_reconst_alpha": (i32, [vp, vp, vp, f32, vp, vp, i64, i32, i32, i32, i32, vp]),
     "efts_pack_vt": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "efts_cumsum_rows": (i32, [vp, vp, i32, i32, vp]),

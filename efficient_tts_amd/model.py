@@ -166,8 +166,6 @@ class EfficientTTSCNN(torch.nn.Module):
             raise ValueError("symbol_embedding_dim must equal n_channels (the reference adds them residually)")
         if k_size != 5:
             raise NotImplementedError("k_size must be 5 (row-space gap = 2)")
-        if not delta_e_method_1:
-            raise NotImplementedError("delta_e_method_1=False (efficient_tts.py:205-213) is not implemented (no shipped config selects it)")
         if use_weighted_masking:
             raise NotImplementedError("FastSpeechLoss(use_weighted_masking=True) is not implemented (no shipped config selects it)")
         if n_channels % 256 or odim > 128:
@@ -536,7 +534,10 @@ class EfficientTTSCNN(torch.nn.Module):
             O.attn_soft_index(scores, T1, tl, ml, sidx, alpha, B, T1, T2)         # :391-398, :168, :312
         O.imv_scan(sidx, tl, ml, imv, B, T2)                                      # :314-323
         e, lde = ws.tensor("e", (B, T1)), ws.tensor("lde", (B, T1))
-        O.aligned_positions(imv, tl, ml, float(self.sigma_e), float(self.duration_offset), e, lde, B, T1, T2)  # :178-180, :203-216
+        O.aligned_positions(imv, tl, ml, float(self.sigma_e), float(self.duration_offset), e, lde if self.delta_e_method_1 else None,
+                            B, T1, T2)                                            # :178-180, :203-216
+        if not self.delta_e_method_1:
+            O.duration_target(e, tl, ml, float(self.duration_offset), False, lde, B, T1)   # :205-213
         ralpha = torch.empty(B, T1, T2, dtype=torch.float32, device=dev)
         ra_p = ws.plane("ra_p", rs2, T1, 2)
         O.reconst_alpha(e, tl, ml, float(self.sigma), ralpha, ra_p, B, T1, T2, rs2.Tp)   # :184-186
@@ -584,6 +585,8 @@ class EfficientTTSCNN(torch.nn.Module):
         e = ws.tensor("e", (1, T1))
         O.cumsum_rows(delta[:T1], e, 1, T1)                                       # :260
         t2 = int(torch.round(e[0, -1]).item())                                    # :361 (host sync, as the reference)
+        if not self.delta_e_method_1:                                             # :261-265 + trim_e (:362-363): positions start at 0
+            e = e - delta[:T1].view(1, T1)
         if t2 <= 0:
             raise ValueError("predicted total duration rounds to 0 frames")
         rs2 = Rows(1, t2)
@@ -629,6 +632,8 @@ class EfficientTTSCNN(torch.nn.Module):
         O.cumsum_rows(d2, e, B, T1)
         last = e.gather(1, (tl.long() - 1).clamp(min=0)[:, None]).squeeze(1)
         ml = torch.round(last).to(torch.int32)
+        if not self.delta_e_method_1:                                             # efficient_tts.py:261-265 + trim_e: positions start at 0
+            e = e - d2
         return e, ml
 
     def _infer_mel(self, e, tl, ml, T2: int):

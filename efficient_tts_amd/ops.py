@@ -271,6 +271,11 @@ def aligned_positions(imv, tl, ml, sigma_e, offset, e, lde, B, T1, T2) -> None:
                                             e.data_ptr(), _p(lde), B, T1, T2, _stream()), "efts_aligned_positions")
 
 
+def duration_target(e, tl, ml, offset, method1: bool, lde, B, T1) -> None:
+    L.check(L.load().efts_duration_target(e.data_ptr(), tl.data_ptr(), ml.data_ptr(), offset, int(method1), lde.data_ptr(), B, T1, _stream()),
+            "efts_duration_target")
+
+
 def reconst_alpha(e, tl, ml, sigma, alpha_out, plane: Optional[Plane], B, T1, T2, T2p) -> None:
     L.check(L.load().efts_reconst_alpha(e.data_ptr(), _p(tl), _p(ml), sigma, _p(alpha_out),
                                         None if plane is None else plane.ptr, 0 if plane is None else plane.ld,

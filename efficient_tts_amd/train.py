@@ -338,7 +338,9 @@ class TrainEngine:
         O.attn_soft_index(scores, T1, tl, ml, sidx, None, B, T1, T2)
         O.imv_scan(sidx, tl, ml, imv, B, T2)
         e, lde = ws.tensor("Te", (B, T1)), ws.tensor("Tlde", (B, T1))
-        O.aligned_positions(imv, tl, ml, float(m.sigma_e), float(m.duration_offset), e, lde, B, T1, T2)
+        O.aligned_positions(imv, tl, ml, float(m.sigma_e), float(m.duration_offset), e, lde if m.delta_e_method_1 else None, B, T1, T2)
+        if not m.delta_e_method_1:                                   # efficient_tts.py:205-213 (the target is detached either way)
+            O.duration_target(e, tl, ml, float(m.duration_offset), False, lde, B, T1)
         ralpha = ws.tensor("Tralpha", (B, T1, T2))
         ra_p = ws.plane("Tra_p", rs2, T1, 2)
         O.reconst_alpha(e, tl, ml, float(m.sigma), ralpha, ra_p, B, T1, T2, rs2.Tp)

@@ -241,6 +241,10 @@ int efts_imv_scan(const float* soft_idx, const int32_t* text_len, const int32_t*
 int efts_aligned_positions(const float* imv, const int32_t* text_len, const int32_t* mel_len, float sigma_e,
                            float offset, float* e, float* log_delta_e, int32_t B, int32_t T1, int32_t T2,
                            void* stream);
+/* the duration target alone: log(delta_e + offset) with delta_e_i = e_i - e_{i-1} (method1 != 0, efficient_tts.py:204) or
+ * e_{i+1} - e_i with e_{len} = mel_len (method1 == 0, :205-213); 0 at padded text.  e, log_delta_e: [B][T1]. */
+int efts_duration_target(const float* e, const int32_t* text_len, const int32_t* mel_len, float offset, int32_t method1,
+                         float* log_delta_e, int32_t B, int32_t T1, void* stream);
 int efts_reconst_alpha(const float* e, const int32_t* text_len, const int32_t* mel_len, float sigma,
                        float* alpha_out, void* plane, int64_t ld_plane, int32_t B, int32_t T1, int32_t T2,
                        int32_t T2p, void* stream);

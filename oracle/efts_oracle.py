@@ -47,6 +47,7 @@ DEFAULT_HP = dict(
     use_masking=True,                      # False: FastSpeechLoss means over the padded tensors (fastspeech_loss.py:54-61 skipped)
     share_text_encoder_key_value=False,    # True: value = key projection, no text_encoder_value (:72-75, :150-153)
     use_mel_query_fc=False,                # True: Linear(C, C) on the mel encoder output in front of the attention (:90-95, :163-164)
+    delta_e_method_1=True,                 # False: duration target e_{i+1} - e_i with e_{len} = mel length (:205-213); inference from 0 (:261-265)
 )
 
 
@@ -289,7 +290,13 @@ def forward(P: Params, text: torch.Tensor, text_lengths: torch.Tensor, speech: t
                 t.retain_grad()
     mel_pred = decode(P, expanded, hp) * mel_mask[:, :, None]                   # :197-200
 
-    delta_e = torch.cat([e[:, :1], e[:, 1:] - e[:, :-1]], dim=1).detach()       # :204 (method 1)
+    if hp.get("delta_e_method_1", True):
+        delta_e = torch.cat([e[:, :1], e[:, 1:] - e[:, :-1]], dim=1).detach()   # :204 (method 1)
+    else:                                                                       # :205-213
+        ee = torch.cat([e.detach(), torch.zeros(e.shape[0], 1)], dim=1)
+        for i in range(e.shape[0]):
+            ee[i, int(text_lengths[i])] = float(speech_lengths[i])
+        delta_e = ee[:, 1:] - ee[:, :-1]
     log_delta_e = torch.log(delta_e + hp["duration_offset"]).masked_fill(~text_mask, 0.0)  # :215-216
     dur_pred = duration_predictor(val, P, hp["n_duration_layer"], hp["ln_eps"], ~text_mask,
                                   False, hp["duration_offset"])                 # :219
@@ -320,6 +327,8 @@ def inference(P: Params, text: torch.Tensor, hp: dict = DEFAULT_HP,
         delta = forced_delta
     e = torch.cumsum(delta, dim=1)                                              # :260
     t2 = int(torch.round(e[:, -1]).reshape(-1)[0].item())                        # :361
+    if not hp.get("delta_e_method_1", True):                                     # :261-265 + trim_e (:362-363): positions start at 0
+        e = e - delta
     ralpha = reconstruct_alignment(e, hp["sigma"], None, None, t2)              # :270-274
     mel_pred = decode(P, torch.bmm(val.transpose(1, 2), ralpha), hp)            # :278-284
     return dict(mel_pred=mel_pred, reconst_alpha=ralpha, delta=delta, e=e, t2=t2)

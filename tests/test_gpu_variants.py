@@ -1,5 +1,6 @@
 """GPU (-m gpu): the ctor options outside the shipped YAML -- use_masking=False (the reference's ctor default,
-efficient_tts.py:43), share_text_encoder_key_value=True (:72-75, :150-153, :252-253), use_mel_query_fc=True (:90-95, :163-164) --
+efficient_tts.py:43), share_text_encoder_key_value=True (:72-75, :150-153, :252-253), use_mel_query_fc=True (:90-95, :163-164),
+delta_e_method_1=False (:205-213, :261-265) --
 against fixtures the REFERENCE produced for each of them (tools/gen_golden_variants.py): forward outputs, losses, parameter
 gradients of the fused training pass, state_dict layout, and the free-running path where the option touches it."""
 import os
@@ -11,7 +12,8 @@ import torch
 from oracle import efts_oracle as O
 
 pytestmark = pytest.mark.gpu
-VARIANTS = dict(nomask=dict(use_masking=False), sharekv=dict(share_text_encoder_key_value=True), queryfc=dict(use_mel_query_fc=True))
+VARIANTS = dict(nomask=dict(use_masking=False), sharekv=dict(share_text_encoder_key_value=True), queryfc=dict(use_mel_query_fc=True),
+                delta2=dict(delta_e_method_1=False))
 MEL_TOL = 1e-3
 
 
@@ -80,9 +82,10 @@ def test_variant_param_grads_match_reference_golden(golden_dir, name):
         assert abs(gn - float(g["gradnorm:" + n])) <= 5e-3 * float(g["gradnorm:" + n]) + 1e-5, n
 
 
-def test_shared_key_value_inference_matches_reference_golden(golden_dir):
-    g = np.load(os.path.join(golden_dir, "variant_sharekv.npz"))
-    m = _model(VARIANTS["sharekv"])
+@pytest.mark.parametrize("name", ["sharekv", "delta2"])
+def test_variant_inference_matches_reference_golden(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, f"variant_{name}.npz"))
+    m = _model(VARIANTS[name])
     ids = torch.from_numpy(g["inf_text"]).to(_dev())
     mel, ralpha = m.inference(ids)
     assert mel.shape[1] == int(g["inf_t2"])

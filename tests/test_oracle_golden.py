@@ -109,7 +109,8 @@ def test_train3_matches_reference(golden_dir, params):
         assert np.abs(flat - ref).max() <= 2e-6 + 1e-4 * np.abs(ref).max(), k
 
 
-VARIANTS = dict(nomask=dict(use_masking=False), sharekv=dict(share_text_encoder_key_value=True), queryfc=dict(use_mel_query_fc=True))
+VARIANTS = dict(nomask=dict(use_masking=False), sharekv=dict(share_text_encoder_key_value=True), queryfc=dict(use_mel_query_fc=True),
+                delta2=dict(delta_e_method_1=False))
 
 
 @pytest.mark.parametrize("name", list(VARIANTS))
@@ -133,7 +134,7 @@ def test_ctor_option_variants_match_reference(golden_dir, name):
         if "grad_stride:" + k in g.files:
             flat = flat[:: int(g["grad_stride:" + k])]
         assert np.abs(flat - ref).max() <= 2e-4 * max(float(np.abs(ref).max()), 1e-3), (name, k)
-    if name == "sharekv":
+    if name in ("sharekv", "delta2"):
         o = O.inference(O.fill_params(hp), torch.from_numpy(g["inf_text"]), hp)
         assert o["mel_pred"].shape[1] == int(g["inf_t2"])
         assert float((o["mel_pred"] - torch.from_numpy(g["inf_mel_pred"])).abs().max()) <= 5e-4

@@ -4,9 +4,9 @@
 
     PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden_variants.py
 
-use_masking=False (the ctor default), share_text_encoder_key_value=True, use_mel_query_fc=True, each on the ragged
-(2, 16, 64) case of gen_golden.py with parameter gradients (strided samples + norms); share_text_encoder_key_value also on one
-free-running utterance.  Writes tests/golden/variant_<name>.npz; only data is stored."""
+use_masking=False (the ctor default), share_text_encoder_key_value=True, use_mel_query_fc=True, delta_e_method_1=False, each on
+the ragged (2, 16, 64) case of gen_golden.py with parameter gradients (strided samples + norms); share_text_encoder_key_value and
+delta_e_method_1=False also on one free-running utterance.  Writes tests/golden/variant_<name>.npz; only data is stored."""
 import os
 import sys
 
@@ -22,6 +22,7 @@ VARIANTS = dict(
     nomask=dict(use_masking=False),
     sharekv=dict(share_text_encoder_key_value=True),
     queryfc=dict(use_mel_query_fc=True),
+    delta2=dict(delta_e_method_1=False),
 )
 
 
@@ -64,7 +65,7 @@ def main():
             d["grad:" + k] = flat
             d["gradnorm:" + k] = np.float64(g.double().norm())
         print(f"  [{name}] oracle vs reference param-grad worst rel-to-max {worst:.3e}")
-        if name == "sharekv":                                  # free-running path: value = key (:252-253)
+        if name in ("sharekv", "delta2"):                      # free-running path: value = key (:252-253) / positions from 0 (:261-265)
             ids = torch.randint(1, 76, (1, 23), generator=torch.Generator().manual_seed(5))
             m.remove_weight_norm()
             with torch.no_grad():
