@@ -233,6 +233,11 @@ __global__ __launch_bounds__(256, 2) void conv5_kernel(GemmKernelArgs p) {
                         store_b128(w, rsg, trow * ld_sg + (unsigned)(n0 >> 7) * 16, row_of(ep, ps) * ld_sg);
                     }
                 }
+                if (p.drop_thresh) {                         // Dropout on the activated value (see gemm_kernel)
+                    const unsigned e0 = (unsigned)(m0 + row_of(ep, ps) + (int)trow) * (unsigned)p.n + col;
+                    v.x *= drop_scale(p.drop_seed_h, e0, p.drop_thresh, p.drop_inv_keep); v.y *= drop_scale(p.drop_seed_h, e0 + 1, p.drop_thresh, p.drop_inv_keep);
+                    v.z *= drop_scale(p.drop_seed_h, e0 + 2, p.drop_thresh, p.drop_inv_keep); v.w *= drop_scale(p.drop_seed_h, e0 + 3, p.drop_thresh, p.drop_inv_keep);
+                }
                 const u32x4 x = rres[ps % NRING];
                 const float rm = has_mask ? rmv[ps % NRING] : 1.f;
                 if (ps + NRING < NPS) request(ep, ps + NRING);

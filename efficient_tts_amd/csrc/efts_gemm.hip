@@ -340,6 +340,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
                     store_b128(w, rsg, trow * ld_sg + (unsigned)(n0 >> 7) * 16, ps * RPP * ld_sg);
                 }
             }
+            if (p.drop_thresh) {                             // Dropout on the activated value, in front of the residual add
+                const unsigned e0 = (unsigned)(m0 + rl) * (unsigned)p.n + col;
+                v.x *= drop_scale(p.drop_seed_h, e0, p.drop_thresh, p.drop_inv_keep); v.y *= drop_scale(p.drop_seed_h, e0 + 1, p.drop_thresh, p.drop_inv_keep);
+                v.z *= drop_scale(p.drop_seed_h, e0 + 2, p.drop_thresh, p.drop_inv_keep); v.w *= drop_scale(p.drop_seed_h, e0 + 3, p.drop_thresh, p.drop_inv_keep);
+            }
             const u32x4 x = rres[ps];
             const float rm = has_mask ? rmv[ps] : 1.f;
             v.x = (v.x + __uint_as_float(x.x)) * rm; v.y = (v.y + __uint_as_float(x.y)) * rm;
@@ -481,6 +486,13 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     k.bias = a->bias; k.resid = a->resid; k.rowmask = a->rowmask;
     k.out_f32 = a->out_f32; k.out_bf16 = (char*)a->out_bf16; k.out_lo = (char*)a->out_bf16_lo; k.sign = (char*)a->sign_mask;
     k.sidx = a->soft_index; k.klen = a->key_len; k.qlen = a->query_len;
+    k.drop_thresh = 0; k.drop_seed_h = 0; k.drop_inv_keep = 1.f;
+    if (a->drop_p > 0.f) {
+        if (!(a->drop_p < 1.f)) return efts_fail(EFTS_EINVAL, "efts_gemm: drop_p must be in [0, 1)");
+        k.drop_thresh = (unsigned)((double)a->drop_p * 4294967296.0);
+        k.drop_seed_h = hash_u32(a->drop_seed);
+        k.drop_inv_keep = 1.f / (1.f - a->drop_p);
+    }
     if (a->out_bf16_lo && (!a->out_bf16 || a->out_split != 1 || a->plane_act || ((uintptr_t)a->out_bf16_lo & 7)))
         return efts_fail(EFTS_EINVAL, "efts_gemm: out_bf16_lo goes with an un-activated split-1 out_bf16 plane (8-byte aligned)");
     k.lda = a->lda; k.ldb = a->ldb; k.b_tap_stride = a->b_tap_stride; k.ldr = a->ldr; k.ldo = a->ldo; k.ldob = a->ldob;
@@ -501,6 +513,8 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     k.prof = nullptr; k.dbg = 0;
     if (a->soft_index && (!a->key_len || !a->query_len || a->n > BN || nb2 > 1 || a->resid || a->out_bf16 || a->taps != 1 || a->act != EFTS_ACT_NONE))
         return efts_fail(EFTS_EINVAL, "efts_gemm: soft_index needs key_len / query_len, n <= 128, one tap, no activation, residual, plane output or batch2");
+    if (k.drop_thresh && (a->batch > 1 || nb2 > 1 || !k.vec_ok || a->n % 4 || (long)a->m * a->n > 0xffffffffL))
+        return efts_fail(EFTS_EINVAL, "efts_gemm: dropout needs batch 1, 16-byte aligned fp32 / plane rows, n % 4 == 0 and m * n < 2^32");
     if (a->sign_mask && (a->n % 128 || a->batch > 1 || nb2 > 1 || !k.vec_ok || ((uintptr_t)a->sign_mask & 15)))
         return efts_fail(EFTS_EINVAL, "efts_gemm: sign_mask needs n %% 128 == 0, batch 1, 16-byte aligned output rows and mask");
     hipStream_t st = (hipStream_t)stream;
@@ -510,7 +524,7 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     const int tiling = a->tiling;
     if (tiling < EFTS_TILING_AUTO || tiling > EFTS_TILING_RESIDENT) return efts_fail(EFTS_EINVAL, "efts_gemm: unknown tiling %d", tiling);
     const bool generic_only = a->out_bf16_lo != nullptr || nb2 > 1 || a->soft_index != nullptr;      // the remainder plane / the outer batch / the soft index: gemm_kernel only
-    const bool no_narrow = generic_only || a->sign_mask != nullptr;      // the sign words: gemm_kernel and conv5_kernel write them
+    const bool no_narrow = generic_only || a->sign_mask != nullptr || k.drop_thresh != 0;      // sign words / dropout: gemm_kernel and conv5_kernel only
     if (generic_only && tiling > EFTS_TILING_GENERIC) return efts_fail(EFTS_EINVAL, "efts_gemm: out_bf16_lo / batch2 need the generic tiling");
     const dim3 grid(k.mtiles * k.ntiles, a->batch, nb2);                  // one workgroup per 124 x 128 tile, 2 resident per CU
 

@@ -30,6 +30,8 @@ struct GemmKernelArgs {
     float* sidx;                // soft index of the softmax over each output row (efts_abi.h `soft_index`), [batch][m], or null
     const int* klen;            // valid columns per batch item
     const int* qlen;            // valid rows per batch item
+    unsigned drop_thresh, drop_seed_h;   // train-mode dropout of the activated value (efts_abi.h drop_p): keep iff hash >= thresh; 0 = off
+    float drop_inv_keep;
     long lda, ldb, b_tap_stride, ldr, ldo, ldob;
     long a_bs, b_bs, r_bs, m_bs, o_bs, ob_bs;
     long a_bs2, b_bs2, o_bs2;   // outer batch (blockIdx.z)

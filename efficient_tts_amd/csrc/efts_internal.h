@@ -54,7 +54,7 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // counter-based dropout mask: keep (and scale by 1/(1-p)) iff hash(seed, element index) >= p * 2^32.
 // Stateless, so forward and backward regenerate the same mask from (seed, index).
-__device__ __forceinline__ unsigned hash_u32(unsigned x) {
+__host__ __device__ __forceinline__ unsigned hash_u32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }

@@ -76,7 +76,8 @@ __global__ void loss_bwd_kernel(const float* __restrict__ mp, long ldm, const fl
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
                                                       const float* __restrict__ x, const float* __restrict__ rowmask,
                                                       float slope, int mode, float* __restrict__ dz, char* __restrict__ plane,
-                                                      long ldp, int split, float* __restrict__ dbias, int bias_parts, int rows, int c) {
+                                                      long ldp, int split, float* __restrict__ dbias, int bias_parts, int rows, int c,
+                                                      unsigned drop_thresh, unsigned drop_seed_h, float drop_inv_keep) {
     // block: 64 rows x 128 columns (blockIdx.y = column group); 256 threads = 32 column quads x 8
     // rows in flight.  Column sums are combined in LDS first: ONE global atomic per column per
     // block (same-address atomics serialise at L2 and were the bottleneck of the first version).
@@ -108,6 +109,11 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
                 const float neg = mode == 2 ? 0.f : slope;
                 m.x = yv.x > 0.f ? 1.f : neg; m.y = yv.y > 0.f ? 1.f : neg;
                 m.z = yv.z > 0.f ? 1.f : neg; m.w = yv.w > 0.f ? 1.f : neg;
+            }
+            if (drop_thresh) {                               // the forward launch's Dropout mask, regenerated from (seed, element index)
+                const unsigned e0 = (unsigned)o;
+                m.x *= drop_scale(drop_seed_h, e0, drop_thresh, drop_inv_keep); m.y *= drop_scale(drop_seed_h, e0 + 1, drop_thresh, drop_inv_keep);
+                m.z *= drop_scale(drop_seed_h, e0 + 2, drop_thresh, drop_inv_keep); m.w *= drop_scale(drop_seed_h, e0 + 3, drop_thresh, drop_inv_keep);
             }
             gv.x *= m.x * rm; gv.y *= m.y * rm; gv.z *= m.z * rm; gv.w *= m.w * rm;
             if (dz) *(float4*)(dz + o) = gv;
@@ -774,17 +780,31 @@ extern "C" int efts_loss_bwd(const float* mel_pred, int64_t ldm, const float* sp
     return efts_check_launch("efts_loss_bwd");
 }
 
-extern "C" int efts_act_bwd(const float* g, const float* y, const float* x, const float* rowmask, float slope, int32_t mode, float* dz,
-                            void* plane, int64_t ld_plane, int32_t split, float* dbias, int32_t rows, int32_t c, void* stream) {
+extern "C" int efts_act_bwd_dropout(const float* g, const float* y, const float* x, const float* rowmask, float slope, int32_t mode, float* dz,
+                                    void* plane, int64_t ld_plane, int32_t split, float* dbias, int32_t rows, int32_t c, float drop_p,
+                                    uint32_t drop_seed, void* stream) {
     if (!g || (!dz && !plane)) return efts_fail(EFTS_EINVAL, "efts_act_bwd: null pointer");
     const int parts = mode & EFTS_ACT_BWD_BIAS_PARTS ? 1 : 0;
     mode &= ~EFTS_ACT_BWD_BIAS_PARTS;
     if (c % 4 || (mode == 1 && (!x || !y)) || ((mode == 2 || mode == 3) && !y) || (mode == 4 && (!y || c % 128 || ((uintptr_t)y & 15))) || mode < 0 || mode > 4 ||
         (parts && !dbias))
         return efts_fail(EFTS_EINVAL, "efts_act_bwd: bad mode/shape");
+    unsigned thresh = 0, seed_h = 0;
+    float inv_keep = 1.f;
+    if (drop_p > 0.f) {
+        if (!(drop_p < 1.f) || (long)rows * c > 0xffffffffL) return efts_fail(EFTS_EINVAL, "efts_act_bwd_dropout: drop_p must be in [0, 1) and rows * c < 2^32");
+        thresh = (unsigned)((double)drop_p * 4294967296.0);
+        seed_h = hash_u32(drop_seed);
+        inv_keep = 1.f / (1.f - drop_p);
+    }
     hipLaunchKernelGGL(act_bwd_kernel, dim3((rows + 63) / 64, (c + 127) / 128), dim3(256), 0, ST, g, y, x, rowmask, slope, mode, dz, (char*)plane, (long)ld_plane,
-                       split, dbias, parts, rows, c);
+                       split, dbias, parts, rows, c, thresh, seed_h, inv_keep);
     return efts_check_launch("efts_act_bwd");
+}
+
+extern "C" int efts_act_bwd(const float* g, const float* y, const float* x, const float* rowmask, float slope, int32_t mode, float* dz,
+                            void* plane, int64_t ld_plane, int32_t split, float* dbias, int32_t rows, int32_t c, void* stream) {
+    return efts_act_bwd_dropout(g, y, x, rowmask, slope, mode, dz, plane, ld_plane, split, dbias, rows, c, 0.f, 0u, stream);
 }
 
 extern "C" int efts_pack_t(const float* x, int64_t ldx, void* plane, int64_t ld_plane, int64_t plane_stride, int32_t split, int32_t rows,

@@ -38,7 +38,7 @@ class GemmArgs(C.Structure):
         ("out_split", i32), ("batch2", i32),
         ("a_batch2_stride", i64), ("b_batch2_stride", i64), ("out_batch2_stride", i64),
         ("dilation", i32), ("plane_act", i32), ("plane_slope", f32),
-        ("out_bf16_lo", vp), ("tiling", i32), ("sign_mask", vp), ("soft_index", vp), ("key_len", vp), ("query_len", vp),
+        ("out_bf16_lo", vp), ("tiling", i32), ("sign_mask", vp), ("soft_index", vp), ("key_len", vp), ("query_len", vp), ("drop_p", f32), ("drop_seed", C.c_uint32),
     ]
 
 
@@ -81,6 +81,7 @@ _SIGS = {
     "efts_pack_weights_grouped": (i32, [vp, i32, vp, i64, i64, i32, i32, i32, i32, i32, vp]),
     "efts_loss_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "efts_act_bwd": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, i64, i32, vp, i32, i32, vp]),
+    "efts_act_bwd_dropout": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, i64, i32, vp, i32, i32, f32, C.c_uint32, vp]),
     "efts_pack_t": (i32, [vp, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, vp]),
     "efts_wgrad_reduce": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
     "efts_wgrad_reduce_bias": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp, vp]),

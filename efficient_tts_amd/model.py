@@ -443,12 +443,11 @@ class EfficientTTSCNN(torch.nn.Module):
         """Teacher-forced forward.  Returns (loss, stats, imv[B,T2], reconst_alpha[B,T1,T2],
         mel_pred[B,T2,odim], speech) exactly like the reference (:228)."""
         training_path = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if training_path and self.training and self.dropout_rate >= 1e-5:
-            # ResConv1d's Dropout (nntts/layers/efts_modules.py:38-47) and the prenet's (efficient_tts.py:76-80) are not part of
-            # the HIP training path (the shipped recipe trains with dropout_rate 0.0): refuse instead of training another model
-            raise NotImplementedError(f"dropout_rate={self.dropout_rate} in train() mode: the HIP training step implements the conv / "
-                                      "prenet Dropout only for dropout_rate 0.0 (egs/lj/conf/efficient_tts_cnn_phnseq_noDropout.v1.yaml); "
-                                      "construct the model with dropout_rate=0.0 or call eval()")
+        if not training_path and self.training and self.dropout_rate >= 1e-5:
+            # the reference would apply ResConv1d's / the prenet's Dropout here (efts_modules.py:38-47, efficient_tts.py:76-80); the
+            # masks live in the fused training pass only: refuse instead of returning a dropout-free result in train() mode
+            raise NotImplementedError(f"dropout_rate={self.dropout_rate} in train() mode without gradients: the conv / prenet Dropout is "
+                                      "applied by the fused training pass only; call eval() for a dropout-free forward")
         self._require(text)
         if training_path:
             from .autograd import training_forward

@@ -124,7 +124,8 @@ def gemm(*, a: Plane, a_ptr: Optional[int] = None, b_ptr: int, ldb: int, b_tap_s
          nchunk: Optional[int] = None, batch2: int = 0, a_batch2_stride: int = 0, b_batch2_stride: int = 0,
          out_batch2_stride: int = 0, dilation: int = 1, plane_act: bool = False, plane_slope: float = 0.0,
          out_plane_lo: Optional[Plane] = None, tiling: Optional[int] = None, sign_mask_ptr: Optional[int] = None,
-         soft_index: Optional[torch.Tensor] = None, key_len: Optional[torch.Tensor] = None, query_len: Optional[torch.Tensor] = None) -> None:
+         soft_index: Optional[torch.Tensor] = None, key_len: Optional[torch.Tensor] = None, query_len: Optional[torch.Tensor] = None,
+         drop_p: float = 0.0, drop_seed: int = 0) -> None:
     g = L.GemmArgs()
     g.a, g.lda, g.a_batch_stride = (a_ptr if a_ptr is not None else a.ptr), a.ld, a_batch_stride
     g.b, g.ldb, g.b_tap_stride, g.b_batch_stride = b_ptr, ldb, b_tap_stride, b_batch_stride
@@ -144,6 +145,7 @@ def gemm(*, a: Plane, a_ptr: Optional[int] = None, b_ptr: int, ldb: int, b_tap_s
     g.out_bf16_lo = None if out_plane_lo is None else out_plane_lo.ptr
     g.tiling = GEMM_TILING if tiling is None else tiling
     g.sign_mask = sign_mask_ptr
+    g.drop_p, g.drop_seed = drop_p, drop_seed & 0xFFFFFFFF
     if soft_index is not None:                  # expected key index of the row softmax, computed in the epilogue (int32 lengths per batch item)
         g.soft_index, g.key_len, g.query_len = soft_index.data_ptr(), key_len.data_ptr(), query_len.data_ptr()
     if PROFILE is not None and (PROFILE_TAG is None or PROFILE_TAG == (taps, m, n)):

@@ -141,10 +141,20 @@ class TrainEngine:
         return pk
 
     # ------------------------------------------------------------------ small wrappers
-    def _act_bwd(self, g_ptr, y_ptr, x_ptr, mask_ptr, mode, dz: Optional[F32Rows], plane: Optional[Plane], dbias, rows, c):
-        L.check(_lib().efts_act_bwd(g_ptr, y_ptr, x_ptr, mask_ptr, self.m.slope, mode, None if dz is None else dz.ptr,
-                                    None if plane is None else plane.ptr, 0 if plane is None else plane.ld,
-                                    1 if plane is None else plane.split, _ptr(dbias), rows, c, O._stream()), "efts_act_bwd")
+    def _act_bwd(self, g_ptr, y_ptr, x_ptr, mask_ptr, mode, dz: Optional[F32Rows], plane: Optional[Plane], dbias, rows, c,
+                 drop_p: float = 0.0, drop_seed: int = 0):
+        L.check(_lib().efts_act_bwd_dropout(g_ptr, y_ptr, x_ptr, mask_ptr, self.m.slope, mode, None if dz is None else dz.ptr,
+                                            None if plane is None else plane.ptr, 0 if plane is None else plane.ld,
+                                            1 if plane is None else plane.split, _ptr(dbias), rows, c, drop_p, drop_seed & 0xFFFFFFFF,
+                                            O._stream()), "efts_act_bwd")
+
+    def _conv_drop(self, k: int):
+        """(p, seed) of the train-mode Dropout behind the activation of conv / prenet launch k (efts_modules.py:38-47,
+        efficient_tts.py:76-80): one mask per launch and step, regenerated by the backward from the same seed"""
+        m = self.m
+        if not m.training or m.dropout_rate < 1e-5:
+            return 0.0, 0
+        return float(m.dropout_rate), (m.dropout_seed * 2654435761 + self.drop_calls * 1000003 + k * 7919 + 12345) & 0xFFFFFFFF
 
     def _wgrad(self, ws, dz_ptr, cout, x_ptr, ldx, cin, taps, rows, v, g, out_dw, out_dg):
         """dW[co][ci][k] = sum_t dZ[t][co] X[t+k-pad][ci] as `taps` split-K GEMMs on transposed planes"""
@@ -190,11 +200,13 @@ class TrainEngine:
             w = pk[f"{blk}.{i}"]
             o_f = ws.f32(f"T{tag}_f{i}", rs, C)
             o_p = ws.plane(f"T{tag}_p{i}", rs, C, last_split if last else m.split)
-            sg = ws.tensor(f"T{tag}_sg{i}", (rs.rows, C // 8), torch.uint8) if (0 < _SIGN_MIN_ROWS <= rs.rows and C % 128 == 0) else None
+            dp, dseed = self._conv_drop(dict(te=10, me=20, dec=30)[tag] + i)
+            # under Dropout y - x no longer carries the activation's sign where the element was dropped: always the sign words then
+            sg = ws.tensor(f"T{tag}_sg{i}", (rs.rows, C // 8), torch.uint8) if ((0 < _SIGN_MIN_ROWS <= rs.rows or dp > 0) and C % 128 == 0) else None
             O.gemm(a=x_p, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=5, m=rs.rows, n=C, act=L.ACT_LEAKY, slope=m.slope,
                    bias=layer.conv[0].bias, resid_ptr=x_f.ptr, ldr=C, rowmask_ptr=gap_ptr, out_f32_ptr=o_f.ptr, ldo=C, out_plane=o_p,
-                   sign_mask_ptr=None if sg is None else sg.data_ptr())
-            saved.append((x_f, o_f, x_p, sg))
+                   sign_mask_ptr=None if sg is None else sg.data_ptr(), drop_p=dp, drop_seed=dseed)
+            saved.append((x_f, o_f, x_p, sg, dp, dseed))
             x_f, x_p = o_f, o_p
         return x_f, x_p, saved
 
@@ -203,7 +215,7 @@ class TrainEngine:
         m, C = self.m, self.m.n_channels
         layers = getattr(m, blk).layers
         for i in reversed(range(len(layers))):
-            x_f, y_f, x_pl, sg = saved[i]
+            x_f, y_f, x_pl, sg, dp, dseed = saved[i]
             conv = layers[i].conv[0]
             pre = f"{blk}.layers.{i}.conv.0."
             dz_p = ws.plane(f"B{tag}_dzp", rs, C, m.split)
@@ -216,9 +228,9 @@ class TrainEngine:
             bp = ws.tensor(f"B{tag}_bp", ((rs.rows + 63) // 64, C)) if (direct and _BIAS_PARTS) else None
             db, parts = (bp, L.ACT_BWD_BIAS_PARTS) if bp is not None else (self.g[pre + "bias"], 0)
             if sg is not None:
-                self._act_bwd(G.ptr, sg.data_ptr(), None, gap_ptr, 4 | parts, dz_f, dz_p, db, rs.rows, C)
+                self._act_bwd(G.ptr, sg.data_ptr(), None, gap_ptr, 4 | parts, dz_f, dz_p, db, rs.rows, C, dp, dseed)
             else:
-                self._act_bwd(G.ptr, y_f.ptr, x_f.ptr, gap_ptr, 1 | parts, dz_f, dz_p, db, rs.rows, C)
+                self._act_bwd(G.ptr, y_f.ptr, x_f.ptr, gap_ptr, 1 | parts, dz_f, dz_p, db, rs.rows, C, dp, dseed)
             wn = hasattr(conv, "weight_g")
             v_, g_ = (conv.weight_v.detach(), conv.weight_g.detach()) if wn else (None, None)
             dw_, dg_ = (self.g[pre + "weight_v"], self.g[pre + "weight_g"]) if wn else (self.g[pre + "weight"], None)
@@ -316,8 +328,9 @@ class TrainEngine:
         O.pack_rows(speech, mel_in_f, mel_in, rs2)
         pre_f, pre_p = ws.f32("Tpre_f", rs2, C), ws.plane("Tpre_p", rs2, C, split)
         wp = pk["prenet"]
+        pre_dp, pre_seed = self._conv_drop(40)                       # mel_prenet's Dropout (efficient_tts.py:76-80)
         O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, act=L.ACT_LEAKY, slope=m.slope, bias=m.mel_prenet[0].bias,
-               rowmask_ptr=gap2.data_ptr(), out_f32_ptr=pre_f.ptr, ldo=C, out_plane=pre_p)
+               rowmask_ptr=gap2.data_ptr(), out_f32_ptr=pre_f.ptr, ldo=C, out_plane=pre_p, drop_p=pre_dp, drop_seed=pre_seed)
         if m.mel_query_fc is None:
             q_f, q_p, me_saved = self._stack_fwd(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2)
         else:                                                       # efficient_tts.py:163-164: Linear(C, C) in front of the attention
@@ -524,7 +537,7 @@ class TrainEngine:
         if self.mark is not None:
             self.mark("bwd_mel_encoder_done")
         dzp_f = ws.f32("Bpre_dz", rs2, C)
-        self._act_bwd(Gm.ptr, pre_f.ptr, None, gap2.data_ptr(), 3, dzp_f, None, g["mel_prenet.0.bias"], rs2.rows, C)
+        self._act_bwd(Gm.ptr, pre_f.ptr, None, gap2.data_ptr(), 3, dzp_f, None, g["mel_prenet.0.bias"], rs2.rows, C, pre_dp, pre_seed)
         self._wgrad(ws, dzp_f.ptr, C, mel_in_f.ptr, odim, odim, 1, rs2.rows, None, None, g["mel_prenet.0.weight"], None)
         if self.bucket_hook:
             self.bucket_hook(1)

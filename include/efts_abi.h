@@ -131,6 +131,12 @@ typedef struct efts_gemm_args {
     float* soft_index;
     const int32_t* key_len;
     const int32_t* query_len;
+    /* train-mode Dropout on the activated value, BEFORE the residual add (ResConv1d / mel_prenet with dropout_rate > 0,
+     * nntts/layers/efts_modules.py:38-47, efficient_tts.py:76-80): element (row, col) is kept and scaled by 1 / (1 - drop_p) iff
+     * hash(drop_seed, row * n + col) >= drop_p * 2^32 -- a stateless counter-based mask efts_act_bwd_dropout regenerates (not
+     * torch's Philox stream: same distribution, different draws).  batch 1, generic / wide tiling, vector epilogue.  0: none. */
+    float drop_p;
+    uint32_t drop_seed;
 } efts_gemm_args;
 
 #define EFTS_TILING_AUTO 0
@@ -320,6 +326,10 @@ int efts_loss_bwd(const float* mel_pred, int64_t ldm, const float* speech, const
  * mode | EFTS_ACT_BWD_BIAS_PARTS: dbias is a [ceil(rows / 64)][c] workspace that receives one column sum per 64-row block
  * (plain stores, overwritten) instead of atomic adds into the gradient; efts_wgrad_reduce_bias adds them up. */
 #define EFTS_ACT_BWD_BIAS_PARTS 16
+/* efts_act_bwd with the Dropout mask of the forward launch (efts_gemm_args.drop_p / drop_seed, c = that launch's n) applied too */
+int efts_act_bwd_dropout(const float* g, const float* y, const float* x, const float* rowmask, float slope, int32_t mode,
+                         float* dz, void* plane, int64_t ld_plane, int32_t split, float* dbias, int32_t rows, int32_t c,
+                         float drop_p, uint32_t drop_seed, void* stream);
 int efts_act_bwd(const float* g, const float* y, const float* x, const float* rowmask, float slope, int32_t mode,
                  float* dz, void* plane, int64_t ld_plane, int32_t split, float* dbias, int32_t rows, int32_t c,
                  void* stream);

@@ -81,16 +81,21 @@ def test_model_fails_loudly_without_gpu():
         m.inference(torch.zeros(1, 8, dtype=torch.long))
 
 
-def test_conv_dropout_in_train_mode_is_refused_not_ignored():
+def test_dropout_free_forward_in_train_mode_is_refused_not_ignored():
     """The reference applies Dropout inside ResConv1d and the prenet for dropout_rate > 0 (ctor default 0.1,
-    nntts/layers/efts_modules.py:38-47, efficient_tts.py:76-80); the HIP training step does not, so it must raise instead of
-    silently training a different model (eval() and dropout_rate=0.0 are fine)."""
+    nntts/layers/efts_modules.py:38-47, efficient_tts.py:76-80).  The fused training pass does (tests/test_gpu_train.py); a
+    forward in train() mode WITHOUT gradients would silently be dropout-free, so it raises (eval() and dropout_rate=0.0 are fine)."""
     import torch
     from efficient_tts_amd import EfficientTTSCNN
     m = EfficientTTSCNN(num_symbols=76, use_masking=True)                # dropout_rate = 0.1, train() mode
     t = torch.zeros(1, 8, dtype=torch.long)
-    with pytest.raises(NotImplementedError, match="dropout_rate"):
+    with torch.no_grad(), pytest.raises(NotImplementedError, match="dropout_rate"):
         m(t, torch.tensor([8]), torch.zeros(1, 16, 80), torch.tensor([16]))
+    m.eval()
+    if not torch.cuda.is_available():
+        with torch.no_grad(), pytest.raises(Exception) as ei:             # past the guard: fails on the missing device instead
+            m(t, torch.tensor([8]), torch.zeros(1, 16, 80), torch.tensor([16]))
+        assert "dropout_rate" not in str(ei.value)
 
 
 def test_lazy_stats_behaves_like_a_dict():
