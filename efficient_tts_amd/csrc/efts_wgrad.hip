@@ -1,7 +1,8 @@
-// efts_wgrad.hip -- weight gradient of the k5 residual convolutions straight from the ROW-MAJOR
-// operand planes the forward / dgrad contractions already use (no transposed copies):
+// efts_wgrad.hip -- weight gradient of the k5 residual convolutions (and, since round 2, of the k3 convolutions and the
+// Linears with 128 | cout, 64 | cin: TAPS = 3, 1) straight from the ROW-MAJOR operand planes the forward / dgrad
+// contractions already use (no transposed copies):
 //
-//   part[k][s][co][ci] = sum_{t in split s} dZ[t][co] * X[t + k - 2][ci]         (k = 0..4)
+//   part[k][s][co][ci] = sum_{t in split s} dZ[t][co] * X[t + k - pad][ci]       (k = 0..taps-1, pad = (taps - 1) / 2)
 //
 // Replaces, for the (512, 512, 5) layers, efts_pack_t (one transposed plane of dZ + FIVE shifted
 // transposed planes of X per layer, 183 MB of HBM traffic) + the split-K efts_gemm.
@@ -68,7 +69,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
 }
 
 // grid: x = (cout/128) * (cin/64) tiles, y = nsplit; split s covers steps [s*steps_per_split, ...) of ROWS rows each.
-template <int SPLIT>
+template <int SPLIT, int TAPS>
 __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const char* __restrict__ dz, long ldz, const char* __restrict__ x, long ldx,
                                                            float* __restrict__ part, int steps_per_split, int steps_total, int cout, int cin, int nsplit) {
     using C = WgCfg<SPLIT>;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const char* __restrict
         ldb[q] = (unsigned)(C::A_BYTES + pcc * 1024);
     }
     const char* a_src = dz + (long)t_begin * ldz + (long)(mt * C::CA) * 128;
-    const char* b_src = x + (long)(t_begin - 2) * ldx + (long)(nt * C::CB) * 128;
+    const char* b_src = x + (long)(t_begin - (TAPS - 1) / 2) * ldx + (long)(nt * C::CB) * 128;
     auto issue = [&](int st) {                      // operands of step st -> ring slot st % 3
         const unsigned base = lds0 + (st % WG_NST) * C::STAGE;
         const char* sa = a_src + (long)st * C::ROWS * ldz;
@@ -122,9 +123,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const char* __restrict
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     };
 
-    f32x16 acc[5][2];
+    f32x16 acc[TAPS][2];
 #pragma unroll
-    for (int k = 0; k < 5; ++k)
+    for (int k = 0; k < TAPS; ++k)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -155,8 +156,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const char* __restrict
 #pragma unroll
                 for (int i = 0; i < 2; ++i) af[i] = tr_frag(at + tn_off(ra, (ch_lane + i * 32) * 2), at + tn_off(ra + 4, (ch_lane + i * 32) * 2));
 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const int rb = ra + k;                                     // window row of t at tap k: (t - t0) + 2 + (k - 2)
+                for (int k = 0; k < TAPS; ++k) {
+                    const int rb = ra + k;                                     // window row of t at tap k: (t - t0) + pad + (k - pad)
                     const bf16x8 bfr = tr_frag(bt + tn_off(rb, (wn * 32 + ch_lane) * 2), bt + tn_off(rb + 4, (wn * 32 + ch_lane) * 2));
 #pragma unroll
                     for (int i = 0; i < 2; ++i) acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr, acc[k][i], 0, 0, 0);
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const char* __restrict
                     al[i] = tr_frag(at + tn_off(ra, 64 + ch_lane * 2), at + tn_off(ra + 4, 64 + ch_lane * 2));
                 }
 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
+                for (int k = 0; k < TAPS; ++k) {
                     const int rb = ra + k;
                     const bf16x8 bh = tr_frag(bt + tn_off(rb, ch_lane * 2), bt + tn_off(rb + 4, ch_lane * 2));
                     const bf16x8 bl = tr_frag(bt + tn_off(rb, 64 + ch_lane * 2), bt + tn_off(rb + 4, 64 + ch_lane * 2));
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const char* __restrict
     // ---- partials: C/D layout col n = lane & 31 (ci), row m = (r&3) + 8*(r>>2) + 4*(lane>>5) (co)
     const int ci = nt * 64 + wn * 32 + (lane & 31);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < TAPS; ++k) {
         float* o = part + ((long)(k * nsplit + sp) * cout) * cin;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -211,27 +212,26 @@ using namespace efts;
 extern "C" int efts_wgrad_tn(const void* dz_plane, int64_t ldz, const void* x_plane, int64_t ldx, float* part, int32_t rows,
                              int32_t cout, int32_t cin, int32_t taps, int32_t nsplit, int32_t split, void* stream) {
     if (!dz_plane || !x_plane || !part) return efts_fail(EFTS_EINVAL, "efts_wgrad_tn: null pointer");
-    if (taps != 5 || !(split == 1 || split == 2)) return efts_fail(EFTS_EINVAL, "efts_wgrad_tn: implemented for taps 5, split 1 or 2");
+    if (!(taps == 1 || taps == 3 || taps == 5) || !(split == 1 || split == 2))
+        return efts_fail(EFTS_EINVAL, "efts_wgrad_tn: implemented for taps 1, 3, 5 and split 1 or 2");
     if (rows <= 0 || nsplit <= 0 || cout <= 0 || cin <= 0 || (cout & 127) || (cin & 63))
         return efts_fail(EFTS_ESHAPE, "efts_wgrad_tn: cout must be a multiple of 128, cin of 64");
     if ((ldz & 15) || (ldx & 15) || ldz < (int64_t)cout * 2 * split || ldx < (int64_t)cin * 2 * split || ldz > (1 << 20) || ldx > (1 << 20) ||
         ((uintptr_t)dz_plane & 15) || ((uintptr_t)x_plane & 15))
         return efts_fail(EFTS_EALIGN, "efts_wgrad_tn: plane strides / alignment");
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<1>::LDS);
-        (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<2>::LDS);
-        attr = true;
-    }
     const int rps = split == 1 ? WgCfg<1>::ROWS : WgCfg<2>::ROWS;
     const int steps = (rows + rps - 1) / rps;                // rows past `rows` (< 70 of them) are zero guard rows
     const int per = (steps + nsplit - 1) / nsplit;
     dim3 grid((cout / 128) * (cin / 64), nsplit);
-    if (split == 1)
-        hipLaunchKernelGGL(wgrad_tn_kernel<1>, grid, dim3(256), WgCfg<1>::LDS, (hipStream_t)stream, (const char*)dz_plane, (long)ldz,
-                           (const char*)x_plane, (long)ldx, part, per, steps, cout, cin, nsplit);
-    else
-        hipLaunchKernelGGL(wgrad_tn_kernel<2>, grid, dim3(256), WgCfg<2>::LDS, (hipStream_t)stream, (const char*)dz_plane, (long)ldz,
-                           (const char*)x_plane, (long)ldx, part, per, steps, cout, cin, nsplit);
+#define EFTS_WGTN(S, T)                                                                                                                  \
+    do {                                                                                                                                 \
+        static bool attr = false;                                                                                                        \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<S, T>, hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<S>::LDS); attr = true; } \
+        hipLaunchKernelGGL((wgrad_tn_kernel<S, T>), grid, dim3(256), WgCfg<S>::LDS, (hipStream_t)stream, (const char*)dz_plane, (long)ldz,  \
+                           (const char*)x_plane, (long)ldx, part, per, steps, cout, cin, nsplit);                                        \
+    } while (0)
+    if (split == 1) { if (taps == 5) EFTS_WGTN(1, 5); else if (taps == 3) EFTS_WGTN(1, 3); else EFTS_WGTN(1, 1); }
+    else { if (taps == 5) EFTS_WGTN(2, 5); else if (taps == 3) EFTS_WGTN(2, 3); else EFTS_WGTN(2, 1); }
+#undef EFTS_WGTN
     return efts_check_launch("efts_wgrad_tn");
 }

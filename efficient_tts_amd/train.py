@@ -29,6 +29,8 @@ _WGRAD_TN_SPLITS = int(os.environ.get("EFTS_WGRAD_TN_SPLITS", "8"))     # K-spli
 _SIGN_MIN_ROWS = 16384       # row spaces from here on: the forward convolutions of the stacks write the activation's sign words
                              # (efts_gemm `sign_mask`) and efts_act_bwd reads those instead of y and x in fp32 (14 -> 6 B per element);
                              # shorter ones (the text side) keep the narrow tiling, which does not write them.  0 = never
+_WGRAD_TN_SMALL = 1          # key / value / query Linears and the duration predictor's k3 convolutions: weight gradient straight from
+                             # the row-major planes too (taps 1 / 3) instead of two transposed copies + a split-K efts_gemm (0: the latter)
 _BIAS_PARTS = 1              # direct-wgrad layers: bias gradient as per-row-block sums finished by the wgrad reduction (0: atomics in act_bwd)
 _WGRAD_WGS = int(os.environ.get("EFTS_WGRAD_WGS", "480"))   # split-K target: 480 workgroups per wgrad launch measured best (6.30 vs 6.60 ms/step at 640)
 
@@ -156,6 +158,14 @@ class TrainEngine:
             return 0.0, 0
         return float(m.dropout_rate), (m.dropout_seed * 2654435761 + self.drop_calls * 1000003 + k * 7919 + 12345) & 0xFFFFFFFF
 
+    def _wgrad_any(self, ws, dz_f_ptr, dz_p: Optional[Plane], x_f_ptr, x_p: Optional[Plane], cout, cin, taps, rows, out_dw):
+        """un-normed weights: the direct kernel when both operand planes exist in one format and the shape fits its tiles"""
+        if (_WGRAD_TN_SMALL and _WGRAD_TN_SPLITS > 0 and dz_p is not None and x_p is not None and dz_p.split == x_p.split
+                and cout % 128 == 0 and cin % 64 == 0 and taps in (1, 3, 5)):
+            self._wgrad_tn(ws, dz_p, x_p, cout, cin, rows, None, None, out_dw, None, taps=taps)
+        else:
+            self._wgrad(ws, dz_f_ptr, cout, x_f_ptr, cin, cin, taps, rows, None, None, out_dw, None)
+
     def _wgrad(self, ws, dz_ptr, cout, x_ptr, ldx, cin, taps, rows, v, g, out_dw, out_dg):
         """dW[co][ci][k] = sum_t dZ[t][co] X[t+k-pad][ci] as `taps` split-K GEMMs on transposed planes"""
         split = self.m.split
@@ -179,14 +189,15 @@ class TrainEngine:
         L.check(_lib().efts_wgrad_reduce(part.data_ptr(), S, _ptr(v), _ptr(g), out_dw.data_ptr(), _ptr(out_dg), cout, cin, taps,
                                          O._stream()), "efts_wgrad_reduce")
 
-    def _wgrad_tn(self, ws, dz_p: Plane, x_p: Plane, cout, cin, rows, v, g, out_dw, out_dg, bias_part=None, dbias=None):
-        """k5 wgrad straight from the row-major bf16 planes (csrc/efts_wgrad.hip): no transposed copies.
+    def _wgrad_tn(self, ws, dz_p: Plane, x_p: Plane, cout, cin, rows, v, g, out_dw, out_dg, bias_part=None, dbias=None, taps: int = 5):
+        """wgrad of a k5 / k3 convolution or a Linear (taps 5 / 3 / 1) straight from the row-major bf16 planes
+        (csrc/efts_wgrad.hip): no transposed copies.
         bias_part: the [row blocks][cout] column sums efts_act_bwd left; the reduction adds them into dbias"""
         S = _WGRAD_TN_SPLITS
-        part = ws.get(("part", self._ws_tag, 5, S, cout, cin), lambda: torch.empty(5, S, cout, cin, device=self.dev))
-        L.check(_lib().efts_wgrad_tn(dz_p.ptr, dz_p.ld, x_p.ptr, x_p.ld, part.data_ptr(), rows, cout, cin, 5, S, dz_p.split, O._stream()),
+        part = ws.get(("part", self._ws_tag, taps, S, cout, cin), lambda: torch.empty(taps, S, cout, cin, device=self.dev))
+        L.check(_lib().efts_wgrad_tn(dz_p.ptr, dz_p.ld, x_p.ptr, x_p.ld, part.data_ptr(), rows, cout, cin, taps, S, dz_p.split, O._stream()),
                 "efts_wgrad_tn")
-        L.check(_lib().efts_wgrad_reduce_bias(part.data_ptr(), S, _ptr(v), _ptr(g), out_dw.data_ptr(), _ptr(out_dg), cout, cin, 5,
+        L.check(_lib().efts_wgrad_reduce_bias(part.data_ptr(), S, _ptr(v), _ptr(g), out_dw.data_ptr(), _ptr(out_dg), cout, cin, taps,
                                               _ptr(bias_part), 0 if bias_part is None else bias_part.shape[0], _ptr(dbias), O._stream()),
                 "efts_wgrad_reduce_bias")
 
@@ -406,7 +417,7 @@ class TrainEngine:
                                               g[gname(1, "0.bias")].data_ptr(), g["duration_predictor.linear.weight"].data_ptr(),
                                               g["duration_predictor.linear.bias"].data_ptr(), rs1.rows, C, drop_p, seed1, O._stream()),
                     "efts_layernorm_bwd")
-            self._wgrad(ws, dz2_f.ptr, C, l1_f.ptr, C, C, 3, rs1.rows, None, None, g[gname(1, "0.weight")], None)
+            self._wgrad_any(ws, dz2_f.ptr, dz2_p, l1_f.ptr, l1_p, C, C, 3, rs1.rows, g[gname(1, "0.weight")])
             G1 = ws.f32("Bdur_G1", rs1, C)
             wt = self.wt["dur.1"]
             O.gemm(a=dz2_p, b_ptr=wt.ptr, ldb=wt.ld, b_tap_stride=wt.tap_stride, taps=3, m=rs1.rows, n=C, out_f32_ptr=G1.ptr, ldo=C)
@@ -416,7 +427,7 @@ class TrainEngine:
                                               g[gname(0, "2.weight")].data_ptr(), g[gname(0, "2.bias")].data_ptr(),
                                               g[gname(0, "0.bias")].data_ptr(), None, None, rs1.rows, C, drop_p, seed0, O._stream()),
                     "efts_layernorm_bwd")
-            self._wgrad(ws, dz1_f.ptr, C, val_f.ptr, C, C, 3, rs1.rows, None, None, g[gname(0, "0.weight")], None)
+            self._wgrad_any(ws, dz1_f.ptr, dz1_p, val_f.ptr, val_p, C, C, 3, rs1.rows, g[gname(0, "0.weight")])
             dV_dur = ws.f32("BdV_dur", rs1, C)
             wt = self.wt["dur.0"]
             O.gemm(a=dz1_p, b_ptr=wt.ptr, ldb=wt.ld, b_tap_stride=wt.tap_stride, taps=3, m=rs1.rows, n=C, out_f32_ptr=dV_dur.ptr, ldo=C)
@@ -501,10 +512,10 @@ class TrainEngine:
             if not shared:
                 L.check(_lib().efts_act_bwd(GV.ptr, None, None, None, 0.0, 0, sc.ptr, None, 0, 1,
                                             g["text_encoder_value.bias"].data_ptr(), rs1.rows, C, O._stream()), "efts_act_bwd")
-                self._wgrad(ws, GV.ptr, C, te_f.ptr, C, C, 1, rs1.rows, None, None, g["text_encoder_value.weight"], None)
+                self._wgrad_any(ws, GV.ptr, GV_p, te_f.ptr, te_p, C, C, 1, rs1.rows, g["text_encoder_value.weight"])
             L.check(_lib().efts_act_bwd(GK.ptr, None, None, None, 0.0, 0, sc.ptr, None, 0, 1,
                                         g["text_encoder_key.bias"].data_ptr(), rs1.rows, C, O._stream()), "efts_act_bwd")
-            self._wgrad(ws, GK.ptr, C, te_f.ptr, C, C, 1, rs1.rows, None, None, g["text_encoder_key.weight"], None)
+            self._wgrad_any(ws, GK.ptr, GK_p, te_f.ptr, te_p, C, C, 1, rs1.rows, g["text_encoder_key.weight"])
 
         with O.on_stream(side):
             self._ws_tag = "s"
@@ -529,7 +540,7 @@ class TrainEngine:
         if m.mel_query_fc is not None:                               # backward of q = Linear(mel_h) (efficient_tts.py:163-164)
             GQ_p = ws.plane("BGQ_p", rs2, C, split)
             self._act_bwd(GQ.ptr, None, None, gap2.data_ptr(), 0, None, GQ_p, g["mel_query_fc.bias"], rs2.rows, C)
-            self._wgrad(ws, GQ.ptr, C, mh_f.ptr, C, C, 1, rs2.rows, None, None, g["mel_query_fc.weight"], None)
+            self._wgrad_any(ws, GQ.ptr, GQ_p, mh_f.ptr, mh_p, C, C, 1, rs2.rows, g["mel_query_fc.weight"])
             G_me = ws.f32("BG_mh", rs2, C)
             wtq = self.wt["qfc"]
             O.gemm(a=GQ_p, b_ptr=wtq.ptr, ldb=wtq.ld, m=rs2.rows, n=C, rowmask_ptr=gap2.data_ptr(), out_f32_ptr=G_me.ptr, ldo=C)

@@ -338,8 +338,8 @@ int efts_act_bwd(const float* g, const float* y, const float* x, const float* ro
  * from one pass over x */
 int efts_pack_t(const float* x, int64_t ldx, void* plane, int64_t ld_plane, int64_t plane_stride, int32_t split,
                 int32_t rows, int32_t c, int32_t shift0, int32_t nshift, int32_t kpad, void* stream);
-/* Direct wgrad partials of a k5 convolution from the ROW-MAJOR bf16 planes (no transposed copies):
- * part[k][s][co][ci] = sum over the rows t of K-split s of dZ[t][co] * X[t + k - 2][ci], k = 0..4
+/* Direct wgrad partials of a k5 / k3 convolution or a Linear (taps 5, 3, 1) from the ROW-MAJOR bf16 planes (no transposed copies):
+ * part[k][s][co][ci] = sum over the rows t of K-split s of dZ[t][co] * X[t + k - (taps - 1) / 2][ci], k = 0..taps-1
  * (autograd of the Conv1d in nntts/layers/efts_modules.py:48-51).  dz_plane / x_plane: operand planes of
  * the row space, both of format `split` (1 = bf16, 2 = bf16x3 hi/lo) (row 0 pointers; >= 2 zero rows before row 0 and >= 144 after `rows`),
  * cout % 128 == 0, cin % 64 == 0; part is what efts_wgrad_reduce consumes. */
