@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--dp-algo", default="allreduce", choices=["allreduce", "rs_ag"], help="train32, N > 1: per-bucket all_reduce, or reduce_scatter + all_gather (point-to-point xGMI)")
     ap.add_argument("--side-stream", type=int, default=1, help="0: text-length work on the main stream (A/B)")
     ap.add_argument("--resconv", type=int, default=1, help="0: residual stacks on efts_gemm + fp32 stream (A/B)")
+    ap.add_argument("--fuse-prenet", type=int, default=1, help="A/B: 0 = efts_pack_rows + efts_gemm instead of efts_frame_linear")
     ap.add_argument("--fuse-soft-index", type=int, default=1, help="A/B: 0 = scores stored + efts_attn_soft_index instead of the softmax epilogue of the q.k^T launch")
     ap.add_argument("--resconv-min-rows", type=int, default=-1, help="A/B: row-space size from which the stacks run on efts_resconv5")
     ap.add_argument("--graph", type=int, default=0, help="forward workloads. 0 (default): the timed step is a plain model(...) call, as a drop-in caller issues it (the model replays a per-shape hipGraph internally); 1: a bench-level hipGraph of the eager launches")
@@ -454,6 +455,7 @@ def run_forward(a, world, rank, dev, wl):
         m = m.to(dev).eval()
         m.side_stream, m.resconv = bool(a.side_stream), bool(a.resconv)
         m.fuse_soft_index = bool(a.fuse_soft_index)
+        m.fuse_prenet = bool(a.fuse_prenet)
         if a.resconv_min_rows >= 0:
             m.RESCONV_MIN_ROWS = a.resconv_min_rows
         return m

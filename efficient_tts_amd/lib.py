@@ -42,6 +42,13 @@ class GemmArgs(C.Structure):
     ]
 
 
+class FrameLinearArgs(C.Structure):
+    """mirror of efts_frame_linear_args (include/efts_abi.h)"""
+    _fields_ = [("x", vp), ("w", vp), ("ldw", i64), ("split", i32), ("bias", vp), ("act", i32), ("slope", f32),
+                ("B", i32), ("T", i32), ("Tp", i32), ("cin", i32), ("n", i32), ("y_f32", vp), ("ldo", i64), ("y", vp), ("y_lo", vp),
+                ("ldy", i64), ("y_split", i32)]
+
+
 class ResConv5Args(C.Structure):
     """mirror of `struct efts_resconv5_args` (include/efts_abi.h)"""
     _fields_ = [
@@ -92,6 +99,7 @@ _SIGS = {
     "efts_imv_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "efts_attn_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "efts_embed_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "efts_frame_linear": (i32, [C.POINTER(FrameLinearArgs), vp]),
     "efts_sumsq_workspace_bytes": (C.c_size_t, []),
     "efts_sumsq": (i32, [vp, i64, vp, vp, vp]),
     "efts_scale_unless_one": (i32, [vp, i64, vp, vp]),

@@ -194,6 +194,7 @@ class EfficientTTSCNN(torch.nn.Module):
         self.decoder = _ResConvBlock(n_decoder_layer, n_channels, k_size, a, ap, dropout_rate, use_weight_norm)
         self.mel_output_layer = torch.nn.Linear(n_channels, odim)
         self.duration_predictor = _DurationPredictor(n_channels, n_duration_layer, n_channels, offset=duration_offset)
+        self.fuse_prenet = True             # bf16 mode: the prenet straight from the fp32 frames (efts_frame_linear); False: efts_pack_rows + efts_gemm
         self.fuse_soft_index = True         # T1 <= 128: q.k^T, softmax and soft index in one launch (False: scores stored, efts_attn_soft_index)
         self.graphs = True                  # plain eval calls replay a per-shape hipGraph (False: every kernel launched eagerly)
         self._graph_cache = GraphCache()
@@ -460,7 +461,7 @@ class EfficientTTSCNN(torch.nn.Module):
         key = ("fwd", tuple(text.shape), tuple(speech.shape), text.dtype, speech.dtype, text_lengths.dtype, speech_lengths.dtype)
         ws = self._workspace(("fwd", text.shape[0], text.shape[1], speech.shape[1]), dev)
         # the graph is valid while the buffers its launches point at live: this workspace, the packed planes, the parameters
-        tag = (ws.serial, self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.side_stream, self.RESCONV_MIN_ROWS, self.fuse_soft_index)
+        tag = (ws.serial, self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.side_stream, self.RESCONV_MIN_ROWS, self.fuse_soft_index, self.fuse_prenet)
 
         def body(t, tl, sp, sl):
             (_, stats, imv, ralpha, mel_pred, _), _ = self._forward_impl(t, tl, sp, sl)
@@ -501,13 +502,19 @@ class EfficientTTSCNN(torch.nn.Module):
             key_p, val_f, val_p = self._text_side(ws, pk, text, rs1, gap1, len1, on_key=lambda: k_ready.record(side), vt=vt)  # :144-157
             v_ready.record(side)
             dur = self._duration(ws, pk, rs1, val_p, gap1, len1.data_ptr(), 0)    # :219
-        mel_in = ws.plane("mel_in", rs2, self.odim, self.split)                   # :161 prenet
-        O.pack_rows(speech, None, mel_in, rs2)
-        pre_f, pre_p, pre_l = self._stream_in(ws, "pre", rs2)
+        pre_f, pre_p, pre_l = self._stream_in(ws, "pre", rs2)                     # :161 prenet
         wp = pk["prenet"]
-        O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, act=L.ACT_LEAKY, slope=self.slope,
-               bias=self.mel_prenet[0].bias, rowmask_ptr=gap2.data_ptr(), out_f32_ptr=None if pre_f is None else pre_f.ptr,
-               ldo=C, out_plane=pre_p, out_plane_lo=pre_l)
+        if self.fuse_prenet and self.split == 1 and self.odim % 8 == 0 and self.odim <= 128 and C % 256 == 0:
+            # straight from the caller's fp32 frames: no operand plane of the mel input, one launch (bit-identical on every frame).
+            # bf16 planes only: with hi / lo weights (96 KiB of LDS, one workgroup per CU) the forward measured 0.6 % slower
+            O.frame_linear(x=speech, w=wp, bias=self.mel_prenet[0].bias, act=L.ACT_LEAKY, slope=self.slope, rs=rs2,
+                           y=pre_p, y_lo=pre_l, y_f32=pre_f)
+        else:
+            mel_in = ws.plane("mel_in", rs2, self.odim, self.split)
+            O.pack_rows(speech, None, mel_in, rs2)
+            O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, act=L.ACT_LEAKY, slope=self.slope,
+                   bias=self.mel_prenet[0].bias, rowmask_ptr=gap2.data_ptr(), out_f32_ptr=None if pre_f is None else pre_f.ptr,
+                   ldo=C, out_plane=pre_p, out_plane_lo=pre_l)
         if self.mel_query_fc is None:
             _, q_p = self._res_stack(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2, False, x_lo=pre_l)   # :162
         else:                                                                      # :163-164 Linear(C, C) in front of the attention

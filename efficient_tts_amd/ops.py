@@ -185,6 +185,21 @@ def resconv5(*, x: Plane, x_lo: Optional[Plane] = None, x_f32_ptr: Optional[int]
     L.check(L.load().efts_resconv5(C.byref(g), _stream()), "efts_resconv5")
 
 
+def frame_linear(*, x: torch.Tensor, w: "PackedWeight", bias: Optional[torch.Tensor], act: int, slope: float, rs: Rows,
+                 y: Optional[Plane] = None, y_lo: Optional[Plane] = None, y_f32: Optional[F32Rows] = None) -> None:
+    """y[b * Tp + t] = act(x[b, t] . W^T + bias) straight from the caller's fp32 frames (efts_frame_linear): x [B, T, cin] contiguous"""
+    g = L.FrameLinearArgs()
+    g.x, g.w, g.ldw, g.split = x.data_ptr(), w.ptr, w.ld, w.split
+    g.bias, g.act, g.slope = _p(bias), act, slope
+    g.B, g.T, g.Tp, g.cin, g.n = rs.B, rs.T, rs.Tp, x.shape[2], w.cout
+    if y_f32 is not None:
+        g.y_f32, g.ldo = y_f32.ptr, y_f32.c
+    if y is not None:
+        g.y, g.ldy, g.y_split = y.ptr, y.ld, y.split
+        g.y_lo = None if y_lo is None else y_lo.ptr
+    L.check(L.load().efts_frame_linear(C.byref(g), _stream()), "efts_frame_linear")
+
+
 def resconv5_plan(m: int, n: int, cus: int = 0):
     """the automatic tile schedule as (groups, [(rows, [ni, ...]), ...])"""
     buf = (C.c_int32 * L.RC_PLAN_INTS)()

@@ -186,6 +186,28 @@ typedef struct efts_resconv5_args {
 
 int efts_resconv5(const efts_resconv5_args* a, void* stream);
 
+/* A Linear with few input features applied to the caller's fp32 frames, written into the row space:
+ *   y[b * Tp + t, :] = act(x[b][t][:cin] . W^T + bias), t < T (rows t >= T of the row space are not touched: they stay zero)
+ * -- `mel_prenet` of the reference (nntts/models/efficient_tts.py:76-80, applied at :161; eval / Dropout-free) in one launch,
+ * without an operand plane of the input.  Bit-identical to efts_pack_rows + efts_gemm.  cin % 8 == 0, cin <= 128, n % 256 == 0. */
+typedef struct efts_frame_linear_args {
+    const float* x;      /* [B][T][cin] fp32, contiguous, 16-byte aligned */
+    const void* w;       /* packed B plane [n][ldw] (efts_pack_weight, one tap) of format `split` */
+    int64_t ldw;
+    int32_t split;       /* operand format the contraction runs in: 1 bf16, 2 bf16x3 (hi / lo) */
+    const float* bias;   /* [n] or NULL */
+    int32_t act;         /* EFTS_ACT_* */
+    float slope;
+    int32_t B, T, Tp, cin, n;
+    float* y_f32;        /* [B * Tp][ldo] or NULL */
+    int64_t ldo;         /* floats */
+    void* y;             /* operand plane of the output (row 0) or NULL */
+    void* y_lo;          /* y_split 1 only: bf16 remainder plane or NULL */
+    int64_t ldy;         /* bytes, both planes */
+    int32_t y_split;
+} efts_frame_linear_args;
+int efts_frame_linear(const efts_frame_linear_args* a, void* stream);
+
 /* The static tile schedule of efts_resconv5 for m rows x n columns on `cus` compute units (0: the current device).
  * One persistent workgroup per CU; the workgroups form groups (one workgroup per 256-column tile); group g belongs to
  * class g % classes and owns `rows` consecutive output rows, cut into `ntile` tiles of 32 * h - 4 rows, h = 2..8 half

@@ -404,3 +404,44 @@ def test_soft_index_in_the_gemm_epilogue_equals_the_two_kernel_path(shape):
     with pytest.raises(Exception):                                  # more than one column tile: not in the epilogue
         P.gemm(a=q, b_ptr=q.ptr, ldb=q.ld, m=T2, n=T2 if T2 > 128 else 129, batch=B, a_batch_stride=rs2.Tp * q.ld, b_batch_stride=rs2.Tp * q.ld,
                soft_index=s_fused, key_len=tl, query_len=ml)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", [1, 2])
+@pytest.mark.parametrize("shape", [(3, 37, 80), (2, 800, 80), (5, 129, 80), (2, 100, 128), (1, 64, 24)])
+def test_frame_linear_equals_pack_rows_plus_gemm(split, shape):
+    """efts_frame_linear (the prenet straight from the caller's fp32 frames) against efts_pack_rows + efts_gemm on the same weights:
+    bit for bit (same operand rounding, same k order), fp32 output, operand plane and remainder plane; gap rows stay zero."""
+    from efficient_tts_amd import lib as L, ops as P
+    B, T, cin = shape
+    C = 512
+    dev = torch.device("cuda:0")
+    torch.manual_seed(T + cin)
+    rs = P.Rows(B, T)
+    x = torch.randn(B, T, cin, device=dev)
+    pw = P.PackedWeight(C, cin, 1, split, dev); pw.pack((torch.randn(C, cin, device=dev) * 0.1).contiguous())
+    bias = torch.randn(C, device=dev)
+    gap = torch.zeros(rs.rows, device=dev); P.row_masks(torch.full((B,), T, dtype=torch.int32, device=dev), rs, gap, None)
+    with P.stream_scope():
+        a = P.Plane.for_rows(rs, cin, split, dev); P.pack_rows(x, None, a, rs)
+        o_ref = P.F32Rows(rs, C, dev); p_ref = P.Plane.for_rows(rs, C, split, dev)
+        l_ref = P.Plane.for_rows(rs, C, 1, dev) if split == 1 else None
+        P.gemm(a=a, b_ptr=pw.ptr, ldb=pw.ld, m=rs.rows, n=C, act=L.ACT_LEAKY, slope=0.1, bias=bias, rowmask_ptr=gap.data_ptr(),
+               out_f32_ptr=o_ref.ptr, ldo=C, out_plane=p_ref)
+        if split == 1:
+            P.gemm(a=a, b_ptr=pw.ptr, ldb=pw.ld, m=rs.rows, n=C, act=L.ACT_LEAKY, slope=0.1, bias=bias, rowmask_ptr=gap.data_ptr(),
+                   out_plane=P.Plane.for_rows(rs, C, 1, dev), out_plane_lo=l_ref)
+        o = P.F32Rows(rs, C, dev); y = P.Plane.for_rows(rs, C, split, dev)
+        yl = P.Plane.for_rows(rs, C, 1, dev) if split == 1 else None
+        P.frame_linear(x=x, w=pw, bias=bias, act=L.ACT_LEAKY, slope=0.1, rs=rs, y=y, y_lo=yl, y_f32=o)
+        torch.cuda.synchronize()
+    assert torch.equal(o.buf, o_ref.buf), float((o.buf - o_ref.buf).abs().max())
+    bf = lambda pl: pl.buf.view(torch.bfloat16)            # compared as numbers: the masked gap rows of efts_gemm are -0 where the value was negative
+    assert torch.equal(bf(y), bf(p_ref))
+    live = gap.bool()
+    assert torch.equal(y.buf[L.GUARD_LO:L.GUARD_LO + rs.rows][live], p_ref.buf[L.GUARD_LO:L.GUARD_LO + rs.rows][live])       # live rows: byte for byte
+    assert (y.buf[L.GUARD_LO:L.GUARD_LO + rs.rows][~live] == 0).all()
+    if split == 1:
+        assert torch.equal(bf(yl), bf(l_ref))
+    with pytest.raises(Exception):
+        P.frame_linear(x=torch.randn(B, T, 130, device=dev), w=pw, bias=bias, act=L.ACT_LEAKY, slope=0.1, rs=rs, y=y)
