@@ -15,11 +15,32 @@ int efts_num_cus(void);
 
 namespace efts {
 
-// round-to-nearest-even fp32 -> bf16 bits (same rounding as torch's .to(bfloat16))
-__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+// round-to-nearest-even fp32 -> bf16 bits (same rounding as torch's .to(bfloat16)), integer arithmetic: the reference form
+__device__ __forceinline__ unsigned short f32_to_bf16_sw(float f) {
     unsigned u = __float_as_uint(f);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
+}
+// gfx950's v_cvt_pk_bf16_f32: two values per instruction, round-to-nearest-even -- bit-identical to the integer form on every
+// finite input (tests/test_align_gpu.py sweeps the bit patterns); the planes' producers spend most of their VALU time here
+typedef __bf16 efts_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float efts_f32x2_t __attribute__((ext_vector_type(2)));
+#ifndef EFTS_HW_BF16
+#define EFTS_HW_BF16 1
+#endif
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {      // bf16(a) | bf16(b) << 16
+#if EFTS_HW_BF16
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((efts_f32x2_t){a, b}, efts_bf16x2_t));
+#else
+    return (unsigned)f32_to_bf16_sw(a) | ((unsigned)f32_to_bf16_sw(b) << 16);
+#endif
+}
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+#if EFTS_HW_BF16
+    return (unsigned short)(cvt_pk_bf16(f, 0.f) & 0xffffu);
+#else
+    return f32_to_bf16_sw(f);
+#endif
 }
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
@@ -30,14 +51,13 @@ __device__ __forceinline__ long plane_off_hi(int k, int split) {
 
 // Store 4 consecutive k's (k % 4 == 0) of one row into an operand plane.
 __device__ __forceinline__ void plane_store4(char* row, int k, float v0, float v1, float v2, float v3, int split) {
-    const unsigned short h0 = f32_to_bf16(v0), h1 = f32_to_bf16(v1), h2 = f32_to_bf16(v2), h3 = f32_to_bf16(v3);
-    uint2 hi = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
+    const unsigned p0 = cvt_pk_bf16(v0, v1), p1 = cvt_pk_bf16(v2, v3);
     char* d = row + plane_off_hi(k, split);
-    *(uint2*)d = hi;
+    *(uint2*)d = make_uint2(p0, p1);
     if (split == 2) {
-        const unsigned short l0 = f32_to_bf16(v0 - bf16_to_f32(h0)), l1 = f32_to_bf16(v1 - bf16_to_f32(h1));
-        const unsigned short l2 = f32_to_bf16(v2 - bf16_to_f32(h2)), l3 = f32_to_bf16(v3 - bf16_to_f32(h3));
-        *(uint2*)(d + 64) = make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
+        const unsigned q0 = cvt_pk_bf16(v0 - __uint_as_float(p0 << 16), v1 - __uint_as_float(p0 & 0xffff0000u));
+        const unsigned q1 = cvt_pk_bf16(v2 - __uint_as_float(p1 << 16), v3 - __uint_as_float(p1 & 0xffff0000u));
+        *(uint2*)(d + 64) = make_uint2(q0, q1);
     }
 }
 

@@ -69,10 +69,10 @@ __device__ __forceinline__ void store_b128(u32x4 v, __amdgpu_buffer_rsrc_t r, un
 }
 
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b, float* ra, float* rb) {
-    const unsigned short ha = f32_to_bf16(a), hb = f32_to_bf16(b);
-    *ra = a - bf16_to_f32(ha);
-    *rb = b - bf16_to_f32(hb);
-    return (unsigned)ha | ((unsigned)hb << 16);
+    const unsigned h = cvt_pk_bf16(a, b);
+    *ra = a - __uint_as_float(h << 16);
+    *rb = b - __uint_as_float(h & 0xffff0000u);
+    return h;
 }
 
 }  // namespace efts

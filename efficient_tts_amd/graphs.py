@@ -7,6 +7,7 @@ the same code path into a graph over static input copies, later calls copy the i
 fresh clones of the outputs (the reference returns new tensors every call)."""
 from __future__ import annotations
 
+import logging
 from collections import OrderedDict
 from typing import Callable, Sequence, Tuple
 
@@ -14,10 +15,11 @@ import torch
 
 
 class _Entry:
-    __slots__ = ("calls", "graph", "static_in", "static_out", "tag", "keepalive")
+    __slots__ = ("calls", "graph", "static_in", "static_out", "tag", "keepalive", "eager_only")
 
     def __init__(self):
         self.calls, self.graph, self.static_in, self.static_out, self.tag, self.keepalive = 0, None, None, None, None, None
+        self.eager_only = False          # a capture of this shape failed once: it stays on plain launches
 
 
 class GraphCache:
@@ -41,14 +43,22 @@ class GraphCache:
         if ent.graph is not None and ent.tag != tag:
             ent.graph, ent.static_in, ent.static_out, ent.keepalive, ent.calls = None, None, None, None, 1
         ent.calls += 1
-        if ent.calls == 1:                                   # first sight of this shape: plain eager run (also the warm-up)
+        if ent.calls == 1 or ent.eager_only:                 # first sight of this shape: plain eager run (also the warm-up)
             return fn(*inputs)
         if ent.graph is None:
             ent.static_in = [t.clone() for t in inputs]
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(g):
-                ent.static_out = fn(*ent.static_in)
+            try:
+                # thread_local: HIP calls of OTHER threads (a DataLoader's pin-memory thread, the allocator, RCCL's proxy) during
+                # the capture do not invalidate it
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    ent.static_out = fn(*ent.static_in)
+            except Exception as exc:                         # noqa: BLE001 -- any capture failure: this shape runs eagerly from now on
+                logging.warning("hipGraph capture failed for %s (%s): the shape stays on eager launches", key[0], exc)
+                ent.eager_only, ent.static_in, ent.static_out, ent.keepalive = True, None, None, None
+                torch.cuda.synchronize()
+                return fn(*inputs)
             ent.graph, ent.tag, ent.keepalive = g, tag, keepalive
         else:
             for s, t in zip(ent.static_in, inputs):

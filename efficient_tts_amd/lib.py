@@ -49,6 +49,13 @@ class FrameLinearArgs(C.Structure):
                 ("ldy", i64), ("y_split", i32)]
 
 
+class ExpandArgs(C.Structure):
+    """mirror of efts_expand_args (include/efts_abi.h)"""
+    _fields_ = [("e", vp), ("text_len", vp), ("mel_len", vp), ("sigma", f32), ("v", vp), ("ldv", i64),
+                ("B", i32), ("T1", i32), ("T1p", i32), ("T2", i32), ("T2p", i32), ("n", i32),
+                ("alpha_out", vp), ("y_f32", vp), ("ldo", i64), ("y", vp), ("y_lo", vp), ("ldy", i64), ("y_split", i32)]
+
+
 class ResConv5Args(C.Structure):
     """mirror of `struct efts_resconv5_args` (include/efts_abi.h)"""
     _fields_ = [
@@ -79,6 +86,9 @@ _SIGS = {
     "efts_reconst_alpha": (i32, [vp, vp, vp, f32, vp, vp, i64, i32, i32, i32, i32, vp]),
     "efts_pack_vt": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "efts_cumsum_rows": (i32, [vp, vp, i32, i32, vp]),
+    "efts_imv_align": (i32, [vp, vp, vp, f32, f32, i32, vp, vp, vp, i32, i32, i32, vp]),
+    "efts_expand": (i32, [C.POINTER(ExpandArgs), vp]),
+    "efts_bf16_round": (i32, [vp, vp, i64, i32, vp]),
     "efts_layernorm_rows": (i32, [vp, vp, vp, f32, vp, vp, vp, i64, i32, i32, i32, f32, C.c_uint32, vp]),
     "efts_layernorm_dot": (i32, [vp, vp, vp, f32, vp, vp, vp, i32, f32, vp, i32, i32, f32, C.c_uint32, vp]),
     "efts_losses_workspace_bytes": (C.c_size_t, []),

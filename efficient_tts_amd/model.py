@@ -196,6 +196,8 @@ class EfficientTTSCNN(torch.nn.Module):
         self.duration_predictor = _DurationPredictor(n_channels, n_duration_layer, n_channels, offset=duration_offset)
         self.fuse_prenet = True             # bf16 mode: the prenet straight from the fp32 frames (efts_frame_linear); False: efts_pack_rows + efts_gemm
         self.fuse_soft_index = True         # T1 <= 128: q.k^T, softmax and soft index in one launch (False: scores stored, efts_attn_soft_index)
+        self.fuse_align = True              # imv scan + aligned positions + duration target in one launch (efts_imv_align)
+        self.fuse_expand = True             # T1 <= 256: alpha' generated in registers inside the expand contraction (efts_expand); False: reconst_alpha + pack_vt + efts_gemm
         self.graphs = True                  # plain eval calls replay a per-shape hipGraph (False: every kernel launched eagerly)
         self._graph_cache = GraphCache()
         self._infer_cache = GraphCache(capacity=64)      # free-running inference: two phases per (bucketed) shape
@@ -306,15 +308,21 @@ class EfficientTTSCNN(torch.nn.Module):
             object.__setattr__(self, "_side", st)
         return st
 
-    def _workspace(self, key, device) -> _Workspace:
-        # bound the cached shapes (each holds full activations): 4 teacher-forced / training shapes, 64 free-running ones
-        # (their row spaces are one or a few utterances, a few MB each)
+    def _workspace(self, key, device, pin=()) -> _Workspace:
+        """The buffers of one shape.  Bounded LRU pools (each entry holds full activations): 4 teacher-forced / training
+        shapes, 64 free-running ones (one or a few utterances, a few MB each).  `pin`: workspaces of the call in progress,
+        never evicted -- their buffers are about to be read (the value projection of phase 1) or captured."""
         pool, cap = (self._ws_infer, 64) if key[0] in ("infb", "infb2", "inf", "inf2") else (self._ws, 4)
-        if key not in pool:
-            if len(pool) >= cap:
-                pool.pop(next(iter(pool)))
-            pool[key] = _Workspace(device)
-        return pool[key]
+        ws = pool.pop(key, None)
+        if ws is None:
+            for old in list(pool):
+                if len(pool) < cap:
+                    break
+                if not any(pool[old] is q for q in pin):
+                    del pool[old]
+            ws = _Workspace(device)
+        pool[key] = ws                                   # most recently used last
+        return ws
 
     # ------------------------------------------------------------------ building blocks
     # row spaces of at least this many rows run their residual stacks on efts_resconv5 (hi/lo planes, one persistent
@@ -413,18 +421,29 @@ class EfficientTTSCNN(torch.nn.Module):
                                 dp.linear.bias.detach(), out_mask_ptr, mode, float(dp.offset), out, rs1.rows, C)
         return out
 
-    def _expand_decode(self, ws, pk, B, T1, rs1: Rows, rs2: Rows, val_f: F32Rows, ra_plane: Plane, len2_ptr, gap2,
+    def _fused_expand(self, T1: int) -> bool:
+        return self.fuse_expand and T1 <= 256 and self.n_channels % 128 == 0
+
+    def _expand_decode(self, ws, pk, B, T1, rs1: Rows, rs2: Rows, val_f: F32Rows, e, tl, ml, ralpha, len2_ptr, gap2,
                        vt: Optional[Plane] = None):
-        """bmm(V^T, alpha') -> decoder -> mel head (efficient_tts.py:190-200 / :278-284).  `vt`: V^T already packed."""
+        """Gaussian re-alignment from e, bmm(V^T, alpha') -> decoder -> mel head (efficient_tts.py:184-200 / :270-284).
+        `ralpha` [B, T1, T2] receives alpha' (the API tensor); tl / ml: int32 lengths or None (no masks, :270-274);
+        `vt`: V^T already packed (unfused path only)."""
         C = self.n_channels
-        if vt is None:
-            vt = ws.raw_plane("vt", B * C, T1, 2)
-            O.pack_vt(val_f, vt, B, T1, rs1.Tp, C)
         h_f, h_p, h_l = self._stream_in(ws, "exp", rs2)
-        O.gemm(a=ra_plane, b_ptr=vt.ptr, ldb=vt.ld, m=rs2.T, n=C, batch=B, a_batch_stride=rs2.Tp * ra_plane.ld,
-               b_batch_stride=C * vt.ld, rowmask_ptr=len2_ptr, rowmask_batch_stride=rs2.Tp,
-               out_f32_ptr=None if h_f is None else h_f.ptr, ldo=C, out_batch_stride=rs2.Tp * C, out_plane=h_p,
-               outb_batch_stride=rs2.Tp * h_p.ld, out_plane_lo=h_l)
+        if self._fused_expand(T1):
+            # alpha' is the MFMA A operand, produced in registers; V is read as fp32: no alpha'^T plane, no V^T planes
+            O.expand(e=e, tl=tl, ml=ml, sigma=float(self.sigma), v=val_f, rs1=rs1, rs2=rs2, alpha_out=ralpha, y_f32=h_f, y=h_p, y_lo=h_l)
+        else:
+            ra_plane = ws.plane("ra_p", rs2, T1, 2)
+            O.reconst_alpha(e, tl, ml, float(self.sigma), ralpha, ra_plane, B, T1, rs2.T, rs2.Tp)
+            if vt is None:
+                vt = ws.raw_plane("vt", B * C, T1, 2)
+                O.pack_vt(val_f, vt, B, T1, rs1.Tp, C)
+            O.gemm(a=ra_plane, b_ptr=vt.ptr, ldb=vt.ld, m=rs2.T, n=C, batch=B, a_batch_stride=rs2.Tp * ra_plane.ld,
+                   b_batch_stride=C * vt.ld, rowmask_ptr=len2_ptr, rowmask_batch_stride=rs2.Tp,
+                   out_f32_ptr=None if h_f is None else h_f.ptr, ldo=C, out_batch_stride=rs2.Tp * C, out_plane=h_p,
+                   outb_batch_stride=rs2.Tp * h_p.ld, out_plane_lo=h_l)
         _, d_p = self._res_stack(ws, "dec", "decoder", pk, rs2, h_f, h_p, gap2.data_ptr(), self.split, False, x_lo=h_l)
         mel = ws.f32("mel_pred", rs2, self.odim)
         wh = pk["head"]
@@ -461,7 +480,7 @@ class EfficientTTSCNN(torch.nn.Module):
         key = ("fwd", tuple(text.shape), tuple(speech.shape), text.dtype, speech.dtype, text_lengths.dtype, speech_lengths.dtype)
         ws = self._workspace(("fwd", text.shape[0], text.shape[1], speech.shape[1]), dev)
         # the graph is valid while the buffers its launches point at live: this workspace, the packed planes, the parameters
-        tag = (ws.serial, self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.side_stream, self.RESCONV_MIN_ROWS, self.fuse_soft_index, self.fuse_prenet)
+        tag = (ws.serial, self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.side_stream, self.RESCONV_MIN_ROWS, self.fuse_soft_index, self.fuse_prenet, self.fuse_align, self.fuse_expand)
 
         def body(t, tl, sp, sl):
             (_, stats, imv, ralpha, mel_pred, _), _ = self._forward_impl(t, tl, sp, sl)
@@ -495,7 +514,7 @@ class EfficientTTSCNN(torch.nn.Module):
         side = self._side_stream(dev)
         side.wait_stream(main)
         k_ready, v_ready = torch.cuda.Event(), torch.cuda.Event()
-        vt = ws.raw_plane("vt", B * C, T1, 2)
+        vt = None if self._fused_expand(T1) else ws.raw_plane("vt", B * C, T1, 2)
         O.row_masks(ml, rs2, gap2, len2)                                          # :139
         with O.on_stream(side):
             O.row_masks(tl, rs1, gap1, len1)                                      # :137
@@ -538,18 +557,19 @@ class EfficientTTSCNN(torch.nn.Module):
                    b_batch_stride=rs1.Tp * key_p.ld, alpha=O.INV_SQRT(C), out_f32_ptr=scores.data_ptr(), ldo=T1,
                    out_batch_stride=T2 * T1)
             O.attn_soft_index(scores, T1, tl, ml, sidx, alpha, B, T1, T2)         # :391-398, :168, :312
-        O.imv_scan(sidx, tl, ml, imv, B, T2)                                      # :314-323
         e, lde = ws.tensor("e", (B, T1)), ws.tensor("lde", (B, T1))
-        O.aligned_positions(imv, tl, ml, float(self.sigma_e), float(self.duration_offset), e, lde if self.delta_e_method_1 else None,
-                            B, T1, T2)                                            # :178-180, :203-216
-        if not self.delta_e_method_1:
-            O.duration_target(e, tl, ml, float(self.duration_offset), False, lde, B, T1)   # :205-213
+        if self.fuse_align and (2 * roundup(T2, 4) + T1) * 4 <= 160 * 1024:
+            O.imv_align(sidx, tl, ml, float(self.sigma_e), float(self.duration_offset), self.delta_e_method_1, imv, e, lde, B, T1, T2)   # :314-345, :203-216
+        else:
+            O.imv_scan(sidx, tl, ml, imv, B, T2)                                  # :314-323
+            O.aligned_positions(imv, tl, ml, float(self.sigma_e), float(self.duration_offset), e, lde if self.delta_e_method_1 else None,
+                                B, T1, T2)                                        # :178-180, :203-216
+            if not self.delta_e_method_1:
+                O.duration_target(e, tl, ml, float(self.duration_offset), False, lde, B, T1)   # :205-213
         ralpha = torch.empty(B, T1, T2, dtype=torch.float32, device=dev)
-        ra_p = ws.plane("ra_p", rs2, T1, 2)
-        O.reconst_alpha(e, tl, ml, float(self.sigma), ralpha, ra_p, B, T1, T2, rs2.Tp)   # :184-186
 
         main.wait_event(v_ready)
-        mel = self._expand_decode(ws, pk, B, T1, rs1, rs2, val_f, ra_p, len2.data_ptr(), gap2, vt=vt)   # :190-200
+        mel = self._expand_decode(ws, pk, B, T1, rs1, rs2, val_f, e, tl, ml, ralpha, len2.data_ptr(), gap2, vt=vt)   # :184-200
         main.wait_stream(side)                                                     # duration predictor done
 
         out3 = torch.empty(3, dtype=torch.float32, device=dev)                     # :220-227
@@ -596,26 +616,23 @@ class EfficientTTSCNN(torch.nn.Module):
         if t2 <= 0:
             raise ValueError("predicted total duration rounds to 0 frames")
         rs2 = Rows(1, t2)
-        ws2 = self._workspace(("inf2", 1, T1, t2), dev)
+        ws2 = self._workspace(("inf2", 1, T1, t2), dev, pin=(ws,))
         gap2 = ws2.tensor("gap2", (rs2.rows,))
         O.row_masks(torch.full((1,), t2, dtype=torch.int32, device=dev), rs2, gap2, None)
         ralpha = torch.empty(1, T1, t2, dtype=torch.float32, device=dev)
-        ra_p = ws2.plane("ra_p", rs2, T1, 2)
-        O.reconst_alpha(e, None, None, float(self.sigma), ralpha, ra_p, 1, T1, t2, rs2.Tp)   # :270-274
-        mel = self._expand_decode(ws2, pk, 1, T1, rs1, rs2, val_f, ra_p, None, gap2)         # :278-284
+        mel = self._expand_decode(ws2, pk, 1, T1, rs1, rs2, val_f, e, None, None, ralpha, None, gap2)   # :270-284
         return mel.view().clone(), ralpha
 
     # ------------------------------------------------------------------ batched ragged inference (extension)
     T1_BUCKET, T2_BUCKET = 16, 64       # free-running inference runs on shapes rounded up to these multiples (graph / workspace reuse)
 
-    def _infer_text(self, text, tl, force_delta):
+    def _infer_text(self, ws, text, tl, force_delta):
         """phase 1 (no host sync): embed -> text encoder -> value -> duration predictor -> aligned positions e = cumsum(durations)
         and the mel length of every item (efficient_tts.py:246-260).  text [B, T1] int64 (positions >= tl are ignored), tl int32 [B]."""
         dev = text.device
         B, T1 = text.shape
         C = self.n_channels
         pk = self._weights()
-        ws = self._workspace(("infb", B, T1), dev)
         rs1 = Rows(B, T1)
         gap1, len1 = ws.tensor("gap1", (rs1.rows,)), ws.tensor("len1", (rs1.rows,))
         O.row_masks(tl, rs1, gap1, len1)
@@ -642,23 +659,20 @@ class EfficientTTSCNN(torch.nn.Module):
             e = e - d2
         return e, ml
 
-    def _infer_mel(self, e, tl, ml, T2: int):
+    def _infer_mel(self, ws, ws2, e, tl, ml, T2: int):
         """phase 2: Gaussian re-alignment from e, expand, decoder, mel head on a [B, T2] row space (efficient_tts.py:270-284);
-        reads the value projection phase 1 left in the (B, T1) workspace."""
+        reads the value projection phase 1 left in `ws` (the (B, T1) workspace the caller holds: never looked up again by key,
+        a pool eviction in between would hand back a fresh zero-filled one)."""
         dev = e.device
         B, T1 = e.shape
         C = self.n_channels
         pk = self._weights()
-        ws = self._workspace(("infb", B, T1), dev)
         rs1, rs2 = Rows(B, T1), Rows(B, T2)
-        ws2 = self._workspace(("infb2", B, T1, T2), dev)
         val_f = ws.f32("val_f", rs1, C)
         gap2, len2 = ws2.tensor("gap2", (rs2.rows,)), ws2.tensor("len2", (rs2.rows,))
         O.row_masks(ml, rs2, gap2, len2)
         ralpha = torch.empty(B, T1, T2, dtype=torch.float32, device=dev)
-        ra_p = ws2.plane("ra_p", rs2, T1, 2)
-        O.reconst_alpha(e, tl, ml, float(self.sigma), ralpha, ra_p, B, T1, T2, rs2.Tp)
-        mel = self._expand_decode(ws2, pk, B, T1, rs1, rs2, val_f, ra_p, len2.data_ptr(), len2)
+        mel = self._expand_decode(ws2, pk, B, T1, rs1, rs2, val_f, e, tl, ml, ralpha, len2.data_ptr(), len2)
         return mel.view().clone(), ralpha
 
     @torch.no_grad()
@@ -687,27 +701,27 @@ class EfficientTTSCNN(torch.nn.Module):
             if T1b != T1:
                 text = torch.nn.functional.pad(text, (0, T1b - T1))
             pk = self._weights()
-            wsig = (self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.RESCONV_MIN_ROWS)
+            wsig = (self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.RESCONV_MIN_ROWS, self.fuse_expand)
+            ws = self._workspace(("infb", B, T1b), dev)
             if graphs:
-                ws = self._workspace(("infb", B, T1b), dev)
                 def phase1(t, l):
                     with O.stream_scope():              # resolved INSIDE the capture: the launches must go to the capturing stream
-                        return self._infer_text(t, l, force_delta)
+                        return self._infer_text(ws, t, l, force_delta)
                 e, ml = self._infer_cache.run(("text", B, T1b, force_delta), (ws.serial, wsig), (text.contiguous(), tl), phase1, keepalive=ws)
             else:
-                e, ml = self._infer_text(text, tl, force_delta)
+                e, ml = self._infer_text(ws, text, tl, force_delta)
             t2 = int(ml.max().item())                                                      # the one host sync
             if t2 <= 0:
                 raise ValueError("predicted total durations round to 0 frames")
             T2b = roundup(t2, self.T2_BUCKET) if graphs else t2
+            ws2 = self._workspace(("infb2", B, T1b, T2b), dev, pin=(ws,))
             if graphs:
-                ws2 = self._workspace(("infb2", B, T1b, T2b), dev)
                 def phase2(e_, l, m):
                     with O.stream_scope():
-                        return self._infer_mel(e_, l, m, T2b)
+                        return self._infer_mel(ws, ws2, e_, l, m, T2b)
                 mel, ralpha = self._infer_cache.run(("mel", B, T1b, T2b), (ws.serial, ws2.serial, wsig), (e, tl, ml), phase2, keepalive=(ws, ws2))
             else:
-                mel, ralpha = self._infer_mel(e, tl, ml, T2b)
+                mel, ralpha = self._infer_mel(ws, ws2, e, tl, ml, T2b)
             if T2b != t2 or T1b != T1:
                 mel, ralpha = mel[:, :t2].contiguous(), ralpha[:, :T1, :t2].contiguous()
             return mel, ml.to(torch.int64), ralpha

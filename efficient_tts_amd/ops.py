@@ -299,6 +299,28 @@ def reconst_alpha(e, tl, ml, sigma, alpha_out, plane: Optional[Plane], B, T1, T2
                                         B, T1, T2, T2p, _stream()), "efts_reconst_alpha")
 
 
+def imv_align(soft_idx, tl, ml, sigma_e, offset, method1: bool, imv, e, lde, B, T1, T2) -> None:
+    """imv_scan + aligned_positions + duration_target in one launch (efts_imv_align)"""
+    L.check(L.load().efts_imv_align(soft_idx.data_ptr(), tl.data_ptr(), ml.data_ptr(), sigma_e, offset, int(method1), imv.data_ptr(),
+                                    e.data_ptr(), _p(lde), B, T1, T2, _stream()), "efts_imv_align")
+
+
+def expand(*, e, tl, ml, sigma: float, v: F32Rows, rs1: Rows, rs2: Rows, alpha_out: Optional[torch.Tensor] = None,
+           y_f32: Optional[F32Rows] = None, y: Optional[Plane] = None, y_lo: Optional[Plane] = None) -> None:
+    """alpha' generated in registers and contracted with V (efts_expand): H[b * T2p + j] = sum_i alpha'[b, i, j] V[b * T1p + i]"""
+    g = L.ExpandArgs()
+    g.e, g.text_len, g.mel_len, g.sigma = e.data_ptr(), _p(tl), _p(ml), sigma
+    g.v, g.ldv = v.ptr, v.c
+    g.B, g.T1, g.T1p, g.T2, g.T2p, g.n = rs1.B, rs1.T, rs1.Tp, rs2.T, rs2.Tp, v.c
+    g.alpha_out = _p(alpha_out)
+    if y_f32 is not None:
+        g.y_f32, g.ldo = y_f32.ptr, y_f32.c
+    if y is not None:
+        g.y, g.ldy, g.y_split = y.ptr, y.ld, y.split
+        g.y_lo = None if y_lo is None else y_lo.ptr
+    L.check(L.load().efts_expand(C.byref(g), _stream()), "efts_expand")
+
+
 def pack_vt(v: F32Rows, plane: Plane, B, T1, T1p, c) -> None:
     L.check(L.load().efts_pack_vt(v.ptr, v.c, plane.ptr, plane.ld, B, T1, T1p, c, _stream()), "efts_pack_vt")
 

@@ -280,6 +280,46 @@ int efts_pack_vt(const float* v, int64_t ldv, void* plane, int64_t ld_plane, int
                  int32_t T1p, int32_t c, void* stream);
 int efts_cumsum_rows(const float* x, float* y, int32_t B, int32_t T, void* stream);
 
+/* The middle of the alignment block in ONE launch (one workgroup per item, operands in LDS after the first load):
+ * efts_imv_scan + efts_aligned_positions + efts_duration_target, bit-identical to that chain
+ * (imv_generator efficient_tts.py:314-323, get_aligned_positions :326-345, duration target :203-216).
+ * imv [B][T2], e [B][T1], log_delta_e [B][T1] or NULL.  2 * T2 floats must fit 160 KiB of LDS. */
+int efts_imv_align(const float* soft_idx, const int32_t* text_len, const int32_t* mel_len, float sigma_e, float offset,
+                   int32_t method1, float* imv, float* e, float* log_delta_e, int32_t B, int32_t T1, int32_t T2, void* stream);
+
+/* Gaussian re-alignment + expansion in one launch:
+ *   alpha'[b][i][j] = softmax_i( -sigma (q_j - e[b][i])^2 ), q_j = j for j < mel_len[b] else 0, keys i >= text_len[b] excluded,
+ *                     zero outside the text x mel mask   (reconstruct_align_from_aligned_position efficient_tts.py:347-375, :186)
+ *   H[b * T2p + j][:] = sum_i alpha'[b][i][j] * V[b * T1p + i][:]   (the expand bmm :190-194; frames j >= mel_len[b] are zero)
+ * alpha' is produced in registers as the MFMA A operand (split-bf16: lo*hi + hi*lo + hi*hi, as efts_gemm on split-2 planes)
+ * and never stored as an operand plane; V is read as fp32 from its row space (no V^T planes).  Lengths NULL = inference (no
+ * masks, :270-274).  Outputs, any combination: alpha_out (the API tensor [B][T1][T2] fp32), y_f32 (row space [B*T2p][ldo]),
+ * y (operand plane of format y_split; with y_split 1 an optional remainder plane y_lo).  Rows j >= T2 of the row space are
+ * not touched.  T1 <= 256, n % 128 == 0. */
+typedef struct efts_expand_args {
+    const float* e;          /* [B][T1] aligned positions */
+    const int32_t* text_len; /* [B] or NULL */
+    const int32_t* mel_len;  /* [B] or NULL */
+    float sigma;
+    const float* v;          /* value projection, fp32 row space [B * T1p][ldv] */
+    int64_t ldv;             /* elements */
+    int32_t B, T1, T1p, T2, T2p;
+    int32_t n;               /* channels */
+    float* alpha_out;        /* [B][T1][T2] or NULL */
+    float* y_f32;            /* [B * T2p][ldo] or NULL */
+    int64_t ldo;             /* elements */
+    void* y;                 /* operand plane (row 0) or NULL */
+    void* y_lo;              /* y_split 1 only: bf16 remainder plane or NULL */
+    int64_t ldy;             /* bytes, both planes */
+    int32_t y_split;
+} efts_expand_args;
+int efts_expand(const efts_expand_args* a, void* stream);
+
+/* The fp32 -> bf16 rounding of every operand-plane producer in this library (round to nearest even; torch's
+ * .to(torch.bfloat16)): mode 0 = as the kernels do it (gfx950's packed conversion instruction), mode 1 = the integer
+ * reference form.  y[i] = bf16 bits of x[i].  Exists so that a test can sweep bit patterns through both. */
+int efts_bf16_round(const float* x, uint16_t* y, int64_t n, int32_t mode, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Duration predictor tail (nntts/layers/duration_predictor.py:57-88, layer_norm.py:6-30).
  * efts_layernorm_rows: y = LN_c(x) * gamma + beta (biased variance, eps), times rowmask[row];

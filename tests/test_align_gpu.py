@@ -1,0 +1,173 @@
+"""GPU (-m gpu): the fused alignment kernels (csrc/efts_align.hip) against the kernel chain they replace and against fp64.
+
+efts_imv_align == efts_imv_scan + efts_aligned_positions + efts_duration_target, bit for bit.
+efts_expand    == efts_reconst_alpha + efts_pack_vt + efts_gemm (split-bf16) to fp32 rounding, and within 2e-5 (relative to
+                  the output range) of the fp64 value of reconstruct_align_from_aligned_position + bmm
+                  (nntts/models/efficient_tts.py:347-375, :186, :190-194).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _lengths(B, T, g, full_first=True):
+    ln = torch.randint(max(1, T // 3), T + 1, (B,), generator=g)
+    if full_first:
+        ln[0] = T
+    return ln.to(torch.int32)
+
+
+@pytest.mark.parametrize("method1", [True, False])
+@pytest.mark.parametrize("B,T1,T2", [(3, 37, 211), (2, 128, 800), (4, 100, 124), (1, 9, 33), (2, 200, 1500), (2, 128, 4100)])
+def test_imv_align_equals_the_three_kernel_chain(B, T1, T2, method1):
+    from efficient_tts_amd import ops as P
+    dev = _dev()
+    g = torch.Generator().manual_seed(T1 * 7 + T2)
+    tl, ml = _lengths(B, T1, g).to(dev), _lengths(B, T2, g).to(dev)
+    # a soft index like the attention's: noisy, roughly increasing over the frames
+    sidx = (torch.rand(B, T2, generator=g).cumsum(1) / T2 * T1 * 2 + torch.randn(B, T2, generator=g) * 0.7).to(dev)
+    imv0, e0, lde0 = torch.empty(B, T2, device=dev), torch.empty(B, T1, device=dev), torch.empty(B, T1, device=dev)
+    P.imv_scan(sidx, tl, ml, imv0, B, T2)
+    P.aligned_positions(imv0, tl, ml, 0.5, 1.0, e0, lde0 if method1 else None, B, T1, T2)
+    if not method1:
+        P.duration_target(e0, tl, ml, 1.0, False, lde0, B, T1)
+    imv1, e1, lde1 = torch.full((B, T2), 7.0, device=dev), torch.full((B, T1), 7.0, device=dev), torch.full((B, T1), 7.0, device=dev)
+    P.imv_align(sidx, tl, ml, 0.5, 1.0, method1, imv1, e1, lde1, B, T1, T2)
+    torch.cuda.synchronize()
+    assert torch.equal(imv0, imv1)
+    assert torch.equal(e0, e1)
+    assert torch.equal(lde0, lde1)
+    assert bool((imv1[:, 1:] >= imv1[:, :-1]).logical_or(imv1[:, 1:] == 0).all())      # monotone up to the masked tail
+
+
+def _expand_ref64(e, v, tl, ml, sigma, T2):
+    """fp64 restatement of efficient_tts.py:347-375 + :186 + :190-194 on [B, T1] positions and [B, T1, C] values"""
+    B, T1 = e.shape
+    e, v = e.double(), v.double()
+    out_a = torch.zeros(B, T1, T2, dtype=torch.float64)
+    for b in range(B):
+        t, m = (int(tl[b]), int(ml[b])) if tl is not None else (T1, T2)
+        q = torch.arange(T2, dtype=torch.float64)
+        q[m:] = 0.0
+        en = -sigma * (q[None, :] - e[b, :t, None]) ** 2
+        a = torch.softmax(en, dim=0)
+        a[:, m:] = 0.0
+        out_a[b, :t] = a
+    h = torch.einsum("bij,bic->bjc", out_a, v)
+    return out_a, h
+
+
+@pytest.mark.parametrize("fmt", ["split2", "split1", "f32"])
+@pytest.mark.parametrize("B,T1,T2,masked", [(3, 37, 211, True), (2, 128, 800, True), (2, 200, 333, True), (1, 96, 577, False),
+                                            (2, 256, 70, True), (4, 16, 31, True)])
+def test_expand_vs_fp64_and_the_unfused_chain(B, T1, T2, masked, fmt):
+    from efficient_tts_amd import lib as L, ops as P
+    dev = _dev()
+    C = 512
+    g = torch.Generator().manual_seed(T1 * 13 + T2)
+    tl = _lengths(B, T1, g) if masked else None
+    ml = _lengths(B, T2, g) if masked else None
+    # positions like the model's: increasing over the keys, spanning the frames
+    e = (torch.rand(B, T1, generator=g) + 0.2).cumsum(1)
+    e = e / e[:, -1:] * (T2 - 1)
+    v = torch.randn(B, T1, C, generator=g)
+    if masked:
+        for b in range(B):
+            v[b, int(tl[b]):] = 0.0                    # the value projection is zero at padded text (efficient_tts.py:157)
+    rs1, rs2 = P.Rows(B, T1), P.Rows(B, T2)
+    vf = P.F32Rows(rs1, C, dev)
+    vf.view().copy_(v.to(dev))
+    e_d = e.to(dev).contiguous()
+    tl_d, ml_d = (tl.to(dev), ml.to(dev)) if masked else (None, None)
+
+    # --- fused
+    ra1 = torch.full((B, T1, T2), 7.0, device=dev)
+    y_f = P.F32Rows(rs2, C, dev) if fmt == "f32" else None
+    y_p = P.Plane.for_rows(rs2, C, 2 if fmt == "split2" else 1, dev) if fmt != "f32" else None
+    y_l = P.Plane.for_rows(rs2, C, 1, dev) if fmt == "split1" else None
+    P.expand(e=e_d, tl=tl_d, ml=ml_d, sigma=0.01, v=vf, rs1=rs1, rs2=rs2, alpha_out=ra1, y_f32=y_f, y=y_p, y_lo=y_l)
+
+    # --- the chain it replaces
+    ra0 = torch.empty(B, T1, T2, device=dev)
+    ra_p = P.Plane.for_rows(rs2, T1, 2, dev)
+    P.reconst_alpha(e_d, tl_d, ml_d, 0.01, ra0, ra_p, B, T1, T2, rs2.Tp)
+    vt = P.Plane(B * C, T1, 2, dev)
+    P.pack_vt(vf, vt, B, T1, rs1.Tp, C)
+    lenm = torch.zeros(rs2.rows, device=dev)
+    gap = torch.zeros(rs2.rows, device=dev)
+    P.row_masks(ml_d if masked else torch.full((B,), T2, dtype=torch.int32, device=dev), rs2, gap, lenm)
+    h0 = P.F32Rows(rs2, C, dev)
+    P.gemm(a=ra_p, b_ptr=vt.ptr, ldb=vt.ld, m=T2, n=C, batch=B, a_batch_stride=rs2.Tp * ra_p.ld, b_batch_stride=C * vt.ld,
+           rowmask_ptr=lenm.data_ptr(), rowmask_batch_stride=rs2.Tp, out_f32_ptr=h0.ptr, ldo=C, out_batch_stride=rs2.Tp * C)
+    torch.cuda.synchronize()
+
+    if fmt == "f32":
+        got = y_f.view().cpu()
+        full = y_f.buf.cpu()
+    elif fmt == "split2":
+        pl = y_p.buf[L.GUARD_LO:L.GUARD_LO + rs2.rows].view(torch.bfloat16).view(rs2.rows, y_p.nchunk, 2, 32).float()
+        full = (pl[:, :, 0] + pl[:, :, 1]).reshape(B, rs2.Tp, C).cpu()
+        got = full[:, :T2]
+    else:
+        hi = y_p.buf[L.GUARD_LO:L.GUARD_LO + rs2.rows].view(torch.bfloat16).float().view(B, rs2.Tp, C)
+        lo = y_l.buf[L.GUARD_LO:L.GUARD_LO + rs2.rows].view(torch.bfloat16).float().view(B, rs2.Tp, C)
+        full = (hi + lo).cpu()
+        got = full[:, :T2]
+    a64, h64 = _expand_ref64(e, v, tl, ml, 0.01, T2)
+    scale = float(h64.abs().max())
+    tol = 2e-5 * scale + (0.0 if fmt == "f32" else 2.0 ** -16 * scale)      # + the 16-bit hi/lo stream format
+    assert float((got.double() - h64).abs().max()) <= tol
+    assert float((ra1.cpu().double() - a64).abs().max()) <= 2e-6
+    # against the chain: same maths in the same operand format, different summation order of the softmax only
+    assert float((ra1 - ra0).abs().max()) <= 1e-6
+    assert float((got - h0.view().cpu()).abs().max()) <= 2e-5 * scale + (0.0 if fmt == "f32" else 2.0 ** -16 * scale)
+    # frames past an item's mel length are exact zeros; gap rows (t >= T2) are never touched
+    if masked:
+        for b in range(B):
+            assert float(got[b, int(ml[b]):].abs().max() if int(ml[b]) < T2 else 0.0) == 0.0
+            assert float(ra1[b, :, int(ml[b]):].abs().max() if int(ml[b]) < T2 else 0.0) == 0.0
+            assert float(ra1[b, int(tl[b]):].abs().max() if int(tl[b]) < T1 else 0.0) == 0.0
+    if fmt != "f32":
+        assert float(full[:, T2:].abs().max()) == 0.0
+    assert float((ra1.sum(1).cpu() - (a64.sum(1) > 0.5).float()).abs().max()) <= 1e-5        # columns sum to one where live
+
+
+def test_expand_rejects_long_texts():
+    from efficient_tts_amd import ops as P
+    dev = _dev()
+    rs1, rs2 = P.Rows(1, 300), P.Rows(1, 64)
+    with pytest.raises(ValueError, match="T1 <= 256"):
+        P.expand(e=torch.zeros(1, 300, device=dev), tl=None, ml=None, sigma=0.01, v=P.F32Rows(rs1, 512, dev), rs1=rs1, rs2=rs2,
+                 y_f32=P.F32Rows(rs2, 512, dev))
+
+
+def test_hardware_bf16_rounding_equals_the_integer_form():
+    """every plane producer rounds with v_cvt_pk_bf16_f32; the integer round-to-nearest-even is the reference form (and what
+    torch's .to(bfloat16) does): equal on every finite input, ties and denormals included"""
+    from efficient_tts_amd import lib as L, ops as P
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    bits = torch.randint(-2 ** 31, 2 ** 31, (1 << 22,), generator=g, dtype=torch.int64).to(torch.int32)
+    hi16 = torch.arange(0, 1 << 16, dtype=torch.int64)
+    ties = torch.cat([(hi16 << 16) | 0x8000, (hi16 << 16) | 0x7fff, (hi16 << 16) | 0x8001, hi16 << 16])      # exact ties and their neighbours
+    ties = torch.where(ties >= 2 ** 31, ties - 2 ** 32, ties).to(torch.int32)
+    x = torch.cat([bits, ties]).view(torch.float32)
+    x = x[torch.isfinite(x)].contiguous().to(dev)
+    n = x.numel()
+    y0 = torch.empty(n, dtype=torch.int16, device=dev)
+    y1 = torch.empty(n, dtype=torch.int16, device=dev)
+    lib = L.load()
+    L.check(lib.efts_bf16_round(x.data_ptr(), y0.data_ptr(), n, 0, P._stream()), "efts_bf16_round")
+    L.check(lib.efts_bf16_round(x.data_ptr(), y1.data_ptr(), n, 1, P._stream()), "efts_bf16_round")
+    torch.cuda.synchronize()
+    want = x.to(torch.bfloat16).view(torch.int16)
+    big = x.abs() >= 2.0 ** -126                                  # normal numbers
+    assert torch.equal(y1[big], want[big])
+    bad = (y0 != y1)
+    assert int(bad.sum()) == 0, f"{int(bad.sum())} of {n} differ, e.g. {x[bad][:4].tolist()}"
