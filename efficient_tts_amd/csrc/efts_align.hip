@@ -17,7 +17,7 @@
 #include <math.h>
 #include <stdint.h>
 
-#include "efts_mma.h"
+#include "efts_rowsweep.h"
 
 namespace efts {
 
@@ -149,19 +149,6 @@ struct ExArgs {
     float sigma;
 };
 
-__device__ __forceinline__ void gstore_b128(void* p, u32x4 v) {
-    *(u32x4*)p = v;
-    asm volatile("s_nop 4" ::"v"(v));          // keeps the data registers untouched behind the wide store (efts_mma.h store_b128)
-}
-
-__device__ __forceinline__ void split8(const float* f, u32x4* hi, u32x4* lo) {
-    float r[8], d0, d1;
-    *hi = u32x4{pack_bf16x2(f[0], f[1], &r[0], &r[1]), pack_bf16x2(f[2], f[3], &r[2], &r[3]),
-                pack_bf16x2(f[4], f[5], &r[4], &r[5]), pack_bf16x2(f[6], f[7], &r[6], &r[7])};
-    *lo = u32x4{pack_bf16x2(r[0], r[1], &d0, &d1), pack_bf16x2(r[2], r[3], &d0, &d1),
-                pack_bf16x2(r[4], r[5], &d0, &d1), pack_bf16x2(r[6], r[7], &d0, &d1)};
-}
-
 // One workgroup = one item b x one slice of 32 * NCB channels, 8 waves; wave w takes the 32-frame blocks w, w + 8, ...
 // KS = 16-key slices held per frame (T1 <= 16 KS).  LDS: V fragments [KS][NCB][hi, lo][64 lanes][16 B] (the MFMA B operand
 // in the order the lanes read it), 8 KiB of wave-private staging per wave, e[b, :].
@@ -282,57 +269,12 @@ __global__ __launch_bounds__(512, 2) void expand_kernel(ExArgs p) {
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[cb], acc[cb], 0, 0, 0);
         }
-        // ---- epilogue: 64 channels at a time through the wave's 8 KiB ([32 frames][64 channels] fp32, 16-byte slots XORed
-        // with (row >> 1) & 1), swept out 8 frames per pass with 8 lanes per frame: whole 128-byte lines per store instruction.
-        // Frames >= mel_len hold exact zeros (alpha' = 0), frames >= T2 are not stored.
+        // ---- epilogue (efts_rowsweep.h): 64 channels at a time through the wave's 8 KiB, whole 128-byte lines per store
+        // instruction.  Frames >= mel_len hold exact zeros (alpha' = 0), frames >= T2 are not stored.
+        const RowOut o{p.y_f32, p.y, p.y_lo, p.ldo, p.ldy, p.y_split};
 #pragma unroll
-        for (int hp = 0; hp < NCB / 2; ++hp) {
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rl = (r & 3) + 8 * (r >> 2) + 4 * lhalf, col = jj * 32 + lrow;
-                    *(float*)(st + rl * 256 + (((col >> 2) ^ ((rl >> 1) & 1)) << 4) + (col & 3) * 4) = acc[2 * hp + jj][r];
-                }
-#pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int row = pass * 8 + (lane >> 3), c8 = lane & 7, sw = (row >> 1) & 1;
-                const int jr = rb * 32 + row;
-                const long orow = (long)b * p.T2p + jr;
-                const int col = c0 + hp * 64 + c8 * 8;
-                if (p.y_f32 || (p.y && p.y_split == 1)) {
-                    const float4 d0 = *(const float4*)(st + row * 256 + (((2 * c8) ^ sw) << 4));
-                    const float4 d1 = *(const float4*)(st + row * 256 + (((2 * c8 + 1) ^ sw) << 4));
-                    if (jr < p.T2) {
-                        if (p.y_f32) {
-                            gstore_b128(p.y_f32 + orow * p.ldo + col, __builtin_bit_cast(u32x4, d0));
-                            gstore_b128(p.y_f32 + orow * p.ldo + col + 4, __builtin_bit_cast(u32x4, d1));
-                        }
-                        if (p.y && p.y_split == 1) {
-                            const float f[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-                            u32x4 hi, lo;
-                            split8(f, &hi, &lo);
-                            gstore_b128(p.y + orow * p.ldy + (long)col * 2, hi);
-                            if (p.y_lo) gstore_b128(p.y_lo + orow * p.ldy + (long)col * 2, lo);
-                        }
-                    }
-                }
-                if (p.y && p.y_split == 2) {
-                    // [32 hi | 32 lo] chunks: lanes 0-3 of a frame write the hi slots, lanes 4-7 the lo slots of the same 32 channels
-#pragma unroll
-                    for (int ch = 0; ch < 2; ++ch) {
-                        const int s0 = ch * 8 + 2 * (c8 & 3);
-                        const float4 d0 = *(const float4*)(st + row * 256 + ((s0 ^ sw) << 4));
-                        const float4 d1 = *(const float4*)(st + row * 256 + (((s0 + 1) ^ sw) << 4));
-                        const float f[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-                        u32x4 hi, lo;
-                        split8(f, &hi, &lo);
-                        if (jr < p.T2)
-                            gstore_b128(p.y + orow * p.ldy + (long)(((c0 + hp * 64) >> 5) + ch) * 128 + c8 * 16, c8 < 4 ? hi : lo);
-                    }
-                }
-            }
-        }
+        for (int hp = 0; hp < NCB / 2; ++hp)
+            sweep64<false>(acc[2 * hp], acc[2 * hp + 1], st, lane, o, (long)b * p.T2p + rb * 32, p.T2 - rb * 32, c0 + hp * 64, 0.f, 0.f, 0, 0.f);
     }
 }
 

@@ -313,8 +313,13 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int h
             for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
-    // ---- epilogue, wave-private: staging = this wave's 4 KiB of the ring slot the last step read
-    char* st = smem + RC_RING + (ws == 0 ? 2 : ws - 1) * RC_W_BYTES + wave * 4096;
+    // ---- epilogue, wave-private, 64 columns at a time: the wave's two 32 x 32 accumulator blocks of a block row are staged in
+    // 2 x 4 KiB of LDS that is free between two tiles -- its share of the ring slot the last step read (block j = 0) and of the
+    // window buffer the last chunk used (block j = 1); the other window buffer and the other two ring slots already hold the next
+    // tile's first operands -- and swept out 8 rows per pass with 8 lanes per row: every buffer instruction moves whole 128-byte
+    // lines of the separate hi / lo planes (64-byte segments of the [32 hi | 32 lo] chunks of a split-2 plane).
+    char* const st0 = smem + RC_RING + (ws == 0 ? 2 : ws - 1) * RC_W_BYTES + wave * 4096;
+    char* const st1 = smem + ((c.wpar ^ 1) & 1) * RC_WIN_BYTES + wave * 4096;       // c.wpar now names the NEXT tile's chunk-0 buffer
     const __amdgpu_buffer_rsrc_t r_a = make_rsrc(p.a + (long)m0 * p.lda, (long)rows_out * p.lda);
     const __amdgpu_buffer_rsrc_t r_al = make_rsrc(p.a_lo ? p.a_lo + (long)m0 * p.lda : nullptr, p.a_lo ? (long)rows_out * p.lda : 0);
     const __amdgpu_buffer_rsrc_t r_x = make_rsrc(p.resid ? p.resid + (long)m0 * p.ldr : nullptr, p.resid ? (long)rows_out * p.ldr * 4 : 0);
@@ -324,104 +329,105 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int h
     const __amdgpu_buffer_rsrc_t r_ol = make_rsrc(p.ob_lo ? p.ob_lo + (long)m0 * p.ldob : nullptr, p.ob_lo ? (long)rows_out * p.ldob : 0);
     const bool res_f32 = p.resid != nullptr;
     const bool has_mask = p.rowmask != nullptr && !(RC_EXP & 8);
-    const int srow = lane >> 2;                       // row of the 16-row sweep this lane handles
-    const int sc8 = (lane & 3) * 8;                   // first of its 8 columns inside the 32-column block
+    const int srow = lane >> 3;                       // row of the 8-row pass this lane handles
+    const int c8 = lane & 7;                          // its 8 columns inside the 64-column pair of blocks
+    const char* const stl = (c8 < 4 ? st0 : st1);     // the block those columns were staged in
 
-    // Addressing: one per-lane byte offset per stream (this lane's row of the sweep, its 8 columns); the block row
-    // (i, it) and the block column j go into the scalar offset of the buffer instruction.
-    const unsigned lrow0 = row0w + srow;                           // tile row of this lane in sweep (i = 0, it = 0)
-    const unsigned col0 = c.n0 + wn * 64 + sc8;                    // its first column in block j = 0
+    // Addressing: one per-lane byte offset per stream (this lane's row of the pass, its 8 columns); the block row i and the pass
+    // go into the scalar offset of the buffer instruction.
+    const unsigned lrow0 = row0w + srow;                           // tile row of this lane in pass (i = 0, pass = 0)
+    const unsigned col0 = c.n0 + wn * 64 + c8 * 8;                 // its first column
     const unsigned vx = res_f32 ? lrow0 * (unsigned)p.ldr * 4 + col0 * 4
                                 : lrow0 * (unsigned)p.lda + (SPLIT == 1 ? col0 * 2 : (col0 >> 5) * 128 + (col0 & 31) * 2);
     const unsigned sx_row = res_f32 ? (unsigned)p.ldr * 4 : (unsigned)p.lda;       // bytes per row
-    const unsigned sx_j = res_f32 ? 128u : (SPLIT == 1 ? 64u : 128u);              // bytes per 32-column block
     const unsigned vm = lrow0 * 4;
     const unsigned vof = lrow0 * (unsigned)p.ldo * 4 + col0 * 4, sof_row = (unsigned)p.ldo * 4;
     const unsigned vob = lrow0 * (unsigned)p.ldob + (p.out_split == 1 ? col0 * 2 : (col0 >> 5) * 128 + (col0 & 31) * 2);
-    const unsigned sob_row = (unsigned)p.ldob, sob_j = p.out_split == 1 ? 64u : 128u;
+    const unsigned sob_row = (unsigned)p.ldob;
 
-    // operands of pass (i, j), sweep it: 8 residual values (fp32, or bf16 hi + lo) and the row mask
-    constexpr int PF = 1;                                    // passes in flight ahead of the one being written out (2, 3: no gain measured)
-    u32x4 xa[PF + 1][2], xb[PF + 1][2];
-    float rmv[PF + 1][2];
-    auto request = [&](int i, int j, int b) {
+    // operands of unit u = (block row i = u >> 1, half hf = u & 1): two 8-row passes -- 8 residual values (fp32, or bf16 hi + lo)
+    // and the row mask each; one unit is in flight ahead of the one being written out
+    u32x4 xa[2][2], xb[2][2];
+    float rmv[2][2];
+    auto request = [&](int u, int bsel) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const unsigned so = (i * 32 + it * 16) * sx_row + j * sx_j;
-            if (RC_EXP & 8) { xa[b][it] = u32x4{0, 0, 0, 0}; xb[b][it] = xa[b][it]; }
+        for (int pp = 0; pp < 2; ++pp) {
+            const unsigned rofs = (u >> 1) * 32 + ((u & 1) * 2 + pp) * 8;
+            const unsigned so = rofs * sx_row;
+            if (RC_EXP & 8) { xa[bsel][pp] = u32x4{0, 0, 0, 0}; xb[bsel][pp] = xa[bsel][pp]; }
             else if (res_f32) {
-                xa[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_x, vx, so, 0);
-                xb[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_x, vx, so + 16, 0);
+                xa[bsel][pp] = __builtin_amdgcn_raw_buffer_load_b128(r_x, vx, so, 0);
+                xb[bsel][pp] = __builtin_amdgcn_raw_buffer_load_b128(r_x, vx, so + 16, 0);
             } else if (SPLIT == 1) {
-                xa[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_a, vx, so, 0);
-                xb[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_al, vx, so, 0);      // null plane: zeros
+                xa[bsel][pp] = __builtin_amdgcn_raw_buffer_load_b128(r_a, vx, so, 0);
+                xb[bsel][pp] = __builtin_amdgcn_raw_buffer_load_b128(r_al, vx, so, 0);      // null plane: zeros
             } else {
-                xa[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_a, vx, so, 0);
-                xb[b][it] = __builtin_amdgcn_raw_buffer_load_b128(r_a, vx, so + 64, 0);
+                xa[bsel][pp] = __builtin_amdgcn_raw_buffer_load_b128(r_a, vx, so, 0);
+                xb[bsel][pp] = __builtin_amdgcn_raw_buffer_load_b128(r_a, vx, so + 64, 0);
             }
-            rmv[b][it] = has_mask ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_m, vm, (i * 32 + it * 16) * 4, 0)) : 1.f;
+            rmv[bsel][pp] = has_mask ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_m, vm, rofs * 4, 0)) : 1.f;
         }
     };
-#pragma unroll
-    for (int q = 0; q < PF; ++q) request(q >> 1, q & 1, q % (PF + 1));
+    request(0, 0);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
+        // accumulator blocks -> LDS.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+        // 16-byte slots of a row are XORed with (row >> 1) & 1: the row-major read-back is bank-conflict free
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int b = (i * 2 + j) % (PF + 1);
-            if (i * 2 + j + PF < NI * 2) request((i * 2 + j + PF) >> 1, (i * 2 + j + PF) & 1, (i * 2 + j + PF) % (PF + 1));
-            // accumulator block -> LDS.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-            // 16-byte slots of a row are XORed with (row >> 1) & 1: the row-major read-back is bank-conflict free
+            char* const stj = j ? st1 : st0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
                 float v = acc[i][j][r] + c.bv[j];
                 v = v > 0.f ? v : v * p.slope;
-                *(float*)(st + rl * 128 + ((((lrow >> 2) ^ ((rl >> 1) & 1))) << 4) + (lrow & 3) * 4) = v;
+                *(float*)(stj + rl * 128 + ((((lrow >> 2) ^ ((rl >> 1) & 1))) << 4) + (lrow & 3) * 4) = v;
             }
+        }
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int row = it * 16 + srow;
-                const int sw = (row >> 1) & 1;
-                const float4 d0 = *(const float4*)(st + row * 128 + ((((lane & 3) * 2) ^ sw) << 4));
-                const float4 d1 = *(const float4*)(st + row * 128 + ((((lane & 3) * 2 + 1) ^ sw) << 4));
-                float x[8];
-                const u32x4 qa = xa[b][it], qb = xb[b][it];
-                if (res_f32) {
-                    x[0] = __uint_as_float(qa.x); x[1] = __uint_as_float(qa.y); x[2] = __uint_as_float(qa.z); x[3] = __uint_as_float(qa.w);
-                    x[4] = __uint_as_float(qb.x); x[5] = __uint_as_float(qb.y); x[6] = __uint_as_float(qb.z); x[7] = __uint_as_float(qb.w);
-                } else {
-                    const unsigned ha[4] = {qa.x, qa.y, qa.z, qa.w}, lo[4] = {qb.x, qb.y, qb.z, qb.w};
+        for (int ps = 0; ps < 4; ++ps) {
+            const int u = 2 * i + (ps >> 1), bsel = u & 1, pp = ps & 1;
+            if (pp == 0 && u + 1 < 2 * NI) request(u + 1, bsel ^ 1);
+            const int row = ps * 8 + srow;
+            const int sw = (row >> 1) & 1;
+            const float4 d0 = *(const float4*)(stl + row * 128 + ((((c8 & 3) * 2) ^ sw) << 4));
+            const float4 d1 = *(const float4*)(stl + row * 128 + ((((c8 & 3) * 2 + 1) ^ sw) << 4));
+            float x[8];
+            const u32x4 qa = xa[bsel][pp], qb = xb[bsel][pp];
+            if (res_f32) {
+                x[0] = __uint_as_float(qa.x); x[1] = __uint_as_float(qa.y); x[2] = __uint_as_float(qa.z); x[3] = __uint_as_float(qa.w);
+                x[4] = __uint_as_float(qb.x); x[5] = __uint_as_float(qb.y); x[6] = __uint_as_float(qb.z); x[7] = __uint_as_float(qb.w);
+            } else {
+                const unsigned ha[4] = {qa.x, qa.y, qa.z, qa.w}, lo[4] = {qb.x, qb.y, qb.z, qb.w};
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        x[2 * u] = __uint_as_float(ha[u] << 16) + __uint_as_float(lo[u] << 16);
-                        x[2 * u + 1] = __uint_as_float(ha[u] & 0xffff0000u) + __uint_as_float(lo[u] & 0xffff0000u);
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    x[2 * u] = __uint_as_float(ha[u] << 16) + __uint_as_float(lo[u] << 16);
+                    x[2 * u + 1] = __uint_as_float(ha[u] & 0xffff0000u) + __uint_as_float(lo[u] & 0xffff0000u);
                 }
-                const float rm = rmv[b][it];
-                float y[8] = {(x[0] + d0.x) * rm, (x[1] + d0.y) * rm, (x[2] + d0.z) * rm, (x[3] + d0.w) * rm,
-                              (x[4] + d1.x) * rm, (x[5] + d1.y) * rm, (x[6] + d1.z) * rm, (x[7] + d1.w) * rm};
-                const unsigned brow = i * 32 + it * 16;
-                if ((int)(lrow0 + brow) >= rows_out) continue;
-                if (RC_EXP & 8) { asm volatile("" ::"v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7])); continue; }      // rows of the next tile / past the matrix (the descriptors clip them too)
-                if (p.out_f32) {
-                    const u32x4 o0 = {__float_as_uint(y[0]), __float_as_uint(y[1]), __float_as_uint(y[2]), __float_as_uint(y[3])};
-                    const u32x4 o1 = {__float_as_uint(y[4]), __float_as_uint(y[5]), __float_as_uint(y[6]), __float_as_uint(y[7])};
-                    store_b128(o0, r_of, vof, brow * sof_row + j * 128);             // constant displacements go into the scalar
-                    store_b128(o1, r_of, vof, brow * sof_row + j * 128 + 16);        // offset: no VALU address math between stores
-                }
-                if (p.ob) {
-                    float rr[8];
-                    const u32x4 hi = {pack_bf16x2(y[0], y[1], &rr[0], &rr[1]), pack_bf16x2(y[2], y[3], &rr[2], &rr[3]),
-                                      pack_bf16x2(y[4], y[5], &rr[4], &rr[5]), pack_bf16x2(y[6], y[7], &rr[6], &rr[7])};
-                    float d0_, d1_;
-                    const u32x4 lo = {pack_bf16x2(rr[0], rr[1], &d0_, &d1_), pack_bf16x2(rr[2], rr[3], &d0_, &d1_),
-                                      pack_bf16x2(rr[4], rr[5], &d0_, &d1_), pack_bf16x2(rr[6], rr[7], &d0_, &d1_)};
-                    const unsigned so = brow * sob_row + j * sob_j;
-                    store_b128(hi, r_ob, vob, so);
-                    if (p.out_split == 2) store_b128(lo, r_ob, vob, so + 64);
-                    else if (p.ob_lo) store_b128(lo, r_ol, vob, so);
-                }
+            }
+            const float rm = rmv[bsel][pp];
+            float y[8] = {(x[0] + d0.x) * rm, (x[1] + d0.y) * rm, (x[2] + d0.z) * rm, (x[3] + d0.w) * rm,
+                          (x[4] + d1.x) * rm, (x[5] + d1.y) * rm, (x[6] + d1.z) * rm, (x[7] + d1.w) * rm};
+            const unsigned brow = i * 32 + ps * 8;
+            if ((int)(lrow0 + brow) >= rows_out) continue;      // rows of the next tile / past the matrix (the descriptors clip them too)
+            if (RC_EXP & 8) { asm volatile("" ::"v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7])); continue; }
+            if (p.out_f32) {
+                const u32x4 o0 = {__float_as_uint(y[0]), __float_as_uint(y[1]), __float_as_uint(y[2]), __float_as_uint(y[3])};
+                const u32x4 o1 = {__float_as_uint(y[4]), __float_as_uint(y[5]), __float_as_uint(y[6]), __float_as_uint(y[7])};
+                store_b128(o0, r_of, vof, brow * sof_row);               // constant displacements go into the scalar
+                store_b128(o1, r_of, vof, brow * sof_row + 16);          // offset: no VALU address math between stores
+            }
+            if (p.ob) {
+                float rr[8];
+                const u32x4 hi = {pack_bf16x2(y[0], y[1], &rr[0], &rr[1]), pack_bf16x2(y[2], y[3], &rr[2], &rr[3]),
+                                  pack_bf16x2(y[4], y[5], &rr[4], &rr[5]), pack_bf16x2(y[6], y[7], &rr[6], &rr[7])};
+                float d0_, d1_;
+                const u32x4 lo = {pack_bf16x2(rr[0], rr[1], &d0_, &d1_), pack_bf16x2(rr[2], rr[3], &d0_, &d1_),
+                                  pack_bf16x2(rr[4], rr[5], &d0_, &d1_), pack_bf16x2(rr[6], rr[7], &d0_, &d1_)};
+                const unsigned so = brow * sob_row;
+                store_b128(hi, r_ob, vob, so);
+                if (p.out_split == 2) store_b128(lo, r_ob, vob, so + 64);
+                else if (p.ob_lo) store_b128(lo, r_ol, vob, so);
             }
         }
     }

@@ -194,7 +194,7 @@ class EfficientTTSCNN(torch.nn.Module):
         self.decoder = _ResConvBlock(n_decoder_layer, n_channels, k_size, a, ap, dropout_rate, use_weight_norm)
         self.mel_output_layer = torch.nn.Linear(n_channels, odim)
         self.duration_predictor = _DurationPredictor(n_channels, n_duration_layer, n_channels, offset=duration_offset)
-        self.fuse_prenet = True             # bf16 mode: the prenet straight from the fp32 frames (efts_frame_linear); False: efts_pack_rows + efts_gemm
+        self.fuse_prenet = True             # the prenet straight from the fp32 frames (efts_frame_linear); False: efts_pack_rows + efts_gemm
         self.fuse_soft_index = True         # T1 <= 128: q.k^T, softmax and soft index in one launch (False: scores stored, efts_attn_soft_index)
         self.fuse_align = True              # imv scan + aligned positions + duration target in one launch (efts_imv_align)
         self.fuse_expand = True             # T1 <= 256: alpha' generated in registers inside the expand contraction (efts_expand); False: reconst_alpha + pack_vt + efts_gemm
@@ -445,10 +445,13 @@ class EfficientTTSCNN(torch.nn.Module):
                    out_f32_ptr=None if h_f is None else h_f.ptr, ldo=C, out_batch_stride=rs2.Tp * C, out_plane=h_p,
                    outb_batch_stride=rs2.Tp * h_p.ld, out_plane_lo=h_l)
         _, d_p = self._res_stack(ws, "dec", "decoder", pk, rs2, h_f, h_p, gap2.data_ptr(), self.split, False, x_lo=h_l)
-        mel = ws.f32("mel_pred", rs2, self.odim)
+        # mel head (:198-200), written straight into the [B, T2, odim] tensor the caller gets (one item per batch entry of the
+        # launch: no row-space copy of mel_pred, no clone)
+        mel = torch.empty(B, rs2.T, self.odim, dtype=torch.float32, device=h_p.buf.device)
         wh = pk["head"]
-        O.gemm(a=d_p, b_ptr=wh.ptr, ldb=wh.ld, m=rs2.rows, n=self.odim, bias=self.mel_output_layer.bias,
-               rowmask_ptr=len2_ptr if len2_ptr is not None else gap2.data_ptr(), out_f32_ptr=mel.ptr, ldo=self.odim)
+        O.gemm(a=d_p, b_ptr=wh.ptr, ldb=wh.ld, m=rs2.T, n=self.odim, batch=B, a_batch_stride=rs2.Tp * d_p.ld, bias=self.mel_output_layer.bias,
+               rowmask_ptr=len2_ptr if len2_ptr is not None else gap2.data_ptr(), rowmask_batch_stride=rs2.Tp,
+               out_f32_ptr=mel.data_ptr(), ldo=self.odim, out_batch_stride=rs2.T * self.odim)
         return mel
 
     def _require(self, t: torch.Tensor):
@@ -523,9 +526,8 @@ class EfficientTTSCNN(torch.nn.Module):
             dur = self._duration(ws, pk, rs1, val_p, gap1, len1.data_ptr(), 0)    # :219
         pre_f, pre_p, pre_l = self._stream_in(ws, "pre", rs2)                     # :161 prenet
         wp = pk["prenet"]
-        if self.fuse_prenet and self.split == 1 and self.odim % 8 == 0 and self.odim <= 128 and C % 256 == 0:
-            # straight from the caller's fp32 frames: no operand plane of the mel input, one launch (bit-identical on every frame).
-            # bf16 planes only: with hi / lo weights (96 KiB of LDS, one workgroup per CU) the forward measured 0.6 % slower
+        if self.fuse_prenet and self.odim % 8 == 0 and self.odim <= 128 and C % 128 == 0:
+            # straight from the caller's fp32 frames: no operand plane of the mel input, one launch (bit-identical on every frame)
             O.frame_linear(x=speech, w=wp, bias=self.mel_prenet[0].bias, act=L.ACT_LEAKY, slope=self.slope, rs=rs2,
                            y=pre_p, y_lo=pre_l, y_f32=pre_f)
         else:
@@ -577,9 +579,9 @@ class EfficientTTSCNN(torch.nn.Module):
         # (mel_pred, dur_pred and log_delta_e are zero beyond each item's length, speech is whatever the caller padded with)
         ml_loss = ml if self.use_masking else torch.full_like(ml, T2)
         tl_loss = tl if self.use_masking else torch.full_like(tl, T1)
-        O.masked_losses(mel.ptr, self.odim, speech, ml_loss, dur, lde, tl_loss, out3, ws.tensor("loss_ws", (1024,)), B, T1,
-                        rs1.Tp, T2, rs2.Tp, self.odim)
-        mel_pred = mel.view().clone()
+        O.masked_losses(mel.data_ptr(), self.odim, speech, ml_loss, dur, lde, tl_loss, out3, ws.tensor("loss_ws", (1024,)), B, T1,
+                        rs1.Tp, T2, T2, self.odim)
+        mel_pred = mel
         ret = (out3[0], LazyStats(out3), imv, ralpha, mel_pred, speech)
         extra = dict(e=e, log_delta_e=lde, dur_pred=dur.view(B, rs1.Tp)[:, :T1], ws=ws) if keep else None
         return ret, extra
@@ -621,7 +623,7 @@ class EfficientTTSCNN(torch.nn.Module):
         O.row_masks(torch.full((1,), t2, dtype=torch.int32, device=dev), rs2, gap2, None)
         ralpha = torch.empty(1, T1, t2, dtype=torch.float32, device=dev)
         mel = self._expand_decode(ws2, pk, 1, T1, rs1, rs2, val_f, e, None, None, ralpha, None, gap2)   # :270-284
-        return mel.view().clone(), ralpha
+        return mel, ralpha
 
     # ------------------------------------------------------------------ batched ragged inference (extension)
     T1_BUCKET, T2_BUCKET = 16, 64       # free-running inference runs on shapes rounded up to these multiples (graph / workspace reuse)
@@ -673,7 +675,7 @@ class EfficientTTSCNN(torch.nn.Module):
         O.row_masks(ml, rs2, gap2, len2)
         ralpha = torch.empty(B, T1, T2, dtype=torch.float32, device=dev)
         mel = self._expand_decode(ws2, pk, B, T1, rs1, rs2, val_f, e, tl, ml, ralpha, len2.data_ptr(), len2)
-        return mel.view().clone(), ralpha
+        return mel, ralpha
 
     @torch.no_grad()
     def inference_batch(self, text: torch.Tensor, text_lengths: torch.Tensor, force_delta: Optional[float] = None):

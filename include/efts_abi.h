@@ -189,7 +189,7 @@ int efts_resconv5(const efts_resconv5_args* a, void* stream);
 /* A Linear with few input features applied to the caller's fp32 frames, written into the row space:
  *   y[b * Tp + t, :] = act(x[b][t][:cin] . W^T + bias), t < T (rows t >= T of the row space are not touched: they stay zero)
  * -- `mel_prenet` of the reference (nntts/models/efficient_tts.py:76-80, applied at :161; eval / Dropout-free) in one launch,
- * without an operand plane of the input.  Bit-identical to efts_pack_rows + efts_gemm.  cin % 8 == 0, cin <= 128, n % 256 == 0. */
+ * without an operand plane of the input.  Bit-identical to efts_pack_rows + efts_gemm.  cin % 8 == 0, cin <= 128, n % 128 == 0. */
 typedef struct efts_frame_linear_args {
     const float* x;      /* [B][T][cin] fp32, contiguous, 16-byte aligned */
     const void* w;       /* packed B plane [n][ldw] (efts_pack_weight, one tap) of format `split` */
