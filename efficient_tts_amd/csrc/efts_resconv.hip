@@ -61,7 +61,8 @@ struct RcSched {
     unsigned char ni[RC_MAXCLS][RC_MAXTILES];   // tile heights in half units of 32 window rows, 2..8 (a tile yields 32 * h - 4 rows)
 };
 
-struct RcArgs {
+// one residual layer (a "problem" of a launch): every pointer and stride that differs between the layers of a grouped launch
+struct RcProb {
     const char* a;          // operand plane of x (split 1: bf16 hi; split 2: [32 hi | 32 lo] chunks), row 0
     const char* a_lo;       // split 1: lo plane of x (same layout) or null
     const float* resid;     // fp32 x (takes precedence over the planes as the residual) or null
@@ -72,9 +73,21 @@ struct RcArgs {
     char* ob;
     char* ob_lo;
     long lda, ldw, w_tap_stride, ldr, ldo, ldob;
-    int m, nchunk, ntn;
-    float slope;
+    int m;                  // rows of this layer
     int out_split;
+    float slope;
+    int pad_;
+};
+
+constexpr int RC_MAXPROB = 2;
+
+// A launch covers the rows of up to RC_MAXPROB layers laid end to end ("virtual rows": layer 0 first); the schedule cuts the
+// virtual rows into groups and tiles, and a tile never crosses from one layer into the next.
+struct RcArgs {
+    RcProb pr[RC_MAXPROB];
+    int nprob;
+    int m;                  // virtual rows = sum of pr[i].m
+    int nchunk, ntn;
     RcSched s;
     unsigned long long* stamp;
 };
@@ -98,7 +111,9 @@ struct RcCtx {
     int lane, wave, wm, wn, lrow, lhalf;
     int n0;
     unsigned vow[4];        // per-lane source offsets of this wave's 4 weight pieces (fixed per workgroup)
-    const char* w_base;
+    const char* w_base;       // weights of the current tile's layer, this workgroup's columns
+    const char* w_next;       // ... of the next tile's layer (the weight requests two steps ahead wrap into the next tile)
+    long wts, wts_next;       // tap strides of the two
     float bv[2];            // bias of this lane's two accumulator columns
     int ws;                 // ring slot of the next step
     int wpar;               // window buffer of the next tile's chunk 0
@@ -117,7 +132,7 @@ __device__ __forceinline__ int rc_pieces(int h, int wave) { return (4 * h - wave
 // (rows m1, height h1; 0 = no next tile) is requested at the first tap of this tile's last chunk.  On entry the window of
 // chunk 0 and the weights of steps 0 and 1 are therefore in flight or landed.
 template <int SPLIT, int NI>
-__device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int h, int rows_out, int m1, int h1) {
+__device__ __forceinline__ void rc_tile(const RcArgs& p, const RcProb& pq, const RcProb& pn, RcCtx& c, int m0, int h, int rows_out, int m1, int h1) {
     constexpr int TAPS = 5;
     char* const smem = c.smem;
     const int lane = c.lane, wave = c.wave, lrow = c.lrow, lhalf = c.lhalf, wm = c.wm, wn = c.wn;
@@ -126,15 +141,15 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int h
 
     unsigned voa[4];
     {
-        const int rmax = p.m + 143 - (m0 - 2);
+        const int rmax = pq.m + 143 - (m0 - 2);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = (q * 8 + wave) * 8 + (lane >> 3);
             const int sl = (lane & 7) ^ ((r >> 1) & 7);
-            voa[q] = (unsigned)((r < rmax ? r : rmax) * (int)p.lda + (sl << 4));
+            voa[q] = (unsigned)((r < rmax ? r : rmax) * (int)pq.lda + (sl << 4));
         }
     }
-    const char* a_base = p.a + (long)(m0 - 2) * p.lda;
+    const char* a_base = pq.a + (long)(m0 - 2) * pq.lda;
     auto issue_a = [&](int cn, int buf) {
         const char* sb = a_base + (long)cn * 128;
         const unsigned l = c.lds0 + buf * RC_WIN_BYTES + wave * 1024;
@@ -143,13 +158,13 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int h
             if (q < nq) dma16(l + q * 8192, voa[q], sb);
     };
     auto issue_a_next = [&](int buf) {                     // chunk 0 of the next tile (its own height and rows)
-        const int rmax = p.m + 143 - (m1 - 2);
-        const char* sb = p.a + (long)(m1 - 2) * p.lda;
+        const int rmax = pn.m + 143 - (m1 - 2);
+        const char* sb = pn.a + (long)(m1 - 2) * pn.lda;
         const unsigned l = c.lds0 + buf * RC_WIN_BYTES + wave * 1024;
         for (int q = 0; q < nq1; ++q) {
             const int r = (q * 8 + wave) * 8 + (lane >> 3);
             const int sl = (lane & 7) ^ ((r >> 1) & 7);
-            dma16(l + q * 8192, (unsigned)((r < rmax ? r : rmax) * (int)p.lda + (sl << 4)), sb);
+            dma16(l + q * 8192, (unsigned)((r < rmax ? r : rmax) * (int)pn.lda + (sl << 4)), sb);
         }
     };
 
@@ -260,7 +275,8 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int h
             const int kn = (k + 2) % TAPS;
             int cn = ch + (k + 2) / TAPS;
             cn = cn == p.nchunk ? 0 : cn;
-            const char* wsrc = c.w_base + (long)kn * p.w_tap_stride + (long)cn * 128;
+            const bool into_next = lastc && (k + 2) / TAPS == 1;          // the last two steps request the NEXT tile's steps 0 and 1
+            const char* wsrc = (into_next ? c.w_next + (long)kn * c.wts_next : c.w_base + (long)kn * c.wts) + (long)cn * 128;
             const unsigned wdst = c.lds0 + RC_RING + (ws == 0 ? 2 : ws - 1) * RC_W_BYTES + wave * 1024;
             int nwin = 0;
             auto window = [&]() {                          // next window into the idle buffer: next chunk, or the next tile's chunk 0
@@ -320,15 +336,15 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int h
     // lines of the separate hi / lo planes (64-byte segments of the [32 hi | 32 lo] chunks of a split-2 plane).
     char* const st0 = smem + RC_RING + (ws == 0 ? 2 : ws - 1) * RC_W_BYTES + wave * 4096;
     char* const st1 = smem + ((c.wpar ^ 1) & 1) * RC_WIN_BYTES + wave * 4096;       // c.wpar now names the NEXT tile's chunk-0 buffer
-    const __amdgpu_buffer_rsrc_t r_a = make_rsrc(p.a + (long)m0 * p.lda, (long)rows_out * p.lda);
-    const __amdgpu_buffer_rsrc_t r_al = make_rsrc(p.a_lo ? p.a_lo + (long)m0 * p.lda : nullptr, p.a_lo ? (long)rows_out * p.lda : 0);
-    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(p.resid ? p.resid + (long)m0 * p.ldr : nullptr, p.resid ? (long)rows_out * p.ldr * 4 : 0);
-    const __amdgpu_buffer_rsrc_t r_m = make_rsrc(p.rowmask ? p.rowmask + m0 : nullptr, p.rowmask ? (long)rows_out * 4 : 0);
-    const __amdgpu_buffer_rsrc_t r_of = make_rsrc(p.out_f32 ? p.out_f32 + (long)m0 * p.ldo : nullptr, p.out_f32 ? (long)rows_out * p.ldo * 4 : 0);
-    const __amdgpu_buffer_rsrc_t r_ob = make_rsrc(p.ob ? p.ob + (long)m0 * p.ldob : nullptr, p.ob ? (long)rows_out * p.ldob : 0);
-    const __amdgpu_buffer_rsrc_t r_ol = make_rsrc(p.ob_lo ? p.ob_lo + (long)m0 * p.ldob : nullptr, p.ob_lo ? (long)rows_out * p.ldob : 0);
-    const bool res_f32 = p.resid != nullptr;
-    const bool has_mask = p.rowmask != nullptr && !(RC_EXP & 8);
+    const __amdgpu_buffer_rsrc_t r_a = make_rsrc(pq.a + (long)m0 * pq.lda, (long)rows_out * pq.lda);
+    const __amdgpu_buffer_rsrc_t r_al = make_rsrc(pq.a_lo ? pq.a_lo + (long)m0 * pq.lda : nullptr, pq.a_lo ? (long)rows_out * pq.lda : 0);
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(pq.resid ? pq.resid + (long)m0 * pq.ldr : nullptr, pq.resid ? (long)rows_out * pq.ldr * 4 : 0);
+    const __amdgpu_buffer_rsrc_t r_m = make_rsrc(pq.rowmask ? pq.rowmask + m0 : nullptr, pq.rowmask ? (long)rows_out * 4 : 0);
+    const __amdgpu_buffer_rsrc_t r_of = make_rsrc(pq.out_f32 ? pq.out_f32 + (long)m0 * pq.ldo : nullptr, pq.out_f32 ? (long)rows_out * pq.ldo * 4 : 0);
+    const __amdgpu_buffer_rsrc_t r_ob = make_rsrc(pq.ob ? pq.ob + (long)m0 * pq.ldob : nullptr, pq.ob ? (long)rows_out * pq.ldob : 0);
+    const __amdgpu_buffer_rsrc_t r_ol = make_rsrc(pq.ob_lo ? pq.ob_lo + (long)m0 * pq.ldob : nullptr, pq.ob_lo ? (long)rows_out * pq.ldob : 0);
+    const bool res_f32 = pq.resid != nullptr;
+    const bool has_mask = pq.rowmask != nullptr && !(RC_EXP & 8);
     const int srow = lane >> 3;                       // row of the 8-row pass this lane handles
     const int c8 = lane & 7;                          // its 8 columns inside the 64-column pair of blocks
     const char* const stl = (c8 < 4 ? st0 : st1);     // the block those columns were staged in
@@ -337,13 +353,13 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int h
     // go into the scalar offset of the buffer instruction.
     const unsigned lrow0 = row0w + srow;                           // tile row of this lane in pass (i = 0, pass = 0)
     const unsigned col0 = c.n0 + wn * 64 + c8 * 8;                 // its first column
-    const unsigned vx = res_f32 ? lrow0 * (unsigned)p.ldr * 4 + col0 * 4
-                                : lrow0 * (unsigned)p.lda + (SPLIT == 1 ? col0 * 2 : (col0 >> 5) * 128 + (col0 & 31) * 2);
-    const unsigned sx_row = res_f32 ? (unsigned)p.ldr * 4 : (unsigned)p.lda;       // bytes per row
+    const unsigned vx = res_f32 ? lrow0 * (unsigned)pq.ldr * 4 + col0 * 4
+                                : lrow0 * (unsigned)pq.lda + (SPLIT == 1 ? col0 * 2 : (col0 >> 5) * 128 + (col0 & 31) * 2);
+    const unsigned sx_row = res_f32 ? (unsigned)pq.ldr * 4 : (unsigned)pq.lda;       // bytes per row
     const unsigned vm = lrow0 * 4;
-    const unsigned vof = lrow0 * (unsigned)p.ldo * 4 + col0 * 4, sof_row = (unsigned)p.ldo * 4;
-    const unsigned vob = lrow0 * (unsigned)p.ldob + (p.out_split == 1 ? col0 * 2 : (col0 >> 5) * 128 + (col0 & 31) * 2);
-    const unsigned sob_row = (unsigned)p.ldob;
+    const unsigned vof = lrow0 * (unsigned)pq.ldo * 4 + col0 * 4, sof_row = (unsigned)pq.ldo * 4;
+    const unsigned vob = lrow0 * (unsigned)pq.ldob + (pq.out_split == 1 ? col0 * 2 : (col0 >> 5) * 128 + (col0 & 31) * 2);
+    const unsigned sob_row = (unsigned)pq.ldob;
 
     // operands of unit u = (block row i = u >> 1, half hf = u & 1): two 8-row passes -- 8 residual values (fp32, or bf16 hi + lo)
     // and the row mask each; one unit is in flight ahead of the one being written out
@@ -380,7 +396,7 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int h
             for (int r = 0; r < 16; ++r) {
                 const int rl = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
                 float v = acc[i][j][r] + c.bv[j];
-                v = v > 0.f ? v : v * p.slope;
+                v = v > 0.f ? v : v * pq.slope;
                 *(float*)(stj + rl * 128 + ((((lrow >> 2) ^ ((rl >> 1) & 1))) << 4) + (lrow & 3) * 4) = v;
             }
         }
@@ -411,13 +427,13 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int h
             const unsigned brow = i * 32 + ps * 8;
             if ((int)(lrow0 + brow) >= rows_out) continue;      // rows of the next tile / past the matrix (the descriptors clip them too)
             if (RC_EXP & 8) { asm volatile("" ::"v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7])); continue; }
-            if (p.out_f32) {
+            if (pq.out_f32) {
                 const u32x4 o0 = {__float_as_uint(y[0]), __float_as_uint(y[1]), __float_as_uint(y[2]), __float_as_uint(y[3])};
                 const u32x4 o1 = {__float_as_uint(y[4]), __float_as_uint(y[5]), __float_as_uint(y[6]), __float_as_uint(y[7])};
                 store_b128(o0, r_of, vof, brow * sof_row);               // constant displacements go into the scalar
                 store_b128(o1, r_of, vof, brow * sof_row + 16);          // offset: no VALU address math between stores
             }
-            if (p.ob) {
+            if (pq.ob) {
                 float rr[8];
                 const u32x4 hi = {pack_bf16x2(y[0], y[1], &rr[0], &rr[1]), pack_bf16x2(y[2], y[3], &rr[2], &rr[3]),
                                   pack_bf16x2(y[4], y[5], &rr[4], &rr[5]), pack_bf16x2(y[6], y[7], &rr[6], &rr[7])};
@@ -426,8 +442,8 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, RcCtx& c, int m0, int h
                                   pack_bf16x2(rr[4], rr[5], &d0_, &d1_), pack_bf16x2(rr[6], rr[7], &d0_, &d1_)};
                 const unsigned so = brow * sob_row;
                 store_b128(hi, r_ob, vob, so);
-                if (p.out_split == 2) store_b128(lo, r_ob, vob, so + 64);
-                else if (p.ob_lo) store_b128(lo, r_ol, vob, so);
+                if (pq.out_split == 2) store_b128(lo, r_ob, vob, so + 64);
+                else if (pq.ob_lo) store_b128(lo, r_ol, vob, so);
             }
         }
     }
@@ -460,59 +476,77 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
     const int cls = g % p.s.ncls;
     int sum_rows = 0, pre = 0;
     for (int i = 0; i < p.s.ncls; ++i) { if (i < cls) pre += p.s.rows[i]; sum_rows += p.s.rows[i]; }
-    int m0 = (g / p.s.ncls) * sum_rows + pre;
-    const int end = m0 + p.s.rows[cls] < p.m ? m0 + p.s.rows[cls] : p.m;
+    int vrow = (g / p.s.ncls) * sum_rows + pre;                       // this group's first VIRTUAL row (layer 0's rows, then layer 1's)
+    const int vend = vrow + p.s.rows[cls] < p.m ? vrow + p.s.rows[cls] : p.m;
     const int ntile = p.s.ntile[cls];
-    // height (half units) of tile t starting at row m: the scheduled one, cut to what is left of this group's rows
-    auto height = [&](int t, int m) -> int {
-        if (t >= ntile || m >= end) return 0;
-        int need = (end - m + 4 + 31) >> 5;
+    const int mfirst = p.nprob > 1 ? p.pr[0].m : p.m;                 // virtual row where layer 1 starts
+    // tile t starting at virtual row vr: its layer, its first row inside that layer, its height (half units: the scheduled one, cut
+    // to what is left of this group's rows IN THIS LAYER -- a tile never crosses into the next layer; a group cut by the layer
+    // boundary runs one tile more than scheduled) and the rows it yields
+    auto locate = [&](int t, int vr, int& pi, int& ml, int& hh, int& rows) {
+        pi = 0; ml = 0; hh = 0; rows = 0;
+        if (vr >= vend) return;
+        pi = vr >= mfirst ? 1 : 0;
+        const int lend = (pi == 0 && mfirst < vend) ? mfirst : vend;
+        int need = (lend - vr + 4 + 31) >> 5;
         need = need < 2 ? 2 : need;
-        const int hs = p.s.ni[cls][t];
-        return hs < need ? hs : need;
+        const int hs = t < ntile ? p.s.ni[cls][t] : 8;
+        hh = hs < need ? hs : need;
+        rows = lend - vr < 32 * hh - 4 ? lend - vr : 32 * hh - 4;
+        ml = vr - (pi ? mfirst : 0);
     };
-    int h = height(0, m0);
+    int pi, m0, h, rows_out;
+    locate(0, vrow, pi, m0, h, rows_out);
     if (h == 0) return;
 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int r = (q * 8 + c.wave) * 8 + (c.lane >> 3);
         const int sl = (c.lane & 7) ^ ((r >> 1) & 7);
-        c.vow[q] = (unsigned)(r * (int)p.ldw + (sl << 4));
+        c.vow[q] = (unsigned)(r * (int)p.pr[0].ldw + (sl << 4));     // (every layer of a launch has the same weight row stride)
     }
-    c.w_base = p.w + (long)c.n0 * p.ldw;
+    auto bias_of = [&](const RcProb& q) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) c.bv[j] = p.bias ? p.bias[c.n0 + c.wn * 64 + j * 32 + c.lrow] : 0.f;
-    c.ws = 0; c.wpar = 0;
-
-    // first tile: window of chunk 0, weights of steps 0 and 1
+        for (int j = 0; j < 2; ++j) c.bv[j] = q.bias ? q.bias[c.n0 + c.wn * 64 + j * 32 + c.lrow] : 0.f;
+    };
     {
-        const int rmax = p.m + 143 - (m0 - 2);
-        const char* sb = p.a + (long)(m0 - 2) * p.lda;
+        const RcProb& q0 = p.pr[pi];
+        c.w_base = q0.w + (long)c.n0 * q0.ldw;
+        c.wts = q0.w_tap_stride;
+        bias_of(q0);
+        c.ws = 0; c.wpar = 0;
+        // first tile: window of chunk 0, weights of steps 0 and 1
+        const int rmax = q0.m + 143 - (m0 - 2);
+        const char* sb = q0.a + (long)(m0 - 2) * q0.lda;
         const int nq = rc_pieces(h, c.wave);
         for (int q = 0; q < nq; ++q) {
             const int r = (q * 8 + c.wave) * 8 + (c.lane >> 3);
             const int sl = (c.lane & 7) ^ ((r >> 1) & 7);
-            dma16(c.lds0 + c.wave * 1024 + q * 8192, (unsigned)((r < rmax ? r : rmax) * (int)p.lda + (sl << 4)), sb);
+            dma16(c.lds0 + c.wave * 1024 + q * 8192, (unsigned)((r < rmax ? r : rmax) * (int)q0.lda + (sl << 4)), sb);
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                dma16(c.lds0 + RC_RING + s * RC_W_BYTES + c.wave * 1024 + q * 8192, c.vow[q], c.w_base + (long)s * p.w_tap_stride);
+                dma16(c.lds0 + RC_RING + s * RC_W_BYTES + c.wave * 1024 + q * 8192, c.vow[q], c.w_base + (long)s * c.wts);
     }
     for (int t = 0; h > 0; ++t) {
-        const int m1 = m0 + 32 * h - 4;
-        const int h1 = height(t + 1, m1);
-        const int rows_out = end - m0 < 32 * h - 4 ? end - m0 : 32 * h - 4;
+        const int vnext = vrow + rows_out;
+        int pi1, m1, h1, rows1;
+        locate(t + 1, vnext, pi1, m1, h1, rows1);
+        const RcProb& pq = p.pr[pi];
+        const RcProb& pn = p.pr[h1 > 0 ? pi1 : pi];
+        c.w_next = pn.w + (long)c.n0 * pn.ldw;
+        c.wts_next = pn.w_tap_stride;
         switch (c.wm ? h >> 1 : (h + 1) >> 1) {             // 32-row blocks of this wave's row (wave-uniform)
-            case 1: rc_tile<SPLIT, 1>(p, c, m0, h, rows_out, m1, h1); break;
-            case 2: rc_tile<SPLIT, 2>(p, c, m0, h, rows_out, m1, h1); break;
-            case 3: rc_tile<SPLIT, 3>(p, c, m0, h, rows_out, m1, h1); break;
-            default: rc_tile<SPLIT, 4>(p, c, m0, h, rows_out, m1, h1); break;
+            case 1: rc_tile<SPLIT, 1>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+            case 2: rc_tile<SPLIT, 2>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+            case 3: rc_tile<SPLIT, 3>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+            default: rc_tile<SPLIT, 4>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
         }
-        m0 = m1;
-        h = h1;
+        if (h1 > 0 && pi1 != pi) bias_of(pn);
+        c.w_base = c.w_next; c.wts = c.wts_next;
+        vrow = vnext; pi = pi1; m0 = m1; h = h1; rows_out = rows1;
     }
     // the last tile's wrapped weight requests may still be landing: LDS must not be handed to another workgroup under them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -619,35 +653,52 @@ extern "C" int efts_resconv5_plan(int32_t m, int32_t n, int32_t cus, int32_t* pl
     return RC_PLAN_INTS;
 }
 
-extern "C" int efts_resconv5(const efts_resconv5_args* a, void* stream) {
-    if (!a) return efts_fail(EFTS_EINVAL, "efts_resconv5: null args");
-    if (!(a->split == 1 || a->split == 2)) return efts_fail(EFTS_EINVAL, "efts_resconv5: split must be 1 or 2");
-    if (a->m <= 0 || a->n <= 0 || a->nchunk <= 0) return efts_fail(EFTS_ESHAPE, "efts_resconv5: m, n, nchunk must be positive");
-    if (a->n % RC_BN) return efts_fail(EFTS_ESHAPE, "efts_resconv5: n must be a multiple of 256");
-    if (!a->x || !a->w) return efts_fail(EFTS_EINVAL, "efts_resconv5: null operand");
-    if (!a->y && !a->y_f32) return efts_fail(EFTS_EINVAL, "efts_resconv5: no output");
+static int rc_check(const efts_resconv5_args* a, const char* who) {
+    if (!(a->split == 1 || a->split == 2)) return efts_fail(EFTS_EINVAL, "%s: split must be 1 or 2", who);
+    if (a->m <= 0 || a->n <= 0 || a->nchunk <= 0) return efts_fail(EFTS_ESHAPE, "%s: m, n, nchunk must be positive", who);
+    if (a->n % RC_BN) return efts_fail(EFTS_ESHAPE, "%s: n must be a multiple of 256", who);
+    if (!a->x || !a->w) return efts_fail(EFTS_EINVAL, "%s: null operand", who);
+    if (!a->y && !a->y_f32) return efts_fail(EFTS_EINVAL, "%s: no output", who);
     if (((uintptr_t)a->x & 15) || ((uintptr_t)a->x_lo & 15) || ((uintptr_t)a->w & 15) || (a->ldx & 15) || (a->ldw & 15) || (a->w_tap_stride & 15) ||
         ((uintptr_t)a->y & 15) || ((uintptr_t)a->y_lo & 15) || (a->ldy & 15) || ((uintptr_t)a->x_f32 & 15) || (a->ldr & 3) ||
         ((uintptr_t)a->y_f32 & 15) || (a->ldo & 3))
-        return efts_fail(EFTS_EALIGN, "efts_resconv5: planes and fp32 streams must be 16-byte aligned (pointers and row strides)");
+        return efts_fail(EFTS_EALIGN, "%s: planes and fp32 streams must be 16-byte aligned (pointers and row strides)", who);
     if (a->ldx < (int64_t)a->nchunk * 128 || a->ldw < (int64_t)a->nchunk * 128)
-        return efts_fail(EFTS_ESHAPE, "efts_resconv5: row stride smaller than nchunk*128 bytes");
-    if (a->ldx > (1 << 23) || a->ldw > (1 << 23)) return efts_fail(EFTS_ESHAPE, "efts_resconv5: row stride above 8 MiB");
-    if (a->y && !(a->y_split == 1 || a->y_split == 2)) return efts_fail(EFTS_EINVAL, "efts_resconv5: y_split must be 1 or 2");
-    if (a->split == 2 && a->x_lo) return efts_fail(EFTS_EINVAL, "efts_resconv5: x_lo is for split-1 planes (split 2 carries lo inside x)");
-    if (a->y_split == 2 && a->y_lo) return efts_fail(EFTS_EINVAL, "efts_resconv5: y_lo is for split-1 output planes");
+        return efts_fail(EFTS_ESHAPE, "%s: row stride smaller than nchunk*128 bytes", who);
+    if (a->ldx > (1 << 23) || a->ldw > (1 << 23)) return efts_fail(EFTS_ESHAPE, "%s: row stride above 8 MiB", who);
+    if (a->y && !(a->y_split == 1 || a->y_split == 2)) return efts_fail(EFTS_EINVAL, "%s: y_split must be 1 or 2", who);
+    if (a->split == 2 && a->x_lo) return efts_fail(EFTS_EINVAL, "%s: x_lo is for split-1 planes (split 2 carries lo inside x)", who);
+    if (a->y_split == 2 && a->y_lo) return efts_fail(EFTS_EINVAL, "%s: y_lo is for split-1 output planes", who);
+    return 0;
+}
 
+extern "C" int efts_resconv5_multi(const efts_resconv5_args* a, int32_t count, void* stream) {
+    if (!a) return efts_fail(EFTS_EINVAL, "efts_resconv5: null args");
+    if (count < 1 || count > RC_MAXPROB) return efts_fail(EFTS_EINVAL, "efts_resconv5_multi: 1..%d layers per launch", RC_MAXPROB);
     RcArgs k;
-    k.a = (const char*)a->x; k.a_lo = (const char*)a->x_lo; k.resid = a->x_f32; k.w = (const char*)a->w;
-    k.bias = a->bias; k.rowmask = a->rowmask; k.out_f32 = a->y_f32; k.ob = (char*)a->y; k.ob_lo = (char*)a->y_lo;
-    k.lda = a->ldx; k.ldw = a->ldw; k.w_tap_stride = a->w_tap_stride; k.ldr = a->ldr; k.ldo = a->ldo; k.ldob = a->ldy;
-    k.m = a->m; k.nchunk = a->nchunk; k.ntn = a->n / RC_BN; k.slope = a->slope; k.out_split = a->y_split;
+    long mtot = 0;
+    for (int i = 0; i < count; ++i) {
+        const efts_resconv5_args* q = a + i;
+        const int rc = rc_check(q, count > 1 ? "efts_resconv5_multi" : "efts_resconv5");
+        if (rc) return rc;
+        if (q->split != a->split || q->n != a->n || q->nchunk != a->nchunk || q->ldw != a->ldw)
+            return efts_fail(EFTS_ESHAPE, "efts_resconv5_multi: the layers of a launch must agree in split, n, nchunk and ldw");
+        RcProb& r = k.pr[i];
+        r.a = (const char*)q->x; r.a_lo = (const char*)q->x_lo; r.resid = q->x_f32; r.w = (const char*)q->w;
+        r.bias = q->bias; r.rowmask = q->rowmask; r.out_f32 = q->y_f32; r.ob = (char*)q->y; r.ob_lo = (char*)q->y_lo;
+        r.lda = q->ldx; r.ldw = q->ldw; r.w_tap_stride = q->w_tap_stride; r.ldr = q->ldr; r.ldo = q->ldo; r.ldob = q->ldy;
+        r.m = q->m; r.out_split = q->y_split; r.slope = q->slope; r.pad_ = 0;
+        mtot += q->m;
+    }
+    for (int i = count; i < RC_MAXPROB; ++i) k.pr[i] = k.pr[0];
+    if (mtot > 0x3fffffffL) return efts_fail(EFTS_ESHAPE, "efts_resconv5: too many rows");
+    k.nprob = count; k.m = (int)mtot; k.nchunk = a->nchunk; k.ntn = a->n / RC_BN;
     int groups = 0;
     if (a->plan) {
-        const char* bad = rc_plan_read(a->plan, a->m, &k.s, &groups);
+        const char* bad = rc_plan_read(a->plan, k.m, &k.s, &groups);
         if (bad) return efts_fail(EFTS_EINVAL, "efts_resconv5: %s", bad);
     } else {
-        rc_schedule(a->m, efts_num_cus() / k.ntn > 0 ? efts_num_cus() / k.ntn : 1, &k.s, &groups);
+        rc_schedule(k.m, efts_num_cus() / k.ntn > 0 ? efts_num_cus() / k.ntn : 1, &k.s, &groups);
     }
     static bool attr = false;
     if (!attr) {
@@ -669,3 +720,5 @@ extern "C" int efts_resconv5(const efts_resconv5_args* a, void* stream) {
     else hipLaunchKernelGGL(resconv5_kernel<2>, grid, dim3(512), RC_LDS, (hipStream_t)stream, k);
     return efts_check_launch("efts_resconv5");
 }
+
+extern "C" int efts_resconv5(const efts_resconv5_args* a, void* stream) { return efts_resconv5_multi(a, 1, stream); }

@@ -196,6 +196,7 @@ class EfficientTTSCNN(torch.nn.Module):
         self.duration_predictor = _DurationPredictor(n_channels, n_duration_layer, n_channels, offset=duration_offset)
         self.fuse_prenet = True             # the prenet straight from the fp32 frames (efts_frame_linear); False: efts_pack_rows + efts_gemm
         self.fuse_soft_index = True         # T1 <= 128: q.k^T, softmax and soft index in one launch (False: scores stored, efts_attn_soft_index)
+        self.merge_text = True              # text-encoder layers ride in the persistent launches of the mel-encoder layers (efts_resconv5_multi)
         self.fuse_align = True              # imv scan + aligned positions + duration target in one launch (efts_imv_align)
         self.fuse_expand = True             # T1 <= 256: alpha' generated in registers inside the expand contraction (efts_expand); False: reconst_alpha + pack_vt + efts_gemm
         self.graphs = True                  # plain eval calls replay a per-shape hipGraph (False: every kernel launched eagerly)
@@ -341,25 +342,41 @@ class EfficientTTSCNN(torch.nn.Module):
             return None, pl, (ws.plane(f"{tag}_l", rs, C, 1) if self.split == 1 else None)
         return ws.f32(f"{tag}_f", rs, C), pl, None
 
+    def _res_layer_args(self, ws, tag, blk, pk, rs: Rows, i: int, n: int, x_f32, x_pl: Plane, x_lo, gap_ptr, last_split: int, last_f32: bool):
+        """keyword set of efts_resconv5 for layer i of a stack on hi / lo planes, and the buffers it writes (`x_f32`: the fp32
+        stream to take the residual from instead of the planes, or None)"""
+        C = self.n_channels
+        last = i == n - 1
+        o_split = last_split if last else self.split
+        y = ws.plane(f"{tag}_p{i & 1}", rs, C, o_split)
+        y_lo = ws.plane(f"{tag}_l{i & 1}", rs, C, 1) if (o_split == 1 and not last) else None
+        o_f32 = ws.f32(f"{tag}_f{i & 1}", rs, C) if (last and last_f32) else None
+        kw = dict(x=x_pl, x_lo=x_lo, x_f32_ptr=None if x_f32 is None else x_f32.ptr, ldr=C, w=pk[f"{blk}.{i}"],
+                  m=rs.rows, n=C, bias=getattr(self, blk).layers[i].conv[0].bias, slope=self.slope,
+                  rowmask_ptr=gap_ptr, y_f32_ptr=None if o_f32 is None else o_f32.ptr, ldo=C, y=y, y_lo=y_lo)
+        return kw, o_f32, y, y_lo
+
     def _res_stack(self, ws, tag, blk, pk, rs: Rows, x_f32: Optional[F32Rows], x_pl: Plane, gap_ptr, last_split: int,
-                   last_f32: bool, x_lo: Optional[Plane] = None):
-        """n x ( x + LeakyReLU(conv1d_k5(x)) ) on the row space (efts_modules.py:48-51,77-79)."""
+                   last_f32: bool, x_lo: Optional[Plane] = None, rider=None):
+        """n x ( x + LeakyReLU(conv1d_k5(x)) ) on the row space (efts_modules.py:48-51,77-79).
+        `rider(i)`: optional, returns the efts_resconv5 keyword set of an independent layer of the same geometry that shares
+        layer i's persistent launch (or None)."""
         n = len(getattr(self, blk).layers)
         C = self.n_channels
         if self._on_resconv(rs):
             # The stream between the layers is a pair of bf16 planes (hi = the next layer's MFMA operand, lo = the
             # remainder; split 2 planes carry both): 4 B read + 4 B written per element and layer instead of 4 + 6..8 B.
+            o_f32 = None
             for i in range(n):
-                last = i == n - 1
-                o_split = last_split if last else self.split
-                y = ws.plane(f"{tag}_p{i & 1}", rs, C, o_split)
-                y_lo = ws.plane(f"{tag}_l{i & 1}", rs, C, 1) if (o_split == 1 and not last) else None
-                o_f32 = ws.f32(f"{tag}_f{i & 1}", rs, C) if (last and last_f32) else None
-                O.resconv5(x=x_pl, x_lo=x_lo, x_f32_ptr=x_f32.ptr if (i == 0 and x_f32 is not None) else None, ldr=C, w=pk[f"{blk}.{i}"],
-                           m=rs.rows, n=C, bias=getattr(self, blk).layers[i].conv[0].bias, slope=self.slope,
-                           rowmask_ptr=gap_ptr, y_f32_ptr=None if o_f32 is None else o_f32.ptr, ldo=C, y=y, y_lo=y_lo)
+                kw, o_f32, y, y_lo = self._res_layer_args(ws, tag, blk, pk, rs, i, n, x_f32 if i == 0 else None, x_pl, x_lo, gap_ptr, last_split, last_f32)
+                extra = rider(i) if rider is not None else None
+                if extra is not None:
+                    O.resconv5_multi([kw, extra])
+                else:
+                    O.resconv5(**kw)
                 x_pl, x_lo = y, y_lo
             return o_f32, x_pl
+        assert rider is None
         for i in range(n):
             last = i == n - 1
             w = pk[f"{blk}.{i}"]
@@ -382,23 +399,34 @@ class EfficientTTSCNN(torch.nn.Module):
         x_p = ws.plane("emb_p", rs1, C, self.split)
         O.embed(text, self.text_embedding_table.weight.detach(), x_f, x_p, rs1)
         _, h_p = self._res_stack(ws, "te", "text_encoder", pk, rs1, x_f, x_p, gap1.data_ptr(), self.split, False)
-        key_p = ws.plane("key_p", rs1, C, 2)
-        val_f = ws.f32("val_f", rs1, C)
-        val_p = ws.plane("val_p", rs1, C, self.split)
-        lm = None if len1 is None else len1.data_ptr()
-        shared = self.share_text_encoder_key_value            # (:150-153) the value is the key projection: same weights, the
-        wk = pk["key"]                                        # second launch only writes it in the value's formats
-        wv = wk if shared else pk["value"]
-        vbias = self.text_encoder_key.bias if shared else self.text_encoder_value.bias
-        O.gemm(a=h_p, b_ptr=wk.ptr, ldb=wk.ld, m=rs1.rows, n=C, bias=self.text_encoder_key.bias,
-               rowmask_ptr=lm if lm is not None else gap1.data_ptr(), out_plane=key_p)
+        key_p = self._key_proj(ws, pk, rs1, h_p, gap1, len1)
         if on_key is not None:
             on_key()
+        val_f, val_p = self._value_proj(ws, pk, rs1, h_p, gap1, len1, vt)
+        return key_p, val_f, val_p
+
+    def _key_proj(self, ws, pk, rs1: Rows, h_p: Plane, gap1, len1) -> Plane:
+        """text_encoder_key, zero at padded text (efficient_tts.py:149, :155-156): split-2 operand plane of q.k^T"""
+        C = self.n_channels
+        key_p = ws.plane("key_p", rs1, C, 2)
+        wk = pk["key"]
+        O.gemm(a=h_p, b_ptr=wk.ptr, ldb=wk.ld, m=rs1.rows, n=C, bias=self.text_encoder_key.bias,
+               rowmask_ptr=(gap1 if len1 is None else len1).data_ptr(), out_plane=key_p)
+        return key_p
+
+    def _value_proj(self, ws, pk, rs1: Rows, h_p: Plane, gap1, len1, vt: Optional[Plane] = None):
+        """text_encoder_value (the key projection again when shared, :150-153), zero at padded text (:157): fp32 + operand plane"""
+        C = self.n_channels
+        val_f = ws.f32("val_f", rs1, C)
+        val_p = ws.plane("val_p", rs1, C, self.split)
+        shared = self.share_text_encoder_key_value
+        wv = pk["key"] if shared else pk["value"]
+        vbias = self.text_encoder_key.bias if shared else self.text_encoder_value.bias
         O.gemm(a=h_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=vbias,
-               rowmask_ptr=lm if lm is not None else gap1.data_ptr(), out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p)
+               rowmask_ptr=(gap1 if len1 is None else len1).data_ptr(), out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p)
         if vt is not None:
             O.pack_vt(val_f, vt, rs1.B, rs1.T, rs1.Tp, C)
-        return key_p, val_f, val_p
+        return val_f, val_p
 
     def _duration(self, ws, pk, rs1: Rows, val_p: Plane, gap1, out_mask_ptr, mode: int) -> torch.Tensor:
         """DurationPredictor._forward (duration_predictor.py:66-88); eval-mode (Dropout = identity)."""
@@ -483,7 +511,7 @@ class EfficientTTSCNN(torch.nn.Module):
         key = ("fwd", tuple(text.shape), tuple(speech.shape), text.dtype, speech.dtype, text_lengths.dtype, speech_lengths.dtype)
         ws = self._workspace(("fwd", text.shape[0], text.shape[1], speech.shape[1]), dev)
         # the graph is valid while the buffers its launches point at live: this workspace, the packed planes, the parameters
-        tag = (ws.serial, self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.side_stream, self.RESCONV_MIN_ROWS, self.fuse_soft_index, self.fuse_prenet, self.fuse_align, self.fuse_expand)
+        tag = (ws.serial, self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.side_stream, self.RESCONV_MIN_ROWS, self.fuse_soft_index, self.fuse_prenet, self.fuse_align, self.fuse_expand, self.merge_text)
 
         def body(t, tl, sp, sl):
             (_, stats, imv, ralpha, mel_pred, _), _ = self._forward_impl(t, tl, sp, sl)
@@ -510,40 +538,86 @@ class EfficientTTSCNN(torch.nn.Module):
         rs1, rs2 = Rows(B, T1), Rows(B, T2)
         gap1, len1 = ws.tensor("gap1", (rs1.rows,)), ws.tensor("len1", (rs1.rows,))
         gap2, len2 = ws.tensor("gap2", (rs2.rows,)), ws.tensor("len2", (rs2.rows,))
-        # The text side (masks, embed, 5 convs, K/V) and the duration predictor do not depend on the mel side
-        # (prenet, 3 convs): they run on a second HIP stream so their small grids fill the tail rounds
-        # of the mel-length kernels instead of serialising behind them.
+        # The text side (masks, embed, 5 convs, K/V) and the duration predictor do not depend on the mel side (prenet, 3 convs).
         main = torch.cuda.current_stream(dev)
         side = self._side_stream(dev)
         side.wait_stream(main)
-        k_ready, v_ready = torch.cuda.Event(), torch.cuda.Event()
         vt = None if self._fused_expand(T1) else ws.raw_plane("vt", B * C, T1, 2)
         O.row_masks(ml, rs2, gap2, len2)                                          # :139
-        with O.on_stream(side):
-            O.row_masks(tl, rs1, gap1, len1)                                      # :137
-            key_p, val_f, val_p = self._text_side(ws, pk, text, rs1, gap1, len1, on_key=lambda: k_ready.record(side), vt=vt)  # :144-157
-            v_ready.record(side)
-            dur = self._duration(ws, pk, rs1, val_p, gap1, len1.data_ptr(), 0)    # :219
-        pre_f, pre_p, pre_l = self._stream_in(ws, "pre", rs2)                     # :161 prenet
-        wp = pk["prenet"]
-        if self.fuse_prenet and self.odim % 8 == 0 and self.odim <= 128 and C % 128 == 0:
-            # straight from the caller's fp32 frames: no operand plane of the mel input, one launch (bit-identical on every frame)
-            O.frame_linear(x=speech, w=wp, bias=self.mel_prenet[0].bias, act=L.ACT_LEAKY, slope=self.slope, rs=rs2,
-                           y=pre_p, y_lo=pre_l, y_f32=pre_f)
-        else:
-            mel_in = ws.plane("mel_in", rs2, self.odim, self.split)
-            O.pack_rows(speech, None, mel_in, rs2)
-            O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, act=L.ACT_LEAKY, slope=self.slope,
-                   bias=self.mel_prenet[0].bias, rowmask_ptr=gap2.data_ptr(), out_f32_ptr=None if pre_f is None else pre_f.ptr,
-                   ldo=C, out_plane=pre_p, out_plane_lo=pre_l)
-        if self.mel_query_fc is None:
-            _, q_p = self._res_stack(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2, False, x_lo=pre_l)   # :162
-        else:                                                                      # :163-164 Linear(C, C) in front of the attention
-            _, mh_p = self._res_stack(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), self.split, False, x_lo=pre_l)
+        nt, nm = len(self.text_encoder.layers), len(self.mel_encoder.layers)
+        merged = self.merge_text and self._on_resconv(rs2) and nt >= 1 and nm >= 1
+        v_ready = torch.cuda.Event()
+
+        def prenet():                                                             # :161
+            pre_f, pre_p, pre_l = self._stream_in(ws, "pre", rs2)
+            wp = pk["prenet"]
+            if self.fuse_prenet and self.odim % 8 == 0 and self.odim <= 128 and C % 128 == 0:
+                # straight from the caller's fp32 frames: no operand plane of the mel input, one launch (bit-identical on every frame)
+                O.frame_linear(x=speech, w=wp, bias=self.mel_prenet[0].bias, act=L.ACT_LEAKY, slope=self.slope, rs=rs2,
+                               y=pre_p, y_lo=pre_l, y_f32=pre_f)
+            else:
+                mel_in = ws.plane("mel_in", rs2, self.odim, self.split)
+                O.pack_rows(speech, None, mel_in, rs2)
+                O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, act=L.ACT_LEAKY, slope=self.slope,
+                       bias=self.mel_prenet[0].bias, rowmask_ptr=gap2.data_ptr(), out_f32_ptr=None if pre_f is None else pre_f.ptr,
+                       ldo=C, out_plane=pre_p, out_plane_lo=pre_l)
+            return pre_f, pre_p, pre_l
+
+        def mel_stack(pre_f, pre_p, pre_l, rider=None):                            # :162-164
+            if self.mel_query_fc is None:
+                _, q_p = self._res_stack(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2, False, x_lo=pre_l, rider=rider)
+                return q_p
+            _, mh_p = self._res_stack(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), self.split, False, x_lo=pre_l, rider=rider)
             q_p = ws.plane("q_p", rs2, C, 2)
             wq = pk["qfc"]
             O.gemm(a=mh_p, b_ptr=wq.ptr, ldb=wq.ld, m=rs2.rows, n=C, bias=self.mel_query_fc.bias, rowmask_ptr=gap2.data_ptr(), out_plane=q_p)
-        main.wait_event(k_ready)
+            return q_p
+
+        if merged:
+            # The last min(nt, nm) text-encoder layers ride in the persistent launches of the mel-encoder layers (one grouped
+            # efts_resconv5_multi launch per pair: the text rows are scheduled behind the mel rows at the long launch's efficiency).
+            # A persistent launch owns every CU's LDS, so a text-length launch of its own beside it would get the 4 spare CUs:
+            # only the first nt - nm text layers run by themselves (efts_resconv5 on the short row space), beside the HBM-bound
+            # prenet on the second stream.
+            nr = min(nt, nm)
+            ns = nt - nr                                                           # text layers that run by themselves first
+            pre_ready, te_done = torch.cuda.Event(), torch.cuda.Event()
+            with O.on_stream(side):                                               # the HBM-bound prenet beside the first text layers
+                pre = prenet()
+                pre_ready.record(side)
+            O.row_masks(tl, rs1, gap1, len1)                                      # :137
+            x_f = ws.f32("emb_f", rs1, C)
+            x_p = ws.plane("emb_p", rs1, C, self.split)
+            O.embed(text, self.text_embedding_table.weight.detach(), x_f, x_p, rs1)          # :144
+            tstate = dict(x_f=x_f, x_p=x_p, x_lo=None)
+
+            def text_layer(i):                                                    # efts_resconv5 keyword set of text layer i (:148)
+                kw, _, y, y_lo = self._res_layer_args(ws, "te", "text_encoder", pk, rs1, i, nt, tstate["x_f"], tstate["x_p"], tstate["x_lo"],
+                                                      gap1.data_ptr(), self.split, False)
+                tstate.update(x_f=None, x_p=y, x_lo=y_lo)
+                return kw
+
+            for i in range(ns):
+                O.resconv5(**text_layer(i))
+            main.wait_event(pre_ready)
+            q_p = mel_stack(*pre, rider=lambda i: text_layer(ns + i - (nm - nr)) if i >= nm - nr else None)
+            te_done.record(main)
+            key_p = self._key_proj(ws, pk, rs1, tstate["x_p"], gap1, len1)          # :149, :155-156 (q.k^T is next on this stream)
+            side.wait_event(te_done)
+            with O.on_stream(side):                                               # the value projection beside the key projection
+                val_f, val_p = self._value_proj(ws, pk, rs1, tstate["x_p"], gap1, len1, vt)   # :150-157
+                v_ready.record(side)
+                dur = self._duration(ws, pk, rs1, val_p, gap1, len1.data_ptr(), 0)    # :219
+        else:
+            # second HIP stream: the text-side launches fill the tail rounds of the mel-length kernels
+            k_ready = torch.cuda.Event()
+            with O.on_stream(side):
+                O.row_masks(tl, rs1, gap1, len1)                                  # :137
+                key_p, val_f, val_p = self._text_side(ws, pk, text, rs1, gap1, len1, on_key=lambda: k_ready.record(side), vt=vt)  # :144-157
+                v_ready.record(side)
+                dur = self._duration(ws, pk, rs1, val_p, gap1, len1.data_ptr(), 0)    # :219
+            q_p = mel_stack(*prenet())
+            main.wait_event(k_ready)
 
         sidx = ws.tensor("sidx", (B, T2))
         imv = torch.empty(B, T2, dtype=torch.float32, device=dev)              # returned to the caller: written in place, no copy

@@ -158,12 +158,10 @@ def gemm(*, a: Plane, a_ptr: Optional[int] = None, b_ptr: int, ldb: int, b_tap_s
     L.check(L.load().efts_gemm(C.byref(g), _stream()), "efts_gemm")
 
 
-def resconv5(*, x: Plane, x_lo: Optional[Plane] = None, x_f32_ptr: Optional[int] = None, ldr: int = 0, w: "PackedWeight",
-             m: int, n: int, bias: Optional[torch.Tensor] = None, slope: float = 0.1, rowmask_ptr: Optional[int] = None,
-             y_f32_ptr: Optional[int] = None, ldo: int = 0, y: Optional[Plane] = None, y_lo: Optional[Plane] = None,
-             plan=None) -> None:
-    """one residual k5 convolution layer on hi/lo planes (efts_resconv5); plan: explicit tile schedule (make_plan)"""
-    g = L.ResConv5Args()
+def _resconv5_fill(g, *, x: Plane, x_lo: Optional[Plane] = None, x_f32_ptr: Optional[int] = None, ldr: int = 0, w: "PackedWeight",
+                   m: int, n: int, bias: Optional[torch.Tensor] = None, slope: float = 0.1, rowmask_ptr: Optional[int] = None,
+                   y_f32_ptr: Optional[int] = None, ldo: int = 0, y: Optional[Plane] = None, y_lo: Optional[Plane] = None,
+                   plan=None) -> None:
     if plan is not None:
         g.plan = plan
     g.x, g.x_lo, g.ldx = x.ptr, (None if x_lo is None else x_lo.ptr), x.ld
@@ -175,6 +173,13 @@ def resconv5(*, x: Plane, x_lo: Optional[Plane] = None, x_f32_ptr: Optional[int]
     if y is not None:
         g.y, g.ldy, g.y_split = y.ptr, y.ld, y.split
         g.y_lo = None if y_lo is None else y_lo.ptr
+
+
+def resconv5(**kw) -> None:
+    """one residual k5 convolution layer on hi/lo planes (efts_resconv5); plan: explicit tile schedule (make_plan)"""
+    g = L.ResConv5Args()
+    _resconv5_fill(g, **kw)
+    m, n = kw["m"], kw["n"]
     if PROFILE is not None and (PROFILE_TAG is None or PROFILE_TAG == (5, m, n)):
         s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s0.record()
@@ -183,6 +188,23 @@ def resconv5(*, x: Plane, x_lo: Optional[Plane] = None, x_f32_ptr: Optional[int]
         PROFILE.append(((5, m, n), s0, s1))
         return
     L.check(L.load().efts_resconv5(C.byref(g), _stream()), "efts_resconv5")
+
+
+def resconv5_multi(layers) -> None:
+    """several independent residual layers of the same geometry in ONE persistent launch (efts_resconv5_multi); `layers`: a list
+    of resconv5() keyword dicts, the long layer first"""
+    arr = (L.ResConv5Args * len(layers))()
+    for g, kw in zip(arr, layers):
+        _resconv5_fill(g, **kw)
+    tag = (5, sum(kw["m"] for kw in layers), layers[0]["n"])          # (a grouped launch is tagged with its combined rows)
+    if PROFILE is not None and (PROFILE_TAG is None or PROFILE_TAG == tag):
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        L.check(L.load().efts_resconv5_multi(arr, len(layers), _stream()), "efts_resconv5_multi")
+        s1.record()
+        PROFILE.append((tag, s0, s1))
+        return
+    L.check(L.load().efts_resconv5_multi(arr, len(layers), _stream()), "efts_resconv5_multi")
 
 
 def frame_linear(*, x: torch.Tensor, w: "PackedWeight", bias: Optional[torch.Tensor], act: int, slope: float, rs: Rows,

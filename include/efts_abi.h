@@ -186,6 +186,15 @@ typedef struct efts_resconv5_args {
 
 int efts_resconv5(const efts_resconv5_args* a, void* stream);
 
+/* `count` (1 or 2) independent residual layers of the same geometry (split, n, nchunk, ldw) in ONE persistent launch: the rows of
+ * the layers are laid end to end and scheduled over the compute units as one row space; a tile never crosses from one layer
+ * into the next, and every tile brings its own operands, weights, bias, mask and outputs.  This is how a short stack rides
+ * along with a long one -- text-encoder layer k + 2 (64 x 130 rows) in the launch of mel-encoder layer k (64 x 802 rows;
+ * nntts/models/efficient_tts.py:148 and :162 are independent until :167) -- at the long launch's efficiency instead of a
+ * launch of its own that cannot fill the chip.  Results per layer are those of efts_resconv5.  layers[0].plan (optional)
+ * schedules the combined rows. */
+int efts_resconv5_multi(const efts_resconv5_args* layers, int32_t count, void* stream);
+
 /* A Linear with few input features applied to the caller's fp32 frames, written into the row space:
  *   y[b * Tp + t, :] = act(x[b][t][:cin] . W^T + bias), t < T (rows t >= T of the row space are not touched: they stay zero)
  * -- `mel_prenet` of the reference (nntts/models/efficient_tts.py:76-80, applied at :161; eval / Dropout-free) in one launch,

@@ -164,3 +164,41 @@ def test_resconv5_race_screen(split):
                 bad += int(not torch.equal(y.buf, c.p_ref.buf))
         torch.cuda.synchronize()
     assert bad == 0, f"{bad} of 120 launches differ from efts_gemm"
+
+
+@pytest.mark.parametrize("split", [1, 2])
+@pytest.mark.parametrize("shapes", [((5, 300), (3, 37)), ((2, 801), (2, 130)), ((3, 37), (5, 300)), ((1, 1), (1, 1)), ((16, 800), (16, 128))])
+@pytest.mark.parametrize("classes", [None, [[7, 6], [6, 7]], [[3], [2]], [[8, 2, 5]]])
+def test_resconv5_multi_two_layers_in_one_launch(split, shapes, classes):
+    """efts_resconv5_multi: two independent layers (own operands, weights, bias, mask, outputs; different row counts) laid end to
+    end in ONE persistent launch == each layer through efts_gemm, bit for bit -- for the automatic schedule and explicit ones whose
+    tiles get cut at the layer boundary (tile heights change there, the operand streams carried across tiles switch layers)"""
+    ca, cb = Case(*shapes[0], split, seed=3), Case(*shapes[1], split, seed=11)
+    P, dev = ca.P, _dev()
+    outs, layers = [], []
+    for c, mode in ((ca, "planes"), (cb, "f32")):
+        o = P.F32Rows(c.rs, C, dev)
+        if mode == "f32":
+            y, yl = P.Plane.for_rows(c.rs, C, 2, dev), None
+            kw = dict(x=c.a, x_f32_ptr=c.xf.ptr, ldr=C, w=c.pw, m=c.rs.rows, n=C, bias=c.bias, rowmask_ptr=c.mask.data_ptr(),
+                      y_f32_ptr=o.ptr, ldo=C, y=y)
+        else:
+            y = P.Plane.for_rows(c.rs, C, split, dev)
+            yl = P.Plane.for_rows(c.rs, C, 1, dev) if split == 1 else None
+            kw = dict(x=c.a, x_lo=c.a_lo, w=c.pw, m=c.rs.rows, n=C, bias=c.bias, rowmask_ptr=c.mask.data_ptr(), y_f32_ptr=o.ptr, ldo=C,
+                      y=y, y_lo=yl)
+        layers.append(kw)
+        outs.append((c, mode, o, y, yl))
+    if classes is not None:
+        layers[0]["plan"] = P.make_plan(ca.rs.rows + cb.rs.rows, classes)
+    P.resconv5_multi(layers)
+    torch.cuda.synchronize()
+    for c, mode, o, y, yl in outs:
+        assert torch.equal(o.buf, c.o_ref.buf), f"fp32 differs: {(o.buf - c.o_ref.buf).abs().max().item():.3e}"
+        if mode == "f32" or split == 2:
+            assert torch.equal(y.buf, c.p_ref.buf)
+        else:
+            rh, rl = bf16_split(c.o_ref.buf)
+            n = c.rs.alloc
+            assert torch.equal(y.buf.view(torch.bfloat16).view(n, -1)[:, :C], rh)
+            assert torch.equal(yl.buf.view(torch.bfloat16).view(n, -1)[:, :C], rl)
