@@ -19,9 +19,14 @@ HIP events on the launch stream inside the timed region) and `cpu_baseline` (the
 restatement timed on this box's host cores on a bounded sample).
 """
 import argparse
+import glob
 import json
 import os
+import shutil
+import sqlite3
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -54,6 +59,9 @@ def parse():
     ap.add_argument("--model-graphs", type=int, default=1, help="0 with --graph 0: the model's internal graph cache off = every kernel launched eagerly")
     ap.add_argument("--parity-mode", type=int, default=1, help="forward workloads in bf16: also time the bf16x3 parity-grade mode (same K / W) -> `parity_mode` in the JSON line")
     ap.add_argument("--call-modes", type=int, default=1, help="forward workloads, N=1: 10 extra steps per call mode (plain call / bench graph / eager) -> `call_modes`")
+    ap.add_argument("--train-record", type=int, default=1, help="fwd64, N=1: also time BASELINE config 3 (training step B=32, 10 steps) under the same invocation -> `train32` in the JSON line")
+    ap.add_argument("--measure-traffic", type=int, default=1, help="forward workloads, N=1: roofline.traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) over a 2-step child run, when rocprofv3 is on the box; 0: the committed profiles/traffic.json")
+    ap.add_argument("--merge-text", type=int, default=1, help="A/B: 0 = text-encoder layers as launches of their own on the second stream")
     return ap.parse_args()
 
 
@@ -73,41 +81,45 @@ def synth(B, T1, T2, seed, dev):
     return text, tl, mel, sl
 
 
-def cpu_baseline(T1, T2, hip_check=None):
-    """The oracle (CPU port of the reference path) timed on this box's host cores: forward at
-    B=16 (bounded sample of the same workload), fp32, all cores.  hip_check(P, text, tl, mel, sl) ->
-    mel_pred of the HIP model with the oracle's parameters on the first 2 items; the oracle then acts as
-    the checker and the measured max-abs difference is reported next to the throughput."""
+def cpu_baseline(T1, T2, hip_check=None, Bc=64):
+    """the oracle (CPU port of the reference path) timed on this box's host cores in the same
+    invocation: forward under no_grad, fp32, B=64 x (T1, T2), median of 3 after 1 warm-up, torch.set_num_threads(os.cpu_count()).
+    torch's CPU convolution (oneDNN) does not always scale to every hardware thread of a 2-socket host, so 16 and 32 threads
+    are timed as well and the FASTEST is reported (`cores` = the threads it used; every measurement is in `by_threads`): the
+    scan can only flatter the CPU.  hip_check(P, text, tl, mel, sl) -> mel_pred of the HIP model with the oracle's parameters on
+    the first 2 items; the oracle then acts as the checker and the measured max-abs difference is reported too."""
     from oracle import efts_oracle as O          # the cpu_baseline leg: oracle as the thing timed
     cores = os.cpu_count() or 1
     P = O.fill_params()
-    Bc = 16
     g = torch.Generator().manual_seed(1234)
     text = torch.randint(0, 76, (Bc, T1), generator=g)
     mel = torch.randn(Bc, T2, 80, generator=g)
     tl = torch.full((Bc,), T1, dtype=torch.int64)
     sl = torch.full((Bc,), T2, dtype=torch.int64)
-    best = None
-    # torch's CPU conv (oneDNN) does not scale to every hardware thread of a 2-socket host:
-    # sweep a few thread counts and report the fastest (cores = threads actually used).
-    for nt in sorted({min(cores, n) for n in (8, 16, 32, 64)}):
+    best, by = None, {}
+    # 16 and 32 threads on the full batch; every hardware thread (what BASELINE.md section 3 names) on the full batch too unless the
+    # host is so wide that oneDNN collapses there (256 threads: ~25 s per forward), in which case that point is taken on B=16
+    for nt in sorted({min(cores, 16), min(cores, 32), cores}):
+        bn = Bc if nt <= 64 else 16
         torch.set_num_threads(nt)
         times = []
         with torch.no_grad():
-            O.forward(P, text, tl, mel, sl)
-            for _ in range(3):
+            t0 = time.perf_counter()
+            O.forward(P, text[:bn], tl[:bn], mel[:bn], sl[:bn])
+            warm = time.perf_counter() - t0
+            for _ in range(3 if warm < 4.0 else 1):
                 t0 = time.perf_counter()
-                O.forward(P, text, tl, mel, sl)
+                O.forward(P, text[:bn], tl[:bn], mel[:bn], sl[:bn])
                 times.append(time.perf_counter() - t0)
-        med = sorted(times)[1]
-        if best is None or med < best[0]:
-            best = (med, nt)
-        if med > 4 * best[0]:
-            break
-    med, nt = best
-    res = dict(value=Bc * T2 / med, unit="mel-frames/s", cores=nt, host_cpus=cores, kind="port",
-               sample=f"oracle forward fp32, B={Bc} x (T1={T1}, T2={T2}), median of 3 after 1 warm-up, "
-                      f"best of 8/16/32/64 threads ({med:.3f} s/iter at {nt} threads)")
+        med = sorted(times)[len(times) // 2]
+        by[f"{nt} threads, B={bn}"] = bn * T2 / med
+        if best is None or bn * T2 / med > best[2]:
+            best = (med, nt, bn * T2 / med, bn)
+    med, nt, _, bn = best
+    res = dict(value=bn * T2 / med, unit="mel-frames/s", cores=nt, host_cpus=cores, kind="port", by_threads=by,
+               sample=f"oracle forward fp32, (T1={T1}, T2={T2}), 1 warm-up then the median of 3 (1 if a pass takes > 4 s) at 16 / 32 / all {cores} host "
+                      f"threads; B={Bc} (BASELINE.md section 3: the full config-2 batch; B=16 at more than 64 threads); fastest = {nt} threads, B={bn} "
+                      f"({med:.3f} s/iter)")
     if hip_check is not None:
         with torch.no_grad():
             ref = O.forward(P, text[:2], tl[:2], mel[:2], sl[:2])
@@ -116,6 +128,80 @@ def cpu_baseline(T1, T2, hip_check=None):
         res["hip_vs_oracle_note"] = "same parameters and inputs (2 items, full length); north_star tolerance 1e-3 applies to the bf16x3 mode"
         res["_ref_mel"] = ref["mel_pred"]
     return res
+
+
+def cpu_train_baseline(T1, T2):
+    """the oracle (CPU restatement of the reference path, torch autograd for the backward)
+    timed on this box's host cores for one training step -- fwd + bwd + clip 1.0 + Adam-amsgrad -- on a bounded sample
+    (B=4 full-length items instead of 32; the step is linear in the batch)."""
+    from oracle import efts_oracle as O          # the cpu_baseline leg: oracle as the thing timed
+    cores = os.cpu_count() or 1
+    nt = min(cores, 32)
+    torch.set_num_threads(nt)
+    P = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in O.fill_params().items()}
+    params = [v for v in P.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.99), eps=1e-9, weight_decay=1e-5, amsgrad=True)
+    Bc = 4
+    g = torch.Generator().manual_seed(1234)
+    text = torch.randint(0, 76, (Bc, T1), generator=g)
+    mel = torch.randn(Bc, T2, 80, generator=g)
+    tl = torch.full((Bc,), T1, dtype=torch.int64)
+    sl = torch.full((Bc,), T2, dtype=torch.int64)
+    times = []
+    for it in range(4):
+        t0 = time.perf_counter()
+        out = O.forward(P, text, tl, mel, sl)
+        opt.zero_grad()
+        out["loss"].backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        if it:
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[1]
+    return dict(value=Bc * T2 / med, unit="mel-frames/s", cores=nt, host_cpus=cores, kind="port",
+                sample=f"oracle training step fp32 (forward, autograd backward, clip 1.0, torch Adam-amsgrad), B={Bc} x (T1={T1}, T2={T2}), "
+                       f"median of 3 after 1 warm-up ({med:.3f} s/step at {nt} threads)")
+
+
+def measure_traffic(a, precision):
+    """HBM-side bytes per launch of the dominant kernel from the PMC counters, collected as MI355X_MICROARCH.md prescribes:
+    FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 passes (--kernel-trace --pmc only), each over a 2-step child run of this very
+    workload; FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of wide streaming reads at 64 B), both in KiB.
+    Returns (bytes per launch, description) or None when rocprofv3 is missing / a pass fails (the caller then falls back to
+    the committed profiles/traffic.json)."""
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or os.environ.get("EFTS_BENCH_CHILD") or any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ):
+        return None                                      # no profiler, or this run is itself a profiled one
+    tmp = tempfile.mkdtemp(prefix="efts_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", EFTS_BENCH_CHILD="1")
+    vals, n_disp = {}, {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", out, "-o", "b", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--parity-mode", "0", "--call-modes", "0", "--train-record", "0",
+                   "--measure-traffic", "0", "--precision", precision, "--workload", a.workload]
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=150, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+            if not dbs:
+                return None
+            con = sqlite3.connect(dbs[0])
+            # the mel-length launches WITHOUT a text-encoder rider are the most frequent grid of the kernel (6 of 9 per step)
+            rows = con.execute("select grid_size, avg(value), count(*) from counters_collection where kernel_name like '%resconv5_kernel%' "
+                               "and counter_name = ? group by grid_size order by 3 desc", (ctr,)).fetchall()
+            con.close()
+            if not rows:
+                return None
+            vals[ctr], n_disp[ctr] = float(rows[0][1]), int(rows[0][2])
+        traffic = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+        return traffic, (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes over a 2-step child run, "
+                         f"{n_disp['FETCH_SIZE']} / {n_disp['WRITE_SIZE']} launches averaged): 2 * FETCH_SIZE + WRITE_SIZE, KiB counters "
+                         f"(FETCH_SIZE {vals['FETCH_SIZE']:.0f}, WRITE_SIZE {vals['WRITE_SIZE']:.0f}); FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM), "
+                         "WRITE_SIZE uncalibrated, Infinity-Cache hits counted")
+    except Exception:                                    # noqa: BLE001 -- profiler missing / timed out / format changed: fall back
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def run_infer64(a, world, rank, dev):
@@ -382,6 +468,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if a.workload == "train32":
+            # RCCL's own account of the topology and of the algorithm / protocol it picks per collective goes to per-rank FILES
+            # (never to stdout: the contract is ONE JSON line); efficient_tts_amd/bench_train.py quotes it in the `dp` record
+            os.environ.setdefault("NCCL_DEBUG", "INFO")
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING")
+            os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/efts_rccl_{os.getpid()}_%h_%p.log")
         dist.init_process_group("nccl", device_id=dev)
 
     from efficient_tts_amd import EfficientTTSCNN, ops as P
@@ -397,12 +489,12 @@ def main():
     B, T1, T2 = wl["B"], wl["T1"], wl["T2"]
     if a.workload == "train32":
         from efficient_tts_amd.bench_train import run_train      # DP training step (config 3/4)
-        return run_train(a, world, rank, dev, wl)
+        return run_train(a, world, rank, dev, wl, cpu_baseline_fn=cpu_train_baseline)
 
     return run_forward(a, world, rank, dev, wl)
 
 
-def conv_roofline(P, model, step, B, T2, precision, workload):
+def conv_roofline(P, model, step, B, T2, precision, workload, a=None):
     """The dominant kernel (k5 residual Conv1d 512 -> 512 at mel length): per-launch duration from HIP events recorded
     on the launch stream around every such launch of 3 EAGER steps (graphs off), against the dense bf16 MFMA peak."""
     rows = P.Rows(B, T2).rows
@@ -423,15 +515,18 @@ def conv_roofline(P, model, step, B, T2, precision, workload):
     # written (bf16x3: one 4 B hi|lo chunk read, one written), plus the weight plane once
     alg_bytes = rows * 512 * 8 + 5 * 512 * 512 * (2 if model.split == 1 else 4)
     traffic, src = None, None
+    got = measure_traffic(a, precision) if (a is not None and a.measure_traffic and a.gpus == 1) else None
+    if got is not None:
+        traffic, src = got
     tf = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tf):
+    if traffic is None and os.path.exists(tf):
         try:
             traffic = json.load(open(tf)).get(f"{precision}:{workload}")
             src = "profiles/traffic.json (rocprofv3 PMC passes of this workload: 2 * FETCH_SIZE + WRITE_SIZE per launch; not measured in this run)"
         except Exception:
             traffic = None
     return dict(bound="mfma", kernel=f"resconv5_kernel<split={model.split}> (efts_resconv5: persistent 8-wave workgroups, 256-column tiles, hi/lo bf16 stream): "
-                                      f"k5 Conv1d 512->512, {B}x{T2} frames",
+                                      f"k5 Conv1d 512->512, {B}x{T2} frames (the decoder's launches; the mel encoder's carry a text-encoder layer each and are not in this average)",
                 achieved=flop / avg / 1e12, peak=PEAK_MFMA_BF16_TFLOPS, unit="TFLOP/s", frac=flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS,
                 traffic=traffic, traffic_source=src, avg_launch_us=avg * 1e6, launches_measured=len(durs),
                 algorithmic_flop_per_launch=flop, algorithmic_bytes_per_launch=alg_bytes,
@@ -456,6 +551,7 @@ def run_forward(a, world, rank, dev, wl):
         m.side_stream, m.resconv = bool(a.side_stream), bool(a.resconv)
         m.fuse_soft_index = bool(a.fuse_soft_index)
         m.fuse_prenet = bool(a.fuse_prenet)
+        m.merge_text = bool(a.merge_text)
         if a.resconv_min_rows >= 0:
             m.RESCONV_MIN_ROWS = a.resconv_min_rows
         return m
@@ -507,7 +603,7 @@ def run_forward(a, world, rank, dev, wl):
     model = build(a.precision)
     mode = "graph" if a.graph == 1 else ("call" if a.model_graphs else "eager")
     dt, loss, step = timed(model, a.steps, a.warmup, mode)               # ---- THE timed region: exactly K steps
-    roof = conv_roofline(P, model, step, B, T2, a.precision, a.workload)
+    roof = conv_roofline(P, model, step, B, T2, a.precision, a.workload, a)
 
     def line(precision, dt, steps):
         frames = world * B * T2 * steps
@@ -531,7 +627,7 @@ def run_forward(a, world, rank, dev, wl):
     if a.precision == "bf16" and a.parity_mode:
         parity_model = build("bf16x3", {k: v.detach() for k, v in model.state_dict().items()})
         dt2, loss2, step2 = timed(parity_model, a.steps, a.warmup, mode)
-        roof2 = conv_roofline(P, parity_model, step2, B, T2, "bf16x3", a.workload)
+        roof2 = conv_roofline(P, parity_model, step2, B, T2, "bf16x3", a.workload, a)
         if rank == 0:
             res["parity_mode"] = dict(precision="bf16x3", dtype="bf16x3 (split-bf16 MFMA operands: hi*hi + hi*lo + lo*hi, fp32 accumulate)",
                                       steps=a.steps, warmup=a.warmup, loss=loss2, roofline=roof2, **line("bf16x3", dt2, a.steps))
@@ -561,6 +657,14 @@ def run_forward(a, world, rank, dev, wl):
                 res["parity_mode"]["tolerance"] = 1e-3
             if ref is not None:
                 res["hip_vs_oracle_mel_max_abs"] = float((checks[a.precision] - ref).abs().max())
+        if world == 1 and a.workload == "fwd64" and a.train_record and not os.environ.get("EFTS_BENCH_CHILD"):
+            # ---- BASELINE config 3 under the same invocation: the training step at B=32 (fwd + bwd + clip + Adam-amsgrad), 10 steps
+            from efficient_tts_amd.bench_train import measure_train
+            torch.cuda.empty_cache()
+            tr = measure_train(a, 1, 0, dev, WORKLOADS["train32"], steps=10, warmup=3)
+            if not a.no_cpu_baseline:
+                tr["cpu_baseline"] = cpu_train_baseline(T1, T2)
+            res["train32"] = tr
         print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -1,7 +1,14 @@
 """bench.py --workload train32: the data-parallel training step (BASELINE configs 3 and 4):
 fwd + bwd + clip(1.0) + Adam-amsgrad + WarmupLR at batch 32 per GPU, (T1, T2) = (128, 800), with the
 gradient all-reduce over RCCL overlapped with backward when world > 1
-(reference: nntts/trainers/efficient_tts_trainer.py:139-160 under nntts/bin/train.py:210-216)."""
+(reference: nntts/trainers/efficient_tts_trainer.py:139-160 under nntts/bin/train.py:210-216).
+
+`measure_train` is the measurement (also the `train32` sub-record of the default bench line); `run_train` prints it.
+With world > 1 the run validates itself before it is timed: the process-group backend must be "nccl" (= RCCL), two optimizer
+steps are taken and every rank's parameters are compared BIT FOR BIT with rank 0's, and RCCL's own log (NCCL_DEBUG=INFO into
+per-rank files, set up by bench.py before the process group exists) is searched for the topology / algorithm lines, which go
+into the `dp` record -- so that the first run on a real 8-GPU node explains its scaling number by itself."""
+import glob
 import json
 import os
 import time
@@ -11,41 +18,36 @@ import torch
 TRAIN_FLOP_PER_ITEM = 3 * 21.43e9
 
 
-def cpu_train_baseline(T1, T2):
-    """the oracle (CPU restatement of the reference path, torch autograd for the backward)
-    timed on this box's host cores for one training step -- fwd + bwd + clip 1.0 + Adam-amsgrad -- on a bounded sample
-    (B=4 full-length items instead of 32)."""
-    import time as _t
-    from oracle import efts_oracle as O          # the cpu_baseline leg: oracle as the thing timed
-    cores = os.cpu_count() or 1
-    nt = min(cores, 16)
-    torch.set_num_threads(nt)
-    P = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in O.fill_params().items()}
-    params = [v for v in P.values() if v.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.99), eps=1e-9, weight_decay=1e-5, amsgrad=True)
-    Bc = 4
-    g = torch.Generator().manual_seed(1234)
-    text = torch.randint(0, 76, (Bc, T1), generator=g)
-    mel = torch.randn(Bc, T2, 80, generator=g)
-    tl = torch.full((Bc,), T1, dtype=torch.int64)
-    sl = torch.full((Bc,), T2, dtype=torch.int64)
-    times = []
-    for it in range(4):
-        t0 = _t.perf_counter()
-        out = O.forward(P, text, tl, mel, sl)
-        opt.zero_grad()
-        out["loss"].backward()
-        torch.nn.utils.clip_grad_norm_(params, 1.0)
-        opt.step()
-        if it:
-            times.append(_t.perf_counter() - t0)
-    med = sorted(times)[1]
-    return dict(value=Bc * T2 / med, unit="mel-frames/s", cores=nt, host_cpus=cores, kind="port",
-                sample=f"oracle training step fp32 (forward, autograd backward, clip 1.0, torch Adam-amsgrad), B={Bc} x (T1={T1}, T2={T2}), "
-                       f"median of 3 after 1 warm-up ({med:.3f} s/step at {nt} threads)")
+def _params_fingerprint(model, dev) -> torch.Tensor:
+    """an exact fingerprint of all parameters: wrap-around int64 sums of their bit patterns, plain and position-weighted"""
+    acc = torch.zeros(2, dtype=torch.int64, device=dev)
+    for p in model.parameters():
+        bits = p.detach().reshape(-1).view(torch.int32).to(torch.int64)
+        acc[0] += bits.sum()
+        acc[1] += (bits * (torch.arange(bits.numel(), device=dev, dtype=torch.int64) % 8191 + 1)).sum()
+    return acc
 
 
-def run_train(a, world, rank, dev, wl):
+def _rccl_log_lines(limit: int = 12):
+    """what RCCL said about the rings / trees / algorithms it uses (NCCL_DEBUG_FILE of this job, rank 0's view)"""
+    pat = os.environ.get("NCCL_DEBUG_FILE", "")
+    if not pat:
+        return None
+    out = []
+    for f in sorted(glob.glob(pat.replace("%h", "*").replace("%p", "*")))[:2]:
+        try:
+            for ln in open(f, errors="replace"):
+                if any(k in ln for k in ("Algo", "algo", "Proto", "Connected all", "Channel", "nranks", "NCCL version", "RCCL version", "P2P", "XGMI", "xgmi")):
+                    out.append(ln.strip()[-200:])
+                    if len(out) >= limit:
+                        return out
+        except OSError:
+            pass
+    return out or None
+
+
+def measure_train(a, world, rank, dev, wl, steps, warmup):
+    """K timed training steps (barrier + synchronize on both sides, max over ranks) -> the record (rank 0; None elsewhere)"""
     import torch.distributed as dist
     from . import EfficientTTSCNN, ops as P
     from .dist import DistributedEFTS
@@ -79,7 +81,22 @@ def run_train(a, world, rank, dev, wl):
         sch.step()
         return loss
 
-    for _ in range(a.warmup):
+    selfcheck = None
+    if world > 1:
+        # ---- self-validation before anything is timed
+        backend = dist.get_backend()
+        assert backend == "nccl", f"data-parallel runs use the RCCL backend ('nccl'), got {backend!r}"
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        fp = _params_fingerprint(model, dev)
+        every = [torch.zeros_like(fp) for _ in range(world)]
+        dist.all_gather(every, fp)
+        same = all(bool(torch.equal(e, every[0])) for e in every)
+        assert same, "data-parallel replicas diverged after 2 steps: " + str([e.tolist() for e in every])
+        selfcheck = dict(backend=backend, world_seen_by_rccl=dist.get_world_size(), steps=2, replicas_bit_identical=same,
+                         fingerprint=[int(v) for v in every[0].tolist()])
+    for _ in range(warmup):
         loss = step()
     torch.cuda.synchronize()
     rows = P.Rows(B, T2).rows
@@ -88,7 +105,7 @@ def run_train(a, world, rank, dev, wl):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         loss = step()
     torch.cuda.synchronize()
     if world > 1:
@@ -107,29 +124,36 @@ def run_train(a, world, rank, dev, wl):
     split = model.split
     big = split == 1 and ((rows + 251) // 252) * 4 >= 400           # efts_gemm's own rule for the 256-row kernel
     kname = "conv5_kernel<split=1> (256-row tiles)" if big else f"gemm_kernel<taps=5,split={split}> (124-row tiles)"
-    cpu = cpu_train_baseline(T1, T2) if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None
+    if rank != 0:
+        return None
+    frames = world * B * T2 * steps
+    res = dict(metric="mel-frames/sec (EFTS-CNN training step, batch 32/GPU, 80-mel LJSpeech shape)", value=frames / dt,
+               unit="mel-frames/s", n_gpus=world, steps=steps, warmup=warmup, ms_per_step=dt / steps * 1e3,
+               higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype="bf16" if a.precision == "bf16" else "bf16x3 (split-bf16 MFMA, fp32-class)", data="synthetic",
+               config=dict(workload=wl["desc"], batch_per_gpu=B, phoneme_len=T1, mel_len=T2, precision=a.precision,
+                           parallelism=f"dp{world}", optimizer="Adam-amsgrad fused, clip 1.0, WarmupLR 4000",
+                           allreduce="RCCL, 3 buckets overlapped with backward" if world > 1 else "none"),
+               per_gpu=frames / dt / world, tflops=TRAIN_FLOP_PER_ITEM * B * world * steps / dt / 1e12, loss=lv,
+               roofline=dict(bound="mfma", kernel=f"{kname}: fwd + dgrad launches at mel length (timed while the text-length stream runs beside them)",
+                             achieved=conv_flop / avg / 1e12 if avg else None, peak=2500.0, unit="TFLOP/s",
+                             frac=conv_flop / avg / 1e12 / 2500.0 if avg else None, traffic=None,
+                             avg_launch_us=avg * 1e6, launches_measured=len(durs)))
+    if ddp is not None:
+        # the last timed step's communication: one record that explains the scaling number (backend, ranks, algorithm,
+        # bytes and time per bucket, how much of it the backward did NOT hide)
+        res["dp"] = dict(backend=dist.get_backend(), ranks=dist.get_world_size(), grad_mb=ddp.engine.numel * 4 / 1e6,
+                         nccl_env={k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))},
+                         selfcheck=selfcheck, rccl_log=_rccl_log_lines(), **ddp.reducer.stats())
+    return res
+
+
+def run_train(a, world, rank, dev, wl, cpu_baseline_fn=None):
+    import torch.distributed as dist
+    res = measure_train(a, world, rank, dev, wl, a.steps, a.warmup)
     if rank == 0:
-        frames = world * B * T2 * a.steps
-        res = dict(metric="mel-frames/sec (EFTS-CNN training step, batch 32/GPU, 80-mel LJSpeech shape)", value=frames / dt,
-                   unit="mel-frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
-                   higher_is_better=True, scaling="weak", vs_baseline=None,
-                   dtype="bf16" if a.precision == "bf16" else "bf16x3 (split-bf16 MFMA, fp32-class)", data="synthetic",
-                   config=dict(workload=wl["desc"], batch_per_gpu=B, phoneme_len=T1, mel_len=T2, precision=a.precision,
-                               parallelism=f"dp{world}", optimizer="Adam-amsgrad fused, clip 1.0, WarmupLR 4000",
-                               allreduce="RCCL, 3 buckets overlapped with backward" if world > 1 else "none"),
-                   per_gpu=frames / dt / world, tflops=TRAIN_FLOP_PER_ITEM * B * world * a.steps / dt / 1e12, loss=lv,
-                   roofline=dict(bound="mfma", kernel=f"{kname}: fwd + dgrad launches at mel length (timed while the text-length stream runs beside them)",
-                                 achieved=conv_flop / avg / 1e12 if avg else None, peak=2500.0, unit="TFLOP/s",
-                                 frac=conv_flop / avg / 1e12 / 2500.0 if avg else None, traffic=None,
-                                 avg_launch_us=avg * 1e6, launches_measured=len(durs)))
-        if ddp is not None:
-            # the last timed step's communication: one record that explains the scaling number (backend, ranks, algorithm,
-            # bytes and time per bucket, how much of it the backward did NOT hide)
-            res["dp"] = dict(backend=dist.get_backend(), ranks=dist.get_world_size(), grad_mb=ddp.engine.numel * 4 / 1e6,
-                             nccl_env={k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))},
-                             **ddp.reducer.stats())
-        if cpu is not None:
-            res["cpu_baseline"] = cpu
+        if cpu_baseline_fn is not None and world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline_fn(wl["T1"], wl["T2"])
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -204,7 +204,8 @@ class EfficientTTSCNN(torch.nn.Module):
         self._infer_cache = GraphCache(capacity=64)      # free-running inference: two phases per (bucketed) shape
         self.side_stream = True             # text-length work on a second HIP stream beside the mel-length kernels
         self.resconv = True                 # long row spaces: residual stacks on efts_resconv5 (False: efts_gemm + fp32 stream, A/B and tests)
-        self.dropout_seed = 0x5EED          # base seed of the duration predictor's dropout masks (train mode)
+        self.dropout_seed = 0x5EED          # base seed of the train-mode dropout masks (mixed with the data-parallel rank and the step counter)
+        self.dropout_calls = 0              # training steps taken so far: the position in the mask sequence (the trainer restores it from the step count on --resume)
         self._packed: Dict[str, PackedWeight] = {}
         self._packed_sig = None
         self._ptr_sig = 0
@@ -671,7 +672,9 @@ class EfficientTTSCNN(torch.nn.Module):
         if self.graphs and not torch.cuda.is_current_stream_capturing():
             # same arithmetic as a ragged batch of one (every layer masked by the length; equal to the unmasked B = 1 pass
             # below to ~1e-4), on bucketed shapes whose launches replay as two hipGraphs around the one host sync
-            tl1 = torch.full((1,), text.shape[1], dtype=torch.int64, device=text.device) if text_lengths is None else text_lengths
+            # (text_lengths is accepted and ignored, like the reference's inference(): efficient_tts.py:233, :243 -- every position
+            # of `text` is synthesised; ragged batches go through inference_batch())
+            tl1 = torch.full((1,), text.shape[1], dtype=torch.int64, device=text.device)
             mel, _, ralpha = self.inference_batch(text, tl1)
             return mel, ralpha
         dev = text.device

@@ -8,8 +8,6 @@ ranges that become final early: mel head + decoder first, text encoder + embeddi
 """
 from __future__ import annotations
 
-import os
-
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -25,14 +23,14 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-_WGRAD_TN_SPLITS = int(os.environ.get("EFTS_WGRAD_TN_SPLITS", "8"))     # K-splits of the direct (row-major) k5 wgrad; 0 disables it
+_WGRAD_TN_SPLITS = 8         # K-splits of the direct (row-major) k5 wgrad; 0 disables it (A/B: bench.py --train-set _WGRAD_TN_SPLITS=...)
 _SIGN_MIN_ROWS = 16384       # row spaces from here on: the forward convolutions of the stacks write the activation's sign words
                              # (efts_gemm `sign_mask`) and efts_act_bwd reads those instead of y and x in fp32 (14 -> 6 B per element);
                              # shorter ones (the text side) keep the narrow tiling, which does not write them.  0 = never
 _WGRAD_TN_SMALL = 1          # key / value / query Linears and the duration predictor's k3 convolutions: weight gradient straight from
                              # the row-major planes too (taps 1 / 3) instead of two transposed copies + a split-K efts_gemm (0: the latter)
 _BIAS_PARTS = 1              # direct-wgrad layers: bias gradient as per-row-block sums finished by the wgrad reduction (0: atomics in act_bwd)
-_WGRAD_WGS = int(os.environ.get("EFTS_WGRAD_WGS", "480"))   # split-K target: 480 workgroups per wgrad launch measured best (6.30 vs 6.60 ms/step at 640)
+_WGRAD_WGS = 480             # split-K target: 480 workgroups per wgrad launch measured best (6.30 vs 6.60 ms/step at 640)
 
 
 class _TPlane(Plane):
@@ -156,7 +154,18 @@ class TrainEngine:
         m = self.m
         if not m.training or m.dropout_rate < 1e-5:
             return 0.0, 0
-        return float(m.dropout_rate), (m.dropout_seed * 2654435761 + self.drop_calls * 1000003 + k * 7919 + 12345) & 0xFFFFFFFF
+        return float(m.dropout_rate), (getattr(self, "seed_base", int(m.dropout_seed)) * 2654435761 + self.drop_calls * 1000003 + k * 7919 + 12345) & 0xFFFFFFFF
+
+    def _seed_base(self) -> int:
+        """the model's base seed mixed with the data-parallel rank"""
+        rank = 0
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                rank = dist.get_rank()
+        except Exception:                                  # noqa: BLE001
+            rank = 0
+        return (int(self.m.dropout_seed) + 0x9E3779B1 * rank) & 0xFFFFFFFF
 
     def _wgrad_any(self, ws, dz_f_ptr, dz_p: Optional[Plane], x_f_ptr, x_p: Optional[Plane], cout, cin, taps, rows, out_dw):
         """un-normed weights: the direct kernel when both operand planes exist in one format and the shape fits its tiles"""
@@ -298,8 +307,13 @@ class TrainEngine:
         # Dropout(0.1) of the duration predictor is active in train() mode like the reference's
         # (duration_predictor.py:61; the model never forwards its own dropout_rate to it)
         drop_p = float(dp.conv[0][3].p) if m.training else 0.0
-        self.drop_calls = getattr(self, "drop_calls", 0) + 1
-        seed0, seed1 = (m.dropout_seed + 2 * self.drop_calls) & 0xFFFFFFFF, (m.dropout_seed + 2 * self.drop_calls + 1) & 0xFFFFFFFF
+        # one mask family per (base seed, data-parallel rank, step counter): replicas draw different masks (the reference's ranks
+        # have their own torch RNG streams); the trainer sets the counter to the step count when it loads a checkpoint, so that
+        # --resume continues the sequence instead of replaying it
+        m.dropout_calls = int(getattr(m, "dropout_calls", 0)) + 1
+        self.drop_calls = m.dropout_calls
+        self.seed_base = self._seed_base()
+        seed0, seed1 = (self.seed_base + 2 * self.drop_calls) & 0xFFFFFFFF, (self.seed_base + 2 * self.drop_calls + 1) & 0xFFFFFFFF
 
         # ============================ forward (efficient_tts.py:144-227), activations kept
         with O.on_stream(side):
@@ -360,23 +374,32 @@ class TrainEngine:
                b_batch_stride=rs1.Tp * key_p.ld, alpha=scale, out_f32_ptr=scores.data_ptr(), ldo=T1, out_batch_stride=T2 * T1)
         sidx, imv = ws.tensor("Tsidx", (B, T2)), ws.tensor("Timv", (B, T2))
         O.attn_soft_index(scores, T1, tl, ml, sidx, None, B, T1, T2)
-        O.imv_scan(sidx, tl, ml, imv, B, T2)
         e, lde = ws.tensor("Te", (B, T1)), ws.tensor("Tlde", (B, T1))
-        O.aligned_positions(imv, tl, ml, float(m.sigma_e), float(m.duration_offset), e, lde if m.delta_e_method_1 else None, B, T1, T2)
-        if not m.delta_e_method_1:                                   # efficient_tts.py:205-213 (the target is detached either way)
-            O.duration_target(e, tl, ml, float(m.duration_offset), False, lde, B, T1)
+        if m.fuse_align and (2 * O.roundup(T2, 4)) * 4 <= 150 * 1024:
+            O.imv_align(sidx, tl, ml, float(m.sigma_e), float(m.duration_offset), m.delta_e_method_1, imv, e, lde, B, T1, T2)
+        else:
+            O.imv_scan(sidx, tl, ml, imv, B, T2)
+            O.aligned_positions(imv, tl, ml, float(m.sigma_e), float(m.duration_offset), e, lde if m.delta_e_method_1 else None, B, T1, T2)
+            if not m.delta_e_method_1:                               # efficient_tts.py:205-213 (the target is detached either way)
+                O.duration_target(e, tl, ml, float(m.duration_offset), False, lde, B, T1)
         ralpha = ws.tensor("Tralpha", (B, T1, T2))
-        ra_p = ws.plane("Tra_p", rs2, T1, 2)
-        O.reconst_alpha(e, tl, ml, float(m.sigma), ralpha, ra_p, B, T1, T2, rs2.Tp)
-        if self.mark is not None:
-            self.mark("fwd_alignment_done")
-
-        vt = ws.raw_plane("Tvt", B * C + 136, T1, 2)
-        O.pack_vt(val_f, vt, B, T1, rs1.Tp, C)
         h_f, h_p = ws.f32("Texp_f", rs2, C), ws.plane("Texp_p", rs2, C, split)
-        O.gemm(a=ra_p, b_ptr=vt.ptr, ldb=vt.ld, m=T2, n=C, batch=B, a_batch_stride=rs2.Tp * ra_p.ld, b_batch_stride=C * vt.ld,
-               rowmask_ptr=len2.data_ptr(), rowmask_batch_stride=rs2.Tp, out_f32_ptr=h_f.ptr, ldo=C, out_batch_stride=rs2.Tp * C,
-               out_plane=h_p, outb_batch_stride=rs2.Tp * h_p.ld)
+        if m._fused_expand(T1):
+            # alpha' produced in registers inside the expand contraction (efts_expand); the backward packs its own operands from
+            # the fp32 alpha' kept here
+            if self.mark is not None:
+                self.mark("fwd_alignment_done")
+            O.expand(e=e, tl=tl, ml=ml, sigma=float(m.sigma), v=val_f, rs1=rs1, rs2=rs2, alpha_out=ralpha, y_f32=h_f, y=h_p)
+        else:
+            ra_p = ws.plane("Tra_p", rs2, T1, 2)
+            O.reconst_alpha(e, tl, ml, float(m.sigma), ralpha, ra_p, B, T1, T2, rs2.Tp)
+            if self.mark is not None:
+                self.mark("fwd_alignment_done")
+            vt = ws.raw_plane("Tvt", B * C + 136, T1, 2)
+            O.pack_vt(val_f, vt, B, T1, rs1.Tp, C)
+            O.gemm(a=ra_p, b_ptr=vt.ptr, ldb=vt.ld, m=T2, n=C, batch=B, a_batch_stride=rs2.Tp * ra_p.ld, b_batch_stride=C * vt.ld,
+                   rowmask_ptr=len2.data_ptr(), rowmask_batch_stride=rs2.Tp, out_f32_ptr=h_f.ptr, ldo=C, out_batch_stride=rs2.Tp * C,
+                   out_plane=h_p, outb_batch_stride=rs2.Tp * h_p.ld)
         d_f, d_p, dec_saved = self._stack_fwd(ws, "dec", "decoder", pk, rs2, h_f, h_p, gap2.data_ptr(), split)
         if self.mark is not None:
             self.mark("fwd_decoder_done")

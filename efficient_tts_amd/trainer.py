@@ -105,8 +105,11 @@ class EfficientTTSTrainer:
         n_frames = int(self.frontend.frames_of(third_lengths).max())
         # default buckets: ragged LJSpeech batches otherwise bring a new (B, T1, T2) almost every step, and every new shape
         # allocates and zero-fills a multi-GB activation workspace (4 are cached); 0 in the YAML turns the padding off
-        frame_step = int(self.config.get("bucket_frames", 64))
-        phone_step = int(self.config.get("bucket_phones", 16))
+        # With an UNMASKED FastSpeechLoss (use_masking=False, the reference ctor default) the losses are means over the padded
+        # tensors: extra padding would change their denominators and add |0 - pad| terms, so bucketing defaults to off there.
+        masked = bool(getattr(self._net, "use_masking", True))
+        frame_step = int(self.config.get("bucket_frames", 64 if masked else 0))
+        phone_step = int(self.config.get("bucket_phones", 16 if masked else 0))
         if frame_step > 0:
             n_frames = -(-n_frames // frame_step) * frame_step
         mel, mel_lengths = self.frontend(third, third_lengths, max_frames=n_frames)
@@ -137,6 +140,8 @@ class EfficientTTSTrainer:
         if load_only_params:
             return
         self.steps, self.epochs = payload["steps"], payload["epochs"]
+        net.dropout_calls = int(self.steps)       # position in the counter-based dropout mask sequence: one draw per training step,
+                                                  # so --resume continues the sequence instead of replaying it (no extra checkpoint key)
         self.optimizer.load_state_dict(payload["optimizer"])
         if self.scheduler is not None and "scheduler" in payload:
             self.scheduler.load_state_dict(payload["scheduler"])

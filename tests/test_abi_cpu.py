@@ -37,20 +37,24 @@ def test_version_and_argument_errors(lib):
 
 
 def test_args_layouts_match_header():
-    """sizeof and the offsets of the round-2 fields of efts_gemm_args / efts_resconv5_args as compiled by gcc == the ctypes mirrors."""
+    """sizeof and field offsets of every argument struct of the ABI as compiled by gcc == the ctypes mirrors."""
     import subprocess, tempfile, ctypes
-    fields_g = ["out_bf16_lo", "tiling", "sign_mask", "soft_index", "key_len", "query_len"]
-    fields_r = ["x", "x_lo", "x_f32", "w", "split", "rowmask", "y_f32", "y", "y_lo", "y_split", "plan"]
-    src = '#include <stdio.h>\n#include <stddef.h>\n#include "efts_abi.h"\nint main(){printf("%zu %zu", sizeof(efts_gemm_args), sizeof(efts_resconv5_args));\n'
-    src += "".join(f'printf(" %zu", offsetof(efts_gemm_args, {f}));' for f in fields_g)
-    src += "".join(f'printf(" %zu", offsetof(efts_resconv5_args, {f}));' for f in fields_r)
+    structs = {
+        "efts_gemm_args": (L.GemmArgs, ["out_bf16_lo", "tiling", "sign_mask", "soft_index", "key_len", "query_len", "drop_p", "drop_seed"]),
+        "efts_resconv5_args": (L.ResConv5Args, ["x", "x_lo", "x_f32", "w", "split", "rowmask", "y_f32", "y", "y_lo", "y_split", "plan"]),
+        "efts_frame_linear_args": (L.FrameLinearArgs, ["x", "w", "bias", "act", "B", "n", "y_f32", "y", "y_lo", "ldy", "y_split"]),
+        "efts_expand_args": (L.ExpandArgs, ["e", "text_len", "mel_len", "sigma", "v", "ldv", "B", "n", "alpha_out", "y_f32", "ldo", "y", "y_lo", "ldy", "y_split"]),
+    }
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "efts_abi.h"\nint main(){\n'
+    want = []
+    for name, (cls, fields) in structs.items():
+        src += f'printf(" %zu", sizeof({name}));' + "".join(f'printf(" %zu", offsetof({name}, {f}));' for f in fields) + "\n"
+        want += [ctypes.sizeof(cls)] + [getattr(cls, f).offset for f in fields]
     src += "return 0;}\n"
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
         got = [int(v) for v in subprocess.check_output([os.path.join(d, "s")]).split()]
-    want = [ctypes.sizeof(L.GemmArgs), ctypes.sizeof(L.ResConv5Args)]
-    want += [getattr(L.GemmArgs, f).offset for f in fields_g] + [getattr(L.ResConv5Args, f).offset for f in fields_r]
     assert got == want
 
 

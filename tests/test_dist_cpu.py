@@ -102,3 +102,35 @@ def test_warmup_lr_matches_closed_form():
         assert abs(opt.param_groups[0]["lr"] - O.warmup_lr(1e-3, step, 4000)) < 1e-15
         opt.step()
         sch.step()
+
+
+def test_dp_selfcheck_fingerprint_and_rccl_log_parsing(tmp_path, monkeypatch):
+    """bench.py --workload train32 --gpus N validates itself before timing (efficient_tts_amd/bench_train.py): the exact
+    parameter fingerprint that is all-gathered across ranks must notice a 1-ulp difference and a permutation, and the RCCL log
+    reader must pick the topology / algorithm lines out of an NCCL_DEBUG_FILE."""
+    from efficient_tts_amd.bench_train import _params_fingerprint, _rccl_log_lines
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+    dev = torch.device("cpu")
+    f0 = _params_fingerprint(m, dev)
+    assert torch.equal(f0, _params_fingerprint(m, dev))
+    with torch.no_grad():
+        w = m[0].weight
+        w.view(-1)[3] = torch.nextafter(w.view(-1)[3], torch.tensor(10.0))           # one ulp
+    f1 = _params_fingerprint(m, dev)
+    assert not torch.equal(f0, f1)
+    with torch.no_grad():
+        a, b = w.view(-1)[0].clone(), w.view(-1)[1].clone()
+        w.view(-1)[0], w.view(-1)[1] = b, a                                          # same multiset, different order
+    f2 = _params_fingerprint(m, dev)
+    assert int(f2[0]) == int(f1[0]) and int(f2[1]) != int(f1[1])
+    log = tmp_path / "rccl_host_123.log"
+    log.write_text("host:123:1 [0] NCCL INFO NCCL version 2.22.3+hip6.3\n"
+                   "host:123:1 [0] NCCL INFO Channel 00/08 : 0 1 2 3 4 5 6 7\n"
+                   "host:123:1 [0] NCCL INFO something unrelated\n"
+                   "host:123:1 [0] NCCL INFO AllReduce: 36441248 Bytes -> Algo 1 proto 2 time 310.2\n")
+    monkeypatch.setenv("NCCL_DEBUG_FILE", str(tmp_path / "rccl_%h_%p.log"))
+    lines = _rccl_log_lines()
+    assert lines and any("Algo 1 proto 2" in ln for ln in lines) and not any("unrelated" in ln for ln in lines)
+    monkeypatch.delenv("NCCL_DEBUG_FILE")
+    assert _rccl_log_lines() is None

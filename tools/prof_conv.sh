@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 TAG=${1:-r01}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-BENCH="python $R/bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --parity-mode 0 --call-modes 0 --precision ${PREC:-bf16} --workload ${WL:-fwd64} ${BARGS:-}"
+BENCH="python $R/bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --parity-mode 0 --call-modes 0 --measure-traffic 0 --train-record 0 --precision ${PREC:-bf16} --workload ${WL:-fwd64} ${BARGS:-}"
 timeout -k 5 200 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $BENCH > $OUT/trace.log 2>&1
 if [ -z "$NOPMC" ]; then
 timeout -k 5 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/pmc_sq -o bench -- $BENCH > $OUT/pmc_sq.log 2>&1
