@@ -146,6 +146,7 @@ struct ExArgs {
     char* y_lo;
     long ldv, ldo, ldy;
     int T1, T1p, T2, T2p, n, y_split;
+    int rsplit;            // workgroups per (item, channel slice): the 32-frame blocks are dealt round-robin over rsplit x 8 waves
     float sigma;
 };
 
@@ -161,7 +162,8 @@ __global__ __launch_bounds__(512, 2) void expand_kernel(ExArgs p) {
     float* const km = es + 16 * KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
     const int ncq = p.n / (32 * NCB);
-    const int b = blockIdx.x / ncq, cq = blockIdx.x - b * ncq;
+    const int rpart = blockIdx.x % p.rsplit, bc = blockIdx.x / p.rsplit;
+    const int b = bc / ncq, cq = bc - b * ncq;
     const int c0 = cq * 32 * NCB;
     const int tl = p.tlen ? min(p.tlen[b], p.T1) : p.T1;
     const int ml = p.mlen ? min(p.mlen[b], p.T2) : p.T2;
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void expand_kernel(ExArgs p) {
 
     char* const st = smem + VF_BYTES + wave * 8192;
     const int nrb = (p.T2 + 31) >> 5;
-    for (int rb = wave; rb < nrb; rb += 8) {
+    for (int rb = rpart * 8 + wave; rb < nrb; rb += 8 * p.rsplit) {
         const int j = rb * 32 + lrow;
         const bool live = j < ml;
         const float q = live ? (float)j : 0.f;                 // (:366-367) padded frames sit at position 0, then are zeroed
@@ -303,6 +305,52 @@ extern "C" int efts_imv_align(const float* soft_idx, const int32_t* text_len, co
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// efts_duration_positions: the glue between the two phases of free-running synthesis in ONE launch -- per item the
+// cumulative sum of the predicted durations (the aligned positions e, efficient_tts.py:260), the mel length
+// round(e[len - 1]) (:270 / :361, round-half-to-even like torch.round) and, for delta_e_method_1 = False, positions that
+// start at 0 (:261-265).  Replaces a slice copy, efts_cumsum_rows, a gather, a round, two casts and a subtraction.  The scan
+// is efts_cumsum_rows' (256 threads, contiguous chunks, wave scans combined in wave order): same sums, bit for bit.
+// ---------------------------------------------------------------------------------------------------------------
+namespace efts {
+__global__ __launch_bounds__(256) void dur_positions_kernel(const float* __restrict__ dur, long ld, const int* __restrict__ tlen, float force,
+                                                            int method1, float* __restrict__ e, int* __restrict__ mlen, int T) {
+    __shared__ float sh[4];
+    __shared__ float last;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tl = min(tlen[b], T);
+    const float* xr = dur + (long)b * ld;
+    float* yr = e + (long)b * T;
+    auto x = [&](int j) { return force >= 0.f ? (j < tl ? force : 0.f) : xr[j]; };
+    const int chunk = (T + 255) / 256;
+    const int j0 = tid * chunk, j1 = min(j0 + chunk, T);
+    float loc = 0.f;
+    for (int j = j0; j < j1; ++j) loc += x(j);
+    const float incl = wave_scan_incl(loc);
+    if (lane == 63) sh[w] = incl;
+    if (tid == 0) last = 0.f;
+    __syncthreads();
+    float base = 0.f;
+    for (int i = 0; i < w; ++i) base += sh[i];
+    float run = base + incl - loc;
+    for (int j = j0; j < j1; ++j) {
+        const float d = x(j);
+        run += d;
+        yr[j] = method1 ? run : run - d;
+        if (j == tl - 1) last = run;
+    }
+    __syncthreads();
+    if (tid == 0) mlen[b] = (int)rintf(last);
+}
+}  // namespace efts
+
+extern "C" int efts_duration_positions(const float* dur, int64_t ld, const int32_t* text_len, float force_delta, int32_t method1, float* e,
+                                       int32_t* mel_len, int32_t B, int32_t T1, void* stream) {
+    if (!dur || !text_len || !e || !mel_len || B <= 0 || T1 <= 0 || ld < T1) return efts_fail(EFTS_EINVAL, "efts_duration_positions: bad arguments");
+    hipLaunchKernelGGL(dur_positions_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dur, (long)ld, text_len, force_delta, method1 ? 1 : 0, e, mel_len, T1);
+    return efts_check_launch("efts_duration_positions");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // efts_bf16_round: the fp32 -> bf16 rounding every operand-plane producer of this library applies (mode 0; gfx950's
 // v_cvt_pk_bf16_f32) next to its integer reference form (mode 1), so that a test can sweep bit patterns through both.
 // ---------------------------------------------------------------------------------------------------------------
@@ -341,12 +389,19 @@ extern "C" int efts_expand(const efts_expand_args* a, void* stream) {
         (void)hipFuncSetAttribute((const void*)expand_kernel<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
+    // small batches: several workgroups per (item, channel slice) share its 32-frame blocks, so that one utterance still covers
+    // a few dozen CUs (each re-reads the item's V slice, 64 KiB: nothing next to the launch's latency)
+    const int ncq = a->T1 <= 128 ? a->n / 128 : a->n / 64, nrb = (a->T2 + 31) / 32;
+    int rs = efts_num_cus() / (a->B * ncq);                   // (one workgroup per CU: 128 KiB of LDS each)
+    rs = rs < 1 ? 1 : rs;
+    if (rs > (nrb + 7) / 8) rs = (nrb + 7) / 8;
+    k.rsplit = rs;
     if (a->T1 <= 128) {
         const size_t lds = 8 * 4 * 2048 + 8 * 8192 + 2 * 16 * 8 * sizeof(float);
-        hipLaunchKernelGGL((expand_kernel<8, 4>), dim3(a->B * (a->n / 128)), dim3(512), lds, (hipStream_t)stream, k);
+        hipLaunchKernelGGL((expand_kernel<8, 4>), dim3(a->B * ncq * rs), dim3(512), lds, (hipStream_t)stream, k);
     } else {
         const size_t lds = 16 * 2 * 2048 + 8 * 8192 + 2 * 16 * 16 * sizeof(float);
-        hipLaunchKernelGGL((expand_kernel<16, 2>), dim3(a->B * (a->n / 64)), dim3(512), lds, (hipStream_t)stream, k);
+        hipLaunchKernelGGL((expand_kernel<16, 2>), dim3(a->B * ncq * rs), dim3(512), lds, (hipStream_t)stream, k);
     }
     return efts_check_launch("efts_expand");
 }

@@ -522,7 +522,17 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     // ---- which kernel.  `tiling` AUTO (0) applies the measured rules below; the explicit values exist for A/B runs and
     // for the bit-equality tests between the kernels (they all compute identical results).
     const int tiling = a->tiling;
-    if (tiling < EFTS_TILING_AUTO || tiling > EFTS_TILING_RESIDENT) return efts_fail(EFTS_EINVAL, "efts_gemm: unknown tiling %d", tiling);
+    if (tiling < EFTS_TILING_AUTO || tiling > EFTS_TILING_SMALLM) return efts_fail(EFTS_EINVAL, "efts_gemm: unknown tiling %d", tiling);
+    // (0) short row spaces on request (never AUTO: the K dimension is split across the waves, so the summation order -- not the
+    //     operand rounding -- differs from the ring kernels): 64 x 32 tiles, fragments straight from global memory
+    if (tiling == EFTS_TILING_SMALLM) {
+        if (a->batch != 1 || nb2 != 1 || dil != 1 || !(a->taps == 1 || a->taps == 3 || a->taps == 5) || a->n % 32 || a->plane_act || a->act == EFTS_ACT_TANH ||
+            a->out_bf16_lo || a->sign_mask || a->soft_index || k.drop_thresh || !k.vec_ok || (a->out_bf16 && ((a->ldob & 15) || ((uintptr_t)a->out_bf16 & 15))) ||
+            (a->ldo & 3) || (a->ldr & 3) || a->n % 8)
+            return efts_fail(EFTS_ESHAPE, "efts_gemm: the small-M tiling takes one dense 1 / 3 / 5-tap launch, n %% 32 == 0, 16-byte aligned rows, plain outputs");
+        if (launch_smallm_any(a->split, a->taps, st, k)) return efts_check_launch("efts_gemm");
+        return efts_fail(EFTS_ESHAPE, "efts_gemm: no small-M instantiation for taps %d", a->taps);
+    }
     const bool generic_only = a->out_bf16_lo != nullptr || nb2 > 1 || a->soft_index != nullptr;      // the remainder plane / the outer batch / the soft index: gemm_kernel only
     const bool no_narrow = generic_only || a->sign_mask != nullptr || k.drop_thresh != 0;      // sign words / dropout: gemm_kernel and conv5_kernel only
     if (generic_only && tiling > EFTS_TILING_GENERIC) return efts_fail(EFTS_EINVAL, "efts_gemm: out_bf16_lo / batch2 need the generic tiling");

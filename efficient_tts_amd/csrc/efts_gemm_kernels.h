@@ -61,6 +61,8 @@ constexpr int C8_LDS = C5_A_BYTES + NST * C8_W_BYTES;            // 131072
 // efts_gemm_narrow.hip: false = no instantiation for this tap count
 bool launch_narrow_any(int split, int bnt, int taps, dim3 grid, hipStream_t st, const GemmKernelArgs& k);
 bool launch_resident32_any(int split, int taps, dim3 grid, hipStream_t st, const GemmKernelArgs& k);
+// efts_smallm.hip: false = no instantiation for this tap count
+bool launch_smallm_any(int split, int taps, hipStream_t st, const GemmKernelArgs& k);
 // efts_conv5.hip
 void launch_conv5_any(int split, dim3 grid, hipStream_t st, const GemmKernelArgs& k);
 void conv5_set_lds_attr();

@@ -30,10 +30,11 @@ class GraphCache:
     def clear(self) -> None:
         self.entries.clear()
 
-    def run(self, key: tuple, tag, inputs: Sequence[torch.Tensor], fn: Callable[..., Tuple[torch.Tensor, ...]], keepalive=None):
+    def run(self, key: tuple, tag, inputs: Sequence[torch.Tensor], fn: Callable[..., Tuple[torch.Tensor, ...]], keepalive=None, clone: bool = True):
         """fn(*inputs) -> tuple of tensors, pure device work on the current stream (no host sync).  `tag` invalidates the
         captured graph when it changes (the buffers the launches point at were re-allocated); `keepalive` is held as long as
-        the graph is (the owner of those buffers)."""
+        the graph is (the owner of those buffers).  clone=False returns the graph's static output tensors themselves (valid until
+        the next replay of this entry) instead of fresh copies."""
         ent = self.entries.get(key)
         if ent is None:
             ent = self.entries[key] = _Entry()
@@ -64,4 +65,4 @@ class GraphCache:
             for s, t in zip(ent.static_in, inputs):
                 s.copy_(t, non_blocking=True)
         ent.graph.replay()
-        return tuple(t.clone() for t in ent.static_out)
+        return tuple(ent.static_out) if not clone else tuple(t.clone() for t in ent.static_out)

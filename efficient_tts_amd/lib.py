@@ -19,7 +19,7 @@ GUARD_HI = 144
 TILE_M = 128
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 ACT_BWD_BIAS_PARTS = 16
-TILING_AUTO, TILING_GENERIC, TILING_WIDE, TILING_NARROW, TILING_RESIDENT = 0, 1, 2, 3, 4
+TILING_AUTO, TILING_GENERIC, TILING_WIDE, TILING_NARROW, TILING_RESIDENT, TILING_SMALLM = 0, 1, 2, 3, 4, 5
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -89,6 +89,7 @@ _SIGS = {
     "efts_cumsum_rows": (i32, [vp, vp, i32, i32, vp]),
     "efts_imv_align": (i32, [vp, vp, vp, f32, f32, i32, vp, vp, vp, i32, i32, i32, vp]),
     "efts_expand": (i32, [C.POINTER(ExpandArgs), vp]),
+    "efts_duration_positions": (i32, [vp, i64, vp, f32, i32, vp, vp, i32, i32, vp]),
     "efts_bf16_round": (i32, [vp, vp, i64, i32, vp]),
     "efts_layernorm_rows": (i32, [vp, vp, vp, f32, vp, vp, vp, i64, i32, i32, i32, f32, C.c_uint32, vp]),
     "efts_layernorm_dot": (i32, [vp, vp, vp, f32, vp, vp, vp, i32, f32, vp, i32, i32, f32, C.c_uint32, vp]),

@@ -196,6 +196,8 @@ class EfficientTTSCNN(torch.nn.Module):
         self.duration_predictor = _DurationPredictor(n_channels, n_duration_layer, n_channels, offset=duration_offset)
         self.fuse_prenet = True             # the prenet straight from the fp32 frames (efts_frame_linear); False: efts_pack_rows + efts_gemm
         self.fuse_soft_index = True         # T1 <= 128: q.k^T, softmax and soft index in one launch (False: scores stored, efts_attn_soft_index)
+        self.small_m = True                 # free-running inference on short row spaces (<= SMALL_M_ROWS rows): the K-split small-M tiling of efts_gemm
+        self._free_running = False          # set while inference() / inference_batch() enqueue their launches
         self.merge_text = True              # text-encoder layers ride in the persistent launches of the mel-encoder layers (efts_resconv5_multi)
         self.fuse_align = True              # imv scan + aligned positions + duration target in one launch (efts_imv_align)
         self.fuse_expand = True             # T1 <= 256: alpha' generated in registers inside the expand contraction (efts_expand); False: reconst_alpha + pack_vt + efts_gemm
@@ -331,6 +333,15 @@ class EfficientTTSCNN(torch.nn.Module):
     # 8-wave workgroup per CU); shorter ones keep the fp32 stream + efts_gemm, whose 124-row tiles fill the chip better
     RESCONV_MIN_ROWS = 16384
 
+    SMALL_M_ROWS = 1024
+
+    def _til(self, rows: int):
+        """efts_gemm tiling for a 512-column launch over `rows` rows: the small-M kernel (64 x 32 tiles, K split across the waves:
+        ~4x shorter dependent chain per layer) for one-utterance row spaces of the free-running path, else the library's rules"""
+        if self._free_running and self.small_m and rows <= self.SMALL_M_ROWS and self.n_channels % 32 == 0:
+            return L.TILING_SMALLM
+        return None
+
     def _on_resconv(self, rs: Rows) -> bool:
         return self.resconv and rs.rows >= self.RESCONV_MIN_ROWS and self.n_channels % 256 == 0
 
@@ -387,7 +398,7 @@ class EfficientTTSCNN(torch.nn.Module):
             O.gemm(a=x_pl, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=5, m=rs.rows, n=C,
                    act=L.ACT_LEAKY, slope=self.slope, bias=getattr(self, blk).layers[i].conv[0].bias,
                    resid_ptr=x_f32.ptr, ldr=C, rowmask_ptr=gap_ptr,
-                   out_f32_ptr=None if o_f32 is None else o_f32.ptr, ldo=C, out_plane=o_pl)
+                   out_f32_ptr=None if o_f32 is None else o_f32.ptr, ldo=C, out_plane=o_pl, tiling=self._til(rs.rows))
             x_f32, x_pl = o_f32, o_pl
         return x_f32, x_pl
 
@@ -412,7 +423,7 @@ class EfficientTTSCNN(torch.nn.Module):
         key_p = ws.plane("key_p", rs1, C, 2)
         wk = pk["key"]
         O.gemm(a=h_p, b_ptr=wk.ptr, ldb=wk.ld, m=rs1.rows, n=C, bias=self.text_encoder_key.bias,
-               rowmask_ptr=(gap1 if len1 is None else len1).data_ptr(), out_plane=key_p)
+               rowmask_ptr=(gap1 if len1 is None else len1).data_ptr(), out_plane=key_p, tiling=self._til(rs1.rows))
         return key_p
 
     def _value_proj(self, ws, pk, rs1: Rows, h_p: Plane, gap1, len1, vt: Optional[Plane] = None):
@@ -424,7 +435,7 @@ class EfficientTTSCNN(torch.nn.Module):
         wv = pk["key"] if shared else pk["value"]
         vbias = self.text_encoder_key.bias if shared else self.text_encoder_value.bias
         O.gemm(a=h_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=vbias,
-               rowmask_ptr=(gap1 if len1 is None else len1).data_ptr(), out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p)
+               rowmask_ptr=(gap1 if len1 is None else len1).data_ptr(), out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p, tiling=self._til(rs1.rows))
         if vt is not None:
             O.pack_vt(val_f, vt, rs1.B, rs1.T, rs1.Tp, C)
         return val_f, val_p
@@ -439,7 +450,7 @@ class EfficientTTSCNN(torch.nn.Module):
         for i, seq in enumerate(dp.conv):
             w = pk[f"dur.{i}"]
             O.gemm(a=x_p, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=3, m=rs1.rows, n=C, act=L.ACT_RELU,
-                   bias=seq[0].bias, out_f32_ptr=h_f.ptr, ldo=C)
+                   bias=seq[0].bias, out_f32_ptr=h_f.ptr, ldo=C, tiling=self._til(rs1.rows))
             ln = seq[2]
             if i + 1 < len(dp.conv):
                 x_p = ws.plane(f"dur_p{i}", rs1, C, self.split)
@@ -665,6 +676,13 @@ class EfficientTTSCNN(torch.nn.Module):
     @torch.no_grad()
     def inference(self, text: torch.Tensor, text_lengths: torch.Tensor = None):
         """Free-running synthesis of ONE utterance: returns (mel_pred[1,T2,odim], reconst_alpha[1,T1,T2])."""
+        prev, self._free_running = self._free_running, True
+        try:
+            return self._inference_impl(text, text_lengths)
+        finally:
+            self._free_running = prev
+
+    def _inference_impl(self, text: torch.Tensor, text_lengths: torch.Tensor = None):
         self._require(text)
         if text.shape[0] != 1:
             raise ValueError("inference() takes one utterance, like the reference (efficient_tts.py:361); "
@@ -725,17 +743,12 @@ class EfficientTTSCNN(torch.nn.Module):
         shared = self.share_text_encoder_key_value            # (:252-253)
         wv = pk["key"] if shared else pk["value"]
         O.gemm(a=h_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=(self.text_encoder_key if shared else self.text_encoder_value).bias,
-               rowmask_ptr=len1.data_ptr(), out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p)
+               rowmask_ptr=len1.data_ptr(), out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p, tiling=self._til(rs1.rows))
         delta = self._duration(ws, pk, rs1, val_p, len1, len1.data_ptr(), 1)          # zero beyond each length
-        d2 = delta.view(B, rs1.Tp)[:, :T1].contiguous()
-        if force_delta is not None:
-            d2 = (torch.arange(T1, device=dev)[None, :] < tl[:, None]).to(torch.float32) * float(force_delta)
+        # durations -> positions e = cumsum, mel lengths round(e[len - 1]) (:260, :270), positions from 0 for method 2 (:261-265)
         e = torch.empty(B, T1, dtype=torch.float32, device=dev)
-        O.cumsum_rows(d2, e, B, T1)
-        last = e.gather(1, (tl.long() - 1).clamp(min=0)[:, None]).squeeze(1)
-        ml = torch.round(last).to(torch.int32)
-        if not self.delta_e_method_1:                                             # efficient_tts.py:261-265 + trim_e: positions start at 0
-            e = e - d2
+        ml = torch.empty(B, dtype=torch.int32, device=dev)
+        O.duration_positions(delta, rs1.Tp, tl, force_delta, self.delta_e_method_1, e, ml, B, T1)
         return e, ml
 
     def _infer_mel(self, ws, ws2, e, tl, ml, T2: int):
@@ -770,6 +783,13 @@ class EfficientTTSCNN(torch.nn.Module):
 
         force_delta (benchmark hook): the duration predictor still runs, but every
         valid phoneme then gets this many frames, so a synthetic batch yields a known, equal T2."""
+        prev, self._free_running = self._free_running, True
+        try:
+            return self._inference_batch_impl(text, text_lengths, force_delta)
+        finally:
+            self._free_running = prev
+
+    def _inference_batch_impl(self, text, text_lengths, force_delta):
         self._require(text)
         with O.stream_scope():
             dev = text.device
@@ -780,13 +800,15 @@ class EfficientTTSCNN(torch.nn.Module):
             if T1b != T1:
                 text = torch.nn.functional.pad(text, (0, T1b - T1))
             pk = self._weights()
-            wsig = (self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.RESCONV_MIN_ROWS, self.fuse_expand)
+            wsig = (self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.RESCONV_MIN_ROWS, self.fuse_expand, self.small_m, self.SMALL_M_ROWS)
             ws = self._workspace(("infb", B, T1b), dev)
             if graphs:
                 def phase1(t, l):
                     with O.stream_scope():              # resolved INSIDE the capture: the launches must go to the capturing stream
                         return self._infer_text(ws, t, l, force_delta)
-                e, ml = self._infer_cache.run(("text", B, T1b, force_delta), (ws.serial, wsig), (text.contiguous(), tl), phase1, keepalive=ws)
+                # (the graph's static outputs are handed on as they are: phase 2 copies them into ITS static inputs before anything
+                # can overwrite them, and nothing else keeps them)
+                e, ml = self._infer_cache.run(("text", B, T1b, force_delta), (ws.serial, wsig), (text.contiguous(), tl), phase1, keepalive=ws, clone=False)
             else:
                 e, ml = self._infer_text(ws, text, tl, force_delta)
             t2 = int(ml.max().item())                                                      # the one host sync

@@ -351,6 +351,12 @@ def cumsum_rows(x, y, B, T) -> None:
     L.check(L.load().efts_cumsum_rows(x.data_ptr(), y.data_ptr(), B, T, _stream()), "efts_cumsum_rows")
 
 
+def duration_positions(dur: torch.Tensor, ld: int, tl, force_delta, method1: bool, e, ml, B, T1) -> None:
+    """cumsum of the durations -> positions e, mel lengths ml = round(e[len - 1]) (efts_duration_positions)"""
+    L.check(L.load().efts_duration_positions(dur.data_ptr(), ld, tl.data_ptr(), -1.0 if force_delta is None else float(force_delta), int(method1),
+                                             e.data_ptr(), ml.data_ptr(), B, T1, _stream()), "efts_duration_positions")
+
+
 def layernorm_rows(x_ptr, gamma, beta, eps, rowmask_ptr, out_f32_ptr, plane: Optional[Plane], rows, c, drop_p: float = 0.0,
                    drop_seed: int = 0) -> None:
     L.check(L.load().efts_layernorm_rows(x_ptr, gamma.data_ptr(), beta.data_ptr(), eps, rowmask_ptr, out_f32_ptr,

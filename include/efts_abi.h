@@ -115,7 +115,7 @@ typedef struct efts_gemm_args {
      * out - bf16(out), so that a consumer can rebuild out to 16 mantissa bits (the residual input of efts_resconv5). */
     void* out_bf16_lo;
     /* which of the (bit-identical) kernels runs: EFTS_TILING_AUTO picks by shape; the explicit values are for A/B timing and
-     * for the equality tests between the kernels.  An explicit tiling the shape does not allow is an error. */
+     * for the equality tests between the kernels (EFTS_TILING_SMALLM excepted, see below).  An explicit tiling the shape does not allow is an error. */
     int32_t tiling;
     /* training forward of a LeakyReLU / ReLU layer: the sign of every activated output BEFORE the residual add, as bit words
      * for efts_act_bwd mode 4 (instead of keeping y and x in fp32 for the backward: 1/8 B instead of 8 B per element read
@@ -144,6 +144,10 @@ typedef struct efts_gemm_args {
 #define EFTS_TILING_WIDE 2     /* 252-row x 128-column tiles: dense k5 launches */
 #define EFTS_TILING_NARROW 3   /* 64- / 32-column tiles */
 #define EFTS_TILING_RESIDENT 4 /* window + all taps resident in LDS: n <= 64, one K chunk, taps 3 / 7 / 11 */
+#define EFTS_TILING_SMALLM 5   /* short row spaces (one utterance): 64 x 32 tiles, K split across the four waves, operand fragments
+                                * straight from global memory; taps 1 / 3 / 5, batch 1, n % 32 == 0, the A plane readable up to the next
+                                * multiple of 64 rows (+ pad).  Same operand rounding as the other tilings but a different summation
+                                * order (equal to fp32 rounding, not bit for bit): never chosen by AUTO, the caller asks for it */
 
 int efts_gemm(const efts_gemm_args* a, void* stream);
 
@@ -323,6 +327,13 @@ typedef struct efts_expand_args {
     int32_t y_split;
 } efts_expand_args;
 int efts_expand(const efts_expand_args* a, void* stream);
+
+/* Between the two phases of free-running synthesis (efficient_tts.py:258-270), one launch per batch: e[b][i] = cumulative sum of
+ * the durations dur[b * ld + i] (i < T1; efts_cumsum_rows' scan), mel_len[b] = round-half-even(e[b][text_len[b] - 1]), and with
+ * method1 == 0 the positions start at 0 (e[b][i] -= dur[b][i], :261-265).  force_delta >= 0 replaces every valid duration by that
+ * value (benchmark hook: a synthetic batch then yields a known mel length); < 0: off. */
+int efts_duration_positions(const float* dur, int64_t ld, const int32_t* text_len, float force_delta, int32_t method1, float* e,
+                            int32_t* mel_len, int32_t B, int32_t T1, void* stream);
 
 /* The fp32 -> bf16 rounding of every operand-plane producer in this library (round to nearest even; torch's
  * .to(torch.bfloat16)): mode 0 = as the kernels do it (gfx950's packed conversion instruction), mode 1 = the integer

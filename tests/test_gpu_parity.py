@@ -445,3 +445,63 @@ def test_frame_linear_equals_pack_rows_plus_gemm(split, shape):
         assert torch.equal(bf(yl), bf(l_ref))
     with pytest.raises(Exception):
         P.frame_linear(x=torch.randn(B, T, 130, device=dev), w=pw, bias=bias, act=L.ACT_LEAKY, slope=0.1, rs=rs, y=y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", [2, 1])
+@pytest.mark.parametrize("taps,cin,cout,B,T", [(5, 512, 512, 1, 86), (5, 512, 512, 1, 601), (3, 512, 512, 3, 70), (1, 512, 512, 2, 131), (5, 512, 512, 1, 1),
+                                              (1, 320, 96, 1, 64), (5, 64, 32, 2, 33)])
+def test_small_m_tiling_vs_fp64_and_the_ring_kernels(split, taps, cin, cout, B, T):
+    """EFTS_TILING_SMALLM (one-utterance row spaces: 64 x 32 tiles, K split across the four waves, fragments straight from global
+    memory) against fp64 and against the generic ring kernel on the same operands: same operand rounding, so the two agree to fp32
+    summation-order noise; bias, LeakyReLU / ReLU, residual, row mask, fp32 output and both operand-plane formats; gap rows zero."""
+    from efficient_tts_amd import lib as L, ops as P
+    dev = _dev()
+    g = torch.Generator().manual_seed(taps * 1000 + cin + T + 7)
+    x = torch.randn(B, T, cin, generator=g)
+    w = torch.randn(cout, cin, taps, generator=g) * 0.05
+    bias = torch.randn(cout, generator=g)
+    res = torch.randn(B, T, cout, generator=g)
+    rs = P.Rows(B, T)
+    a = P.Plane.for_rows(rs, cin, split, dev)
+    P.pack_rows(x.to(dev), None, a, rs)
+    pw = P.PackedWeight(cout, cin, taps, split, dev)
+    pw.pack(w.to(dev).contiguous())
+    resid = P.F32Rows(rs, cout, dev)
+    resid.view().copy_(res.to(dev))
+    gap = torch.zeros(rs.rows, device=dev)
+    P.row_masks(torch.full((B,), T, dtype=torch.int32, device=dev), rs, gap, None)
+    act = L.ACT_RELU if taps == 3 else L.ACT_LEAKY
+    outs = {}
+    for til in (L.TILING_SMALLM, L.TILING_GENERIC):
+        out = P.F32Rows(rs, cout, dev)
+        outp = P.Plane.for_rows(rs, cout, 3 - split, dev)          # the other plane format than the operands'
+        P.gemm(a=a, b_ptr=pw.ptr, ldb=pw.ld, b_tap_stride=pw.tap_stride, taps=taps, m=rs.rows, n=cout, act=act, slope=0.1, alpha=0.5,
+               bias=bias.to(dev), resid_ptr=resid.ptr, ldr=cout, rowmask_ptr=gap.data_ptr(), out_f32_ptr=out.ptr, ldo=cout, out_plane=outp,
+               tiling=til)
+        outs[til] = (out, outp)
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.conv1d(x.double().transpose(1, 2), w.double(), None, padding=(taps - 1) // 2) * 0.5 + bias.double()[None, :, None]
+    ref = torch.relu(ref) if taps == 3 else torch.nn.functional.leaky_relu(ref, 0.1)
+    ref = (res.double() + ref.transpose(1, 2)).float()
+    out, outp = outs[L.TILING_SMALLM]
+    got = out.view().cpu()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= (2e-5 if split == 2 else 2e-2) * scale
+    assert float((out.buf - outs[L.TILING_GENERIC][0].buf).abs().max()) <= 3e-6 * scale          # same operands, other summation order
+    full = out.buf.cpu()
+    assert float(full[:L.GUARD_LO].abs().max()) == 0.0
+    assert float(full[L.GUARD_LO:L.GUARD_LO + rs.rows].view(B, rs.Tp, cout)[:, T:].abs().max()) == 0.0
+    assert float(full[L.GUARD_LO + rs.rows:].abs().max()) == 0.0
+    # the operand plane holds the fp32 output to its format's precision
+    pl = outp.buf[L.GUARD_LO:L.GUARD_LO + rs.rows].view(torch.bfloat16)
+    if outp.split == 2:
+        pl = pl.view(rs.rows, outp.nchunk, 2, 32).float().cpu()
+        recon = (pl[:, :, 0] + pl[:, :, 1]).reshape(B, rs.Tp, outp.nchunk * 32)[:, :T, :cout]
+        assert float((recon - got).abs().max()) <= 2e-5 * scale
+    else:
+        recon = pl.float().cpu().view(B, rs.Tp, -1)[:, :T, :cout]
+        assert float((recon - got).abs().max()) <= 2.0 ** -8 * scale
+    with pytest.raises(ValueError):
+        P.gemm(a=a, b_ptr=pw.ptr, ldb=pw.ld, b_tap_stride=pw.tap_stride, taps=taps, m=rs.rows, n=cout - 8, out_f32_ptr=out.ptr, ldo=cout,
+               tiling=L.TILING_SMALLM)
