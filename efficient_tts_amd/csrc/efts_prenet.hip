@@ -41,9 +41,14 @@ __global__ __launch_bounds__(512, 2) void frame_linear_kernel(FlArgs p) {
     constexpr int WF_BYTES = KS * FL_NCB * SPLIT * 1024;     // weight fragments [KS][NCB][hi (, lo)][64 lanes][16 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
     const int ncq = p.n / (32 * FL_NCB);
-    const int b = blockIdx.x / ncq, cq = blockIdx.x - b * ncq;
-    const int c0 = cq * 32 * FL_NCB;
     const int ns = (p.cin + 15) >> 4;
+    // a workgroup takes the (item, channel slice) units blockIdx.x, blockIdx.x + gridDim.x, ...: one each by default; the caller may
+    // cap the grid (efts_frame_linear_args.max_workgroups) so that the launch leaves compute units to a concurrent one -- the
+    // kernel is bound by HBM, which half the CUs already saturate
+    for (int unit = blockIdx.x; unit < p.B * ncq; unit += gridDim.x) {
+    const int b = unit / ncq, cq = unit - b * ncq;
+    const int c0 = cq * 32 * FL_NCB;
+    if (unit != (int)blockIdx.x) __syncthreads();            // every wave is done with the previous unit's weight fragments
 
     // ---- 1. the 128 weight rows of this slice -> LDS, in the order the lanes read them: lane l of (slice s, block cb) holds
     // output column c0 + 32 cb + (l & 31), features 16 s + 8 (l >> 5) .. + 7
@@ -118,6 +123,7 @@ __global__ __launch_bounds__(512, 2) void frame_linear_kernel(FlArgs p) {
             sweep64<true>(acc[2 * hp], acc[2 * hp + 1], st, lane, o, (long)b * p.Tp + rb * 32, p.T - rb * 32, c0 + hp * 64, bv[2 * hp], bv[2 * hp + 1],
                           p.act, p.slope);
     }
+    }   // units
 }
 
 }  // namespace efts
@@ -140,7 +146,9 @@ extern "C" int efts_frame_linear(const efts_frame_linear_args* a, void* stream) 
     k.x = a->x; k.w = (const char*)a->w; k.bias = a->bias; k.y_f32 = a->y_f32; k.y = (char*)a->y; k.y_lo = (char*)a->y_lo;
     k.ldw = a->ldw; k.ldo = a->ldo; k.ldy = a->ldy; k.B = a->B; k.T = a->T; k.Tp = a->Tp; k.cin = a->cin; k.n = a->n;
     k.act = a->act; k.slope = a->slope; k.y_split = a->y ? a->y_split : 0;
-    const dim3 grid((unsigned)(a->B * (a->n / (32 * FL_NCB))));
+    int wgs = a->B * (a->n / (32 * FL_NCB));
+    if (a->max_workgroups > 0 && a->max_workgroups < wgs) wgs = a->max_workgroups;
+    const dim3 grid((unsigned)wgs);
 #define EFTS_FL(S, N)                                                                                                                \
     do {                                                                                                                             \
         static bool attr = false;                                                                                                    \

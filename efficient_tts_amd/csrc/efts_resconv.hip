@@ -361,6 +361,10 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, const RcProb& pq, const
     const unsigned vob = lrow0 * (unsigned)pq.ldob + (pq.out_split == 1 ? col0 * 2 : (col0 >> 5) * 128 + (col0 & 31) * 2);
     const unsigned sob_row = (unsigned)pq.ldob;
 
+    // (split-2 planes keep 64-byte hi / lo halves per instruction.  Measured and dropped: lanes 0-3 of a row on the hi slots and
+    // lanes 4-7 on the lo slots of the same 32 columns, words swapped through ds_bpermute, both lanes computing the same outputs --
+    // whole lines per instruction, but 292.6 -> 295.9 us per B = 64 launch: the doubled VALU / LDS work of the sweep costs more
+    // than the half-line requests.)
     // operands of unit u = (block row i = u >> 1, half hf = u & 1): two 8-row passes -- 8 residual values (fp32, or bf16 hi + lo)
     // and the row mask each; one unit is in flight ahead of the one being written out
     u32x4 xa[2][2], xb[2][2];

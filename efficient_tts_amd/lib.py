@@ -46,7 +46,7 @@ class FrameLinearArgs(C.Structure):
     """mirror of efts_frame_linear_args (include/efts_abi.h)"""
     _fields_ = [("x", vp), ("w", vp), ("ldw", i64), ("split", i32), ("bias", vp), ("act", i32), ("slope", f32),
                 ("B", i32), ("T", i32), ("Tp", i32), ("cin", i32), ("n", i32), ("y_f32", vp), ("ldo", i64), ("y", vp), ("y_lo", vp),
-                ("ldy", i64), ("y_split", i32)]
+                ("ldy", i64), ("y_split", i32), ("max_workgroups", i32)]
 
 
 class ExpandArgs(C.Structure):

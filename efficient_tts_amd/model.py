@@ -160,12 +160,14 @@ class EfficientTTSCNN(torch.nn.Module):
         super().__init__()
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {list(PRECISIONS)}")
-        if nonlinear_activation != "LeakyReLU":
-            raise NotImplementedError("the HIP conv epilogue implements LeakyReLU (the only activation any reference config uses)")
+        if nonlinear_activation not in ("LeakyReLU", "ReLU"):
+            raise NotImplementedError("the HIP conv epilogue implements LeakyReLU and ReLU (= slope 0); every reference config uses LeakyReLU")
         if symbol_embedding_dim != n_channels:
             raise ValueError("symbol_embedding_dim must equal n_channels (the reference adds them residually)")
-        if k_size != 5:
-            raise NotImplementedError("k_size must be 5 (row-space gap = 2)")
+        if k_size not in (1, 3, 5):
+            raise NotImplementedError("k_size must be 1, 3 or 5: the row space carries (5 - 1) / 2 = 2 zero gap rows between the items "
+                                      "(include/efts_abi.h EFTS_GAP); 5 (the value of every reference config) runs the mel-length stacks on "
+                                      "efts_resconv5, 1 and 3 on efts_gemm")
         if use_weighted_masking:
             raise NotImplementedError("FastSpeechLoss(use_weighted_masking=True) is not implemented (no shipped config selects it)")
         if n_channels % 256 or odim > 128:
@@ -177,7 +179,9 @@ class EfficientTTSCNN(torch.nn.Module):
         self.delta_e_method_1 = delta_e_method_1
         self.share_text_encoder_key_value = share_text_encoder_key_value
         self.use_masking = bool(use_masking)        # False (the reference ctor default): the two losses are means over the padded tensors
-        self.slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
+        self.k_size = int(k_size)
+        # LeakyReLU's own default slope is 0.01 (torch.nn.LeakyReLU); ReLU = slope 0 through the same epilogue
+        self.slope = float(nonlinear_activation_params.get("negative_slope", 0.01)) if nonlinear_activation == "LeakyReLU" else 0.0
         self.dropout_rate = dropout_rate
         a, ap = nonlinear_activation, nonlinear_activation_params
         # construction order == reference (efficient_tts.py:57-112) so a given torch seed
@@ -198,6 +202,7 @@ class EfficientTTSCNN(torch.nn.Module):
         self.fuse_soft_index = True         # T1 <= 128: q.k^T, softmax and soft index in one launch (False: scores stored, efts_attn_soft_index)
         self.small_m = True                 # free-running inference on short row spaces (<= SMALL_M_ROWS rows): the K-split small-M tiling of efts_gemm
         self._free_running = False          # set while inference() / inference_batch() enqueue their launches
+        self.share_cus = True               # merged mode: the prenet and the first text layers run side by side on disjoint halves of the CUs
         self.merge_text = True              # text-encoder layers ride in the persistent launches of the mel-encoder layers (efts_resconv5_multi)
         self.fuse_align = True              # imv scan + aligned positions + duration target in one launch (efts_imv_align)
         self.fuse_expand = True             # T1 <= 256: alpha' generated in registers inside the expand contraction (efts_expand); False: reconst_alpha + pack_vt + efts_gemm
@@ -343,7 +348,7 @@ class EfficientTTSCNN(torch.nn.Module):
         return None
 
     def _on_resconv(self, rs: Rows) -> bool:
-        return self.resconv and rs.rows >= self.RESCONV_MIN_ROWS and self.n_channels % 256 == 0
+        return self.resconv and rs.rows >= self.RESCONV_MIN_ROWS and self.n_channels % 256 == 0 and self.k_size == 5
 
     def _stream_in(self, ws, tag, rs: Rows):
         """Buffers the producer of a residual stack's input writes: (fp32 stream or None, operand plane, lo plane or None).
@@ -395,7 +400,7 @@ class EfficientTTSCNN(torch.nn.Module):
             o_split = last_split if last else self.split
             o_f32 = ws.f32(f"{tag}_f{i & 1}", rs, C) if (not last or last_f32) else None
             o_pl = ws.plane(f"{tag}_p{i & 1}", rs, C, o_split)
-            O.gemm(a=x_pl, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=5, m=rs.rows, n=C,
+            O.gemm(a=x_pl, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=self.k_size, m=rs.rows, n=C,
                    act=L.ACT_LEAKY, slope=self.slope, bias=getattr(self, blk).layers[i].conv[0].bias,
                    resid_ptr=x_f32.ptr, ldr=C, rowmask_ptr=gap_ptr,
                    out_f32_ptr=None if o_f32 is None else o_f32.ptr, ldo=C, out_plane=o_pl, tiling=self._til(rs.rows))
@@ -523,7 +528,7 @@ class EfficientTTSCNN(torch.nn.Module):
         key = ("fwd", tuple(text.shape), tuple(speech.shape), text.dtype, speech.dtype, text_lengths.dtype, speech_lengths.dtype)
         ws = self._workspace(("fwd", text.shape[0], text.shape[1], speech.shape[1]), dev)
         # the graph is valid while the buffers its launches point at live: this workspace, the packed planes, the parameters
-        tag = (ws.serial, self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.side_stream, self.RESCONV_MIN_ROWS, self.fuse_soft_index, self.fuse_prenet, self.fuse_align, self.fuse_expand, self.merge_text)
+        tag = (ws.serial, self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.side_stream, self.RESCONV_MIN_ROWS, self.fuse_soft_index, self.fuse_prenet, self.fuse_align, self.fuse_expand, self.merge_text, self.share_cus)
 
         def body(t, tl, sp, sl):
             (_, stats, imv, ralpha, mel_pred, _), _ = self._forward_impl(t, tl, sp, sl)
@@ -560,13 +565,13 @@ class EfficientTTSCNN(torch.nn.Module):
         merged = self.merge_text and self._on_resconv(rs2) and nt >= 1 and nm >= 1
         v_ready = torch.cuda.Event()
 
-        def prenet():                                                             # :161
+        def prenet(max_wgs=0):                                                    # :161
             pre_f, pre_p, pre_l = self._stream_in(ws, "pre", rs2)
             wp = pk["prenet"]
             if self.fuse_prenet and self.odim % 8 == 0 and self.odim <= 128 and C % 128 == 0:
                 # straight from the caller's fp32 frames: no operand plane of the mel input, one launch (bit-identical on every frame)
                 O.frame_linear(x=speech, w=wp, bias=self.mel_prenet[0].bias, act=L.ACT_LEAKY, slope=self.slope, rs=rs2,
-                               y=pre_p, y_lo=pre_l, y_f32=pre_f)
+                               y=pre_p, y_lo=pre_l, y_f32=pre_f, max_workgroups=max_wgs)
             else:
                 mel_in = ws.plane("mel_in", rs2, self.odim, self.split)
                 O.pack_rows(speech, None, mel_in, rs2)
@@ -594,9 +599,15 @@ class EfficientTTSCNN(torch.nn.Module):
             nr = min(nt, nm)
             ns = nt - nr                                                           # text layers that run by themselves first
             pre_ready, te_done = torch.cuda.Event(), torch.cuda.Event()
-            with O.on_stream(side):                                               # the HBM-bound prenet beside the first text layers
-                pre = prenet()
+            # The first text layers and the prenet share the chip by halves: both kinds of workgroup take a whole CU (LDS), the
+            # prenet is bound by HBM -- which half the CUs saturate -- and a text-length layer by streaming its weights, so the
+            # prenet's grid is capped at half the CUs and the text layers are scheduled onto the other half.
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            share = self.share_cus and ns > 0 and cus >= 64
+            with O.on_stream(side):
+                pre = prenet(cus // 2 if share else 0)
                 pre_ready.record(side)
+            te_plan = O.resconv5_plan_buf(rs1.rows, C, cus // 2 - 2) if share else None
             O.row_masks(tl, rs1, gap1, len1)                                      # :137
             x_f = ws.f32("emb_f", rs1, C)
             x_p = ws.plane("emb_p", rs1, C, self.split)
@@ -610,7 +621,7 @@ class EfficientTTSCNN(torch.nn.Module):
                 return kw
 
             for i in range(ns):
-                O.resconv5(**text_layer(i))
+                O.resconv5(plan=te_plan, **text_layer(i))
             main.wait_event(pre_ready)
             q_p = mel_stack(*pre, rider=lambda i: text_layer(ns + i - (nm - nr)) if i >= nm - nr else None)
             te_done.record(main)

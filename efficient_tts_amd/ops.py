@@ -208,12 +208,13 @@ def resconv5_multi(layers) -> None:
 
 
 def frame_linear(*, x: torch.Tensor, w: "PackedWeight", bias: Optional[torch.Tensor], act: int, slope: float, rs: Rows,
-                 y: Optional[Plane] = None, y_lo: Optional[Plane] = None, y_f32: Optional[F32Rows] = None) -> None:
+                 y: Optional[Plane] = None, y_lo: Optional[Plane] = None, y_f32: Optional[F32Rows] = None, max_workgroups: int = 0) -> None:
     """y[b * Tp + t] = act(x[b, t] . W^T + bias) straight from the caller's fp32 frames (efts_frame_linear): x [B, T, cin] contiguous"""
     g = L.FrameLinearArgs()
     g.x, g.w, g.ldw, g.split = x.data_ptr(), w.ptr, w.ld, w.split
     g.bias, g.act, g.slope = _p(bias), act, slope
     g.B, g.T, g.Tp, g.cin, g.n = rs.B, rs.T, rs.Tp, x.shape[2], w.cout
+    g.max_workgroups = max_workgroups
     if y_f32 is not None:
         g.y_f32, g.ldo = y_f32.ptr, y_f32.c
     if y is not None:
@@ -233,6 +234,21 @@ def resconv5_plan(m: int, n: int, cus: int = 0):
         q = 2 + c * 10
         classes.append((buf[q], [buf[q + 2 + t] for t in range(buf[q + 1])]))
     return buf[0], classes
+
+
+_plan_cache = {}
+
+
+def resconv5_plan_buf(m: int, n: int, cus: int):
+    """the automatic schedule for `cus` compute units as a plan buffer efts_resconv5 takes (cached: a host-side table)"""
+    key = (m, n, cus)
+    if key not in _plan_cache:
+        buf = (C.c_int32 * L.RC_PLAN_INTS)()
+        rc = L.load().efts_resconv5_plan(m, n, cus, buf, L.RC_PLAN_INTS)
+        if rc < 0:
+            L.check(rc, "efts_resconv5_plan")
+        _plan_cache[key] = buf
+    return _plan_cache[key]
 
 
 def make_plan(m: int, classes):

@@ -223,7 +223,7 @@ class TrainEngine:
             dp, dseed = self._conv_drop(dict(te=10, me=20, dec=30)[tag] + i)
             # under Dropout y - x no longer carries the activation's sign where the element was dropped: always the sign words then
             sg = ws.tensor(f"T{tag}_sg{i}", (rs.rows, C // 8), torch.uint8) if ((0 < _SIGN_MIN_ROWS <= rs.rows or dp > 0) and C % 128 == 0) else None
-            O.gemm(a=x_p, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=5, m=rs.rows, n=C, act=L.ACT_LEAKY, slope=m.slope,
+            O.gemm(a=x_p, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=m.k_size, m=rs.rows, n=C, act=L.ACT_LEAKY, slope=m.slope,
                    bias=layer.conv[0].bias, resid_ptr=x_f.ptr, ldr=C, rowmask_ptr=gap_ptr, out_f32_ptr=o_f.ptr, ldo=C, out_plane=o_p,
                    sign_mask_ptr=None if sg is None else sg.data_ptr(), drop_p=dp, drop_seed=dseed)
             saved.append((x_f, o_f, x_p, sg, dp, dseed))
@@ -255,13 +255,13 @@ class TrainEngine:
             v_, g_ = (conv.weight_v.detach(), conv.weight_g.detach()) if wn else (None, None)
             dw_, dg_ = (self.g[pre + "weight_v"], self.g[pre + "weight_g"]) if wn else (self.g[pre + "weight"], None)
             if direct:
-                self._wgrad_tn(ws, dz_p, x_pl, C, C, rs.rows, v_, g_, dw_, dg_, bias_part=bp, dbias=self.g[pre + "bias"])
+                self._wgrad_tn(ws, dz_p, x_pl, C, C, rs.rows, v_, g_, dw_, dg_, bias_part=bp, dbias=self.g[pre + "bias"], taps=m.k_size)
             else:
-                self._wgrad(ws, dz_f.ptr, C, x_f.ptr, C, C, 5, rs.rows, v_, g_, dw_, dg_)
+                self._wgrad(ws, dz_f.ptr, C, x_f.ptr, C, C, m.k_size, rs.rows, v_, g_, dw_, dg_)
             wt = self.wt[f"{blk}.{i}"]
             Gn = ws.f32(f"B{tag}_G{i & 1}", rs, C)
             last = i == 0
-            O.gemm(a=dz_p, b_ptr=wt.ptr, ldb=wt.ld, b_tap_stride=wt.tap_stride, taps=5, m=rs.rows, n=C, resid_ptr=G.ptr, ldr=C,
+            O.gemm(a=dz_p, b_ptr=wt.ptr, ldb=wt.ld, b_tap_stride=wt.tap_stride, taps=m.k_size, m=rs.rows, n=C, resid_ptr=G.ptr, ldr=C,
                    rowmask_ptr=final_mask_ptr if last else gap_ptr, out_f32_ptr=Gn.ptr, ldo=C,
                    out_plane=final_plane if last else None)
             G = Gn

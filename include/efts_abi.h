@@ -218,6 +218,8 @@ typedef struct efts_frame_linear_args {
     void* y_lo;          /* y_split 1 only: bf16 remainder plane or NULL */
     int64_t ldy;         /* bytes, both planes */
     int32_t y_split;
+    int32_t max_workgroups; /* 0: one workgroup per (item, 128-channel slice); > 0: at most this many (each then takes several units in
+                             * turn), leaving compute units to a launch that runs beside this one -- the kernel is HBM-bound */
 } efts_frame_linear_args;
 int efts_frame_linear(const efts_frame_linear_args* a, void* stream);
 

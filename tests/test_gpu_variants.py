@@ -13,7 +13,8 @@ from oracle import efts_oracle as O
 
 pytestmark = pytest.mark.gpu
 VARIANTS = dict(nomask=dict(use_masking=False), sharekv=dict(share_text_encoder_key_value=True), queryfc=dict(use_mel_query_fc=True),
-                delta2=dict(delta_e_method_1=False))
+                delta2=dict(delta_e_method_1=False), k3=dict(k_size=3), relu=dict(nonlinear_activation="ReLU", nonlinear_activation_params={}))
+ORACLE_HP = dict(relu=dict(leaky_slope=0.0))           # the oracle's name for an option where it differs from the ctor keyword
 MEL_TOL = 1e-3
 
 
@@ -27,7 +28,8 @@ def _model(opt):
     kw = dict(num_symbols=76, dropout_rate=0.0, use_masking=True, sigma=0.01, precision="bf16x3")
     kw.update(opt)
     m = EfficientTTSCNN(**kw)
-    P = O.fill_params(dict(O.DEFAULT_HP, **opt))
+    name = next(k for k, v in VARIANTS.items() if v == opt)
+    P = O.fill_params(dict(O.DEFAULT_HP, **ORACLE_HP.get(name, opt)))
     assert list(m.state_dict().keys()) == list(P.keys())          # the reference's key set and order for this option
     m.load_state_dict(P)
     return m.to(_dev()).eval()
@@ -82,7 +84,7 @@ def test_variant_param_grads_match_reference_golden(golden_dir, name):
         assert abs(gn - float(g["gradnorm:" + n])) <= 5e-3 * float(g["gradnorm:" + n]) + 1e-5, n
 
 
-@pytest.mark.parametrize("name", ["sharekv", "delta2"])
+@pytest.mark.parametrize("name", ["sharekv", "delta2", "k3"])
 def test_variant_inference_matches_reference_golden(golden_dir, name):
     g = np.load(os.path.join(golden_dir, f"variant_{name}.npz"))
     m = _model(VARIANTS[name])

@@ -23,14 +23,18 @@ VARIANTS = dict(
     sharekv=dict(share_text_encoder_key_value=True),
     queryfc=dict(use_mel_query_fc=True),
     delta2=dict(delta_e_method_1=False),
+    k3=dict(k_size=3),                                              # ResConv1d's kernel size (efts_modules.py:19-46)
+    relu=dict(nonlinear_activation="ReLU", nonlinear_activation_params={}),   # ... and its activation
 )
+# what the oracle's hyper-parameter dict calls an option, where it differs from the reference ctor's keyword
+ORACLE_HP = dict(relu=dict(leaky_slope=0.0))
 
 
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     for name, opt in VARIANTS.items():
-        hp = dict(O.DEFAULT_HP, **opt)
+        hp = dict(O.DEFAULT_HP, **ORACLE_HP.get(name, opt))
         kw = dict(num_symbols=76, dropout_rate=0.0, use_masking=True, use_weighted_masking=False, sigma=0.01)
         kw.update(opt)
         m = EfficientTTSCNN(**kw)
@@ -65,7 +69,7 @@ def main():
             d["grad:" + k] = flat
             d["gradnorm:" + k] = np.float64(g.double().norm())
         print(f"  [{name}] oracle vs reference param-grad worst rel-to-max {worst:.3e}")
-        if name in ("sharekv", "delta2"):                      # free-running path: value = key (:252-253) / positions from 0 (:261-265)
+        if name in ("sharekv", "delta2", "k3"):                # free-running path: value = key (:252-253) / positions from 0 (:261-265) / k3 stacks
             ids = torch.randint(1, 76, (1, 23), generator=torch.Generator().manual_seed(5))
             m.remove_weight_norm()
             with torch.no_grad():
