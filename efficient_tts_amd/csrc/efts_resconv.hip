@@ -76,6 +76,8 @@ struct RcProb {
     int m;                  // rows of this layer
     int out_split;
     float slope;
+    int taps;               // 5 | 3
+    int no_resid;           // 1: y = act(conv + bias) * mask (no residual term)
     int pad_;
 };
 
@@ -131,9 +133,10 @@ __device__ __forceinline__ int rc_pieces(int h, int wave) { return (4 * h - wave
 // the weight requests two steps ahead simply wrap into the next tile's steps 0 and 1, and the next tile's first window
 // (rows m1, height h1; 0 = no next tile) is requested at the first tap of this tile's last chunk.  On entry the window of
 // chunk 0 and the weights of steps 0 and 1 are therefore in flight or landed.
-template <int SPLIT, int NI>
+template <int SPLIT, int NI, int TAPS>
 __device__ __forceinline__ void rc_tile(const RcArgs& p, const RcProb& pq, const RcProb& pn, RcCtx& c, int m0, int h, int rows_out, int m1, int h1) {
-    constexpr int TAPS = 5;
+    // TAPS 5 or 3: a k3 layer keeps the k5 geometry (window from row m0 - 2, 32 h - 4 output rows per tile) and simply reads window
+    // rows r + k + 1 for its three taps; fewer steps per chunk, everything else -- streams, barriers, epilogue -- is the same code
     char* const smem = c.smem;
     const int lane = c.lane, wave = c.wave, lrow = c.lrow, lhalf = c.lhalf, wm = c.wm, wn = c.wn;
     const int row0w = wm ? 32 * ((h + 1) >> 1) : 0;         // first tile row of this wave row
@@ -290,7 +293,7 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, const RcProb& pq, const
             asm volatile("" : "+s"(kv));
             const char* at = smem + wbuf * RC_WIN_BYTES;
             const char* wt = smem + RC_RING + ws * RC_W_BYTES;
-            const int arow = row0w + lrow + kv;
+            const int arow = row0w + lrow + kv + (5 - TAPS) / 2;
             if constexpr (ROW == 0) {
                 window();
                 loadH(at, wt, arow, 0); dma_w(0); dma_w(1);
@@ -374,7 +377,7 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, const RcProb& pq, const
         for (int pp = 0; pp < 2; ++pp) {
             const unsigned rofs = (u >> 1) * 32 + ((u & 1) * 2 + pp) * 8;
             const unsigned so = rofs * sx_row;
-            if (RC_EXP & 8) { xa[bsel][pp] = u32x4{0, 0, 0, 0}; xb[bsel][pp] = xa[bsel][pp]; }
+            if ((RC_EXP & 8) || pq.no_resid) { xa[bsel][pp] = u32x4{0, 0, 0, 0}; xb[bsel][pp] = xa[bsel][pp]; }
             else if (res_f32) {
                 xa[bsel][pp] = __builtin_amdgcn_raw_buffer_load_b128(r_x, vx, so, 0);
                 xb[bsel][pp] = __builtin_amdgcn_raw_buffer_load_b128(r_x, vx, so + 16, 0);
@@ -542,11 +545,21 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
         const RcProb& pn = p.pr[h1 > 0 ? pi1 : pi];
         c.w_next = pn.w + (long)c.n0 * pn.ldw;
         c.wts_next = pn.w_tap_stride;
-        switch (c.wm ? h >> 1 : (h + 1) >> 1) {             // 32-row blocks of this wave's row (wave-uniform)
-            case 1: rc_tile<SPLIT, 1>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
-            case 2: rc_tile<SPLIT, 2>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
-            case 3: rc_tile<SPLIT, 3>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
-            default: rc_tile<SPLIT, 4>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+        const int nblk = c.wm ? h >> 1 : (h + 1) >> 1;      // 32-row blocks of this wave's row (wave-uniform)
+        if (pq.taps == 3) {
+            switch (nblk) {
+                case 1: rc_tile<SPLIT, 1, 3>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+                case 2: rc_tile<SPLIT, 2, 3>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+                case 3: rc_tile<SPLIT, 3, 3>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+                default: rc_tile<SPLIT, 4, 3>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+            }
+        } else {
+            switch (nblk) {
+                case 1: rc_tile<SPLIT, 1, 5>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+                case 2: rc_tile<SPLIT, 2, 5>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+                case 3: rc_tile<SPLIT, 3, 5>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+                default: rc_tile<SPLIT, 4, 5>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+            }
         }
         if (h1 > 0 && pi1 != pi) bias_of(pn);
         c.w_base = c.w_next; c.wts = c.wts_next;
@@ -673,6 +686,7 @@ static int rc_check(const efts_resconv5_args* a, const char* who) {
     if (a->y && !(a->y_split == 1 || a->y_split == 2)) return efts_fail(EFTS_EINVAL, "%s: y_split must be 1 or 2", who);
     if (a->split == 2 && a->x_lo) return efts_fail(EFTS_EINVAL, "%s: x_lo is for split-1 planes (split 2 carries lo inside x)", who);
     if (a->y_split == 2 && a->y_lo) return efts_fail(EFTS_EINVAL, "%s: y_lo is for split-1 output planes", who);
+    if (!(a->taps == 0 || a->taps == 3 || a->taps == 5)) return efts_fail(EFTS_EINVAL, "%s: taps must be 5 (0 = default) or 3", who);
     return 0;
 }
 
@@ -691,7 +705,7 @@ extern "C" int efts_resconv5_multi(const efts_resconv5_args* a, int32_t count, v
         r.a = (const char*)q->x; r.a_lo = (const char*)q->x_lo; r.resid = q->x_f32; r.w = (const char*)q->w;
         r.bias = q->bias; r.rowmask = q->rowmask; r.out_f32 = q->y_f32; r.ob = (char*)q->y; r.ob_lo = (char*)q->y_lo;
         r.lda = q->ldx; r.ldw = q->ldw; r.w_tap_stride = q->w_tap_stride; r.ldr = q->ldr; r.ldo = q->ldo; r.ldob = q->ldy;
-        r.m = q->m; r.out_split = q->y_split; r.slope = q->slope; r.pad_ = 0;
+        r.m = q->m; r.out_split = q->y_split; r.slope = q->slope; r.taps = q->taps == 3 ? 3 : 5; r.no_resid = q->no_residual ? 1 : 0; r.pad_ = 0;
         mtot += q->m;
     }
     for (int i = count; i < RC_MAXPROB; ++i) k.pr[i] = k.pr[0];

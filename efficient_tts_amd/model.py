@@ -202,6 +202,8 @@ class EfficientTTSCNN(torch.nn.Module):
         self.fuse_soft_index = True         # T1 <= 128: q.k^T, softmax and soft index in one launch (False: scores stored, efts_attn_soft_index)
         self.small_m = True                 # free-running inference on short row spaces (<= SMALL_M_ROWS rows): the K-split small-M tiling of efts_gemm
         self._free_running = False          # set while inference() / inference_batch() enqueue their launches
+        self.ride_duration = False          # merged mode: the duration predictor's k3 convolutions ride in decoder launches 0, 2, LayerNorms on the second stream
+                                            # (measured 1.665 vs 1.633 ms: a rider costs a whole tile step of the 13, off by default)
         self.share_cus = True               # merged mode: the prenet and the first text layers run side by side on disjoint halves of the CUs
         self.merge_text = True              # text-encoder layers ride in the persistent launches of the mel-encoder layers (efts_resconv5_multi)
         self.fuse_align = True              # imv scan + aligned positions + duration target in one launch (efts_imv_align)
@@ -348,7 +350,7 @@ class EfficientTTSCNN(torch.nn.Module):
         return None
 
     def _on_resconv(self, rs: Rows) -> bool:
-        return self.resconv and rs.rows >= self.RESCONV_MIN_ROWS and self.n_channels % 256 == 0 and self.k_size == 5
+        return self.resconv and rs.rows >= self.RESCONV_MIN_ROWS and self.n_channels % 256 == 0 and self.k_size in (3, 5)
 
     def _stream_in(self, ws, tag, rs: Rows):
         """Buffers the producer of a residual stack's input writes: (fp32 stream or None, operand plane, lo plane or None).
@@ -368,16 +370,16 @@ class EfficientTTSCNN(torch.nn.Module):
         y = ws.plane(f"{tag}_p{i & 1}", rs, C, o_split)
         y_lo = ws.plane(f"{tag}_l{i & 1}", rs, C, 1) if (o_split == 1 and not last) else None
         o_f32 = ws.f32(f"{tag}_f{i & 1}", rs, C) if (last and last_f32) else None
-        kw = dict(x=x_pl, x_lo=x_lo, x_f32_ptr=None if x_f32 is None else x_f32.ptr, ldr=C, w=pk[f"{blk}.{i}"],
+        kw = dict(x=x_pl, x_lo=x_lo, x_f32_ptr=None if x_f32 is None else x_f32.ptr, ldr=C, w=pk[f"{blk}.{i}"], taps=self.k_size,
                   m=rs.rows, n=C, bias=getattr(self, blk).layers[i].conv[0].bias, slope=self.slope,
                   rowmask_ptr=gap_ptr, y_f32_ptr=None if o_f32 is None else o_f32.ptr, ldo=C, y=y, y_lo=y_lo)
         return kw, o_f32, y, y_lo
 
     def _res_stack(self, ws, tag, blk, pk, rs: Rows, x_f32: Optional[F32Rows], x_pl: Plane, gap_ptr, last_split: int,
-                   last_f32: bool, x_lo: Optional[Plane] = None, rider=None):
+                   last_f32: bool, x_lo: Optional[Plane] = None, rider=None, after=None):
         """n x ( x + LeakyReLU(conv1d_k5(x)) ) on the row space (efts_modules.py:48-51,77-79).
         `rider(i)`: optional, returns the efts_resconv5 keyword set of an independent layer of the same geometry that shares
-        layer i's persistent launch (or None)."""
+        layer i's persistent launch (or None); `after(i)`: optional, called when layer i's launch has been enqueued."""
         n = len(getattr(self, blk).layers)
         C = self.n_channels
         if self._on_resconv(rs):
@@ -391,9 +393,11 @@ class EfficientTTSCNN(torch.nn.Module):
                     O.resconv5_multi([kw, extra])
                 else:
                     O.resconv5(**kw)
+                if after is not None:
+                    after(i)
                 x_pl, x_lo = y, y_lo
             return o_f32, x_pl
-        assert rider is None
+        assert rider is None and after is None
         for i in range(n):
             last = i == n - 1
             w = pk[f"{blk}.{i}"]
@@ -451,26 +455,40 @@ class EfficientTTSCNN(torch.nn.Module):
         dp = self.duration_predictor
         h_f = ws.f32("dur_f", rs1, C)
         x_p = val_p
-        out = ws.tensor("dur_out", (rs1.rows,))
         for i, seq in enumerate(dp.conv):
             w = pk[f"dur.{i}"]
             O.gemm(a=x_p, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=3, m=rs1.rows, n=C, act=L.ACT_RELU,
                    bias=seq[0].bias, out_f32_ptr=h_f.ptr, ldo=C, tiling=self._til(rs1.rows))
-            ln = seq[2]
-            if i + 1 < len(dp.conv):
-                x_p = ws.plane(f"dur_p{i}", rs1, C, self.split)
-                O.layernorm_rows(h_f.ptr, ln.weight.detach(), ln.bias.detach(), ln.eps, gap1.data_ptr(), None, x_p,
-                                 rs1.rows, C)
-            else:
-                O.layernorm_dot(h_f.ptr, ln.weight.detach(), ln.bias.detach(), ln.eps, dp.linear.weight.detach(),
-                                dp.linear.bias.detach(), out_mask_ptr, mode, float(dp.offset), out, rs1.rows, C)
-        return out
+            x_p = self._duration_norm(ws, rs1, i, gap1, out_mask_ptr, mode)
+        return ws.tensor("dur_out", (rs1.rows,))
+
+    def _duration_conv_kw(self, ws, pk, rs1: Rows, i: int, x_p: Plane) -> dict:
+        """Conv1d(k3) + ReLU of duration-predictor layer i (duration_predictor.py:57) as an efts_resconv5 layer without a residual
+        term (slope 0 = ReLU), fp32 output for the LayerNorm: what rides in a decoder launch"""
+        C = self.n_channels
+        return dict(x=x_p, w=pk[f"dur.{i}"], m=rs1.rows, n=C, bias=self.duration_predictor.conv[i][0].bias, slope=0.0,
+                    y_f32_ptr=ws.f32("dur_f", rs1, C).ptr, ldo=C, taps=3, no_residual=True)
+
+    def _duration_norm(self, ws, rs1: Rows, i: int, gap1, out_mask_ptr, mode: int) -> Optional[Plane]:
+        """LayerNorm behind conv i (duration_predictor.py:58-61): -> the next conv's operand plane, or (last layer) + Linear(C, 1) ->
+        the predicted log-durations in ws "dur_out" """
+        C = self.n_channels
+        dp = self.duration_predictor
+        ln = dp.conv[i][2]
+        h_f = ws.f32("dur_f", rs1, C)
+        if i + 1 < len(dp.conv):
+            x_p = ws.plane(f"dur_p{i}", rs1, C, self.split)
+            O.layernorm_rows(h_f.ptr, ln.weight.detach(), ln.bias.detach(), ln.eps, gap1.data_ptr(), None, x_p, rs1.rows, C)
+            return x_p
+        O.layernorm_dot(h_f.ptr, ln.weight.detach(), ln.bias.detach(), ln.eps, dp.linear.weight.detach(), dp.linear.bias.detach(),
+                        out_mask_ptr, mode, float(dp.offset), ws.tensor("dur_out", (rs1.rows,)), rs1.rows, C)
+        return None
 
     def _fused_expand(self, T1: int) -> bool:
         return self.fuse_expand and T1 <= 256 and self.n_channels % 128 == 0
 
     def _expand_decode(self, ws, pk, B, T1, rs1: Rows, rs2: Rows, val_f: F32Rows, e, tl, ml, ralpha, len2_ptr, gap2,
-                       vt: Optional[Plane] = None):
+                       vt: Optional[Plane] = None, rider=None, after=None):
         """Gaussian re-alignment from e, bmm(V^T, alpha') -> decoder -> mel head (efficient_tts.py:184-200 / :270-284).
         `ralpha` [B, T1, T2] receives alpha' (the API tensor); tl / ml: int32 lengths or None (no masks, :270-274);
         `vt`: V^T already packed (unfused path only)."""
@@ -489,7 +507,7 @@ class EfficientTTSCNN(torch.nn.Module):
                    b_batch_stride=C * vt.ld, rowmask_ptr=len2_ptr, rowmask_batch_stride=rs2.Tp,
                    out_f32_ptr=None if h_f is None else h_f.ptr, ldo=C, out_batch_stride=rs2.Tp * C, out_plane=h_p,
                    outb_batch_stride=rs2.Tp * h_p.ld, out_plane_lo=h_l)
-        _, d_p = self._res_stack(ws, "dec", "decoder", pk, rs2, h_f, h_p, gap2.data_ptr(), self.split, False, x_lo=h_l)
+        _, d_p = self._res_stack(ws, "dec", "decoder", pk, rs2, h_f, h_p, gap2.data_ptr(), self.split, False, x_lo=h_l, rider=rider, after=after)
         # mel head (:198-200), written straight into the [B, T2, odim] tensor the caller gets (one item per batch entry of the
         # launch: no row-space copy of mel_pred, no clone)
         mel = torch.empty(B, rs2.T, self.odim, dtype=torch.float32, device=h_p.buf.device)
@@ -528,7 +546,7 @@ class EfficientTTSCNN(torch.nn.Module):
         key = ("fwd", tuple(text.shape), tuple(speech.shape), text.dtype, speech.dtype, text_lengths.dtype, speech_lengths.dtype)
         ws = self._workspace(("fwd", text.shape[0], text.shape[1], speech.shape[1]), dev)
         # the graph is valid while the buffers its launches point at live: this workspace, the packed planes, the parameters
-        tag = (ws.serial, self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.side_stream, self.RESCONV_MIN_ROWS, self.fuse_soft_index, self.fuse_prenet, self.fuse_align, self.fuse_expand, self.merge_text, self.share_cus)
+        tag = (ws.serial, self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.side_stream, self.RESCONV_MIN_ROWS, self.fuse_soft_index, self.fuse_prenet, self.fuse_align, self.fuse_expand, self.merge_text, self.share_cus, self.ride_duration)
 
         def body(t, tl, sp, sl):
             (_, stats, imv, ralpha, mel_pred, _), _ = self._forward_impl(t, tl, sp, sl)
@@ -561,6 +579,7 @@ class EfficientTTSCNN(torch.nn.Module):
         side.wait_stream(main)
         vt = None if self._fused_expand(T1) else ws.raw_plane("vt", B * C, T1, 2)
         O.row_masks(ml, rs2, gap2, len2)                                          # :139
+        dec_rider = dec_after = None
         nt, nm = len(self.text_encoder.layers), len(self.mel_encoder.layers)
         merged = self.merge_text and self._on_resconv(rs2) and nt >= 1 and nm >= 1
         v_ready = torch.cuda.Event()
@@ -627,10 +646,38 @@ class EfficientTTSCNN(torch.nn.Module):
             te_done.record(main)
             key_p = self._key_proj(ws, pk, rs1, tstate["x_p"], gap1, len1)          # :149, :155-156 (q.k^T is next on this stream)
             side.wait_event(te_done)
+            ndur, ndec = len(self.duration_predictor.conv), len(self.decoder.layers)
+            ride_dur = self.ride_duration and 2 * ndur - 1 <= ndec
             with O.on_stream(side):                                               # the value projection beside the key projection
                 val_f, val_p = self._value_proj(ws, pk, rs1, tstate["x_p"], gap1, len1, vt)   # :150-157
                 v_ready.record(side)
-                dur = self._duration(ws, pk, rs1, val_p, gap1, len1.data_ptr(), 0)    # :219
+                if not ride_dur:
+                    dur = self._duration(ws, pk, rs1, val_p, gap1, len1.data_ptr(), 0)    # :219
+            if ride_dur:
+                # The duration predictor (:219) is needed by the loss only.  Its k3 convolutions ride in decoder launches 0, 2, ...
+                # (efts_resconv5 layers without a residual term: +13 us each) and its LayerNorms run on the second stream beside
+                # launches 1, 3, ...: nothing of it competes with q.k^T / the alignment block / the expand launch any more, and
+                # nothing of it is still on the CUs when the decoder's first persistent launch wants them.
+                dstate = dict(x_p=val_p, ev=None)
+
+                def dec_rider(i):
+                    if i % 2 or i // 2 >= ndur:
+                        return None
+                    if dstate["ev"] is not None:
+                        main.wait_event(dstate["ev"])                             # the LayerNorm in front of this convolution
+                    return self._duration_conv_kw(ws, pk, rs1, i // 2, dstate["x_p"])
+
+                def dec_after(i):
+                    if i % 2 or i // 2 >= ndur:
+                        return
+                    done = torch.cuda.Event()
+                    done.record(main)
+                    side.wait_event(done)
+                    with O.on_stream(side):
+                        dstate["x_p"] = self._duration_norm(ws, rs1, i // 2, gap1, len1.data_ptr(), 0)
+                        dstate["ev"] = torch.cuda.Event()
+                        dstate["ev"].record(side)
+                dur = ws.tensor("dur_out", (rs1.rows,))
         else:
             # second HIP stream: the text-side launches fill the tail rounds of the mel-length kernels
             k_ready = torch.cuda.Event()
@@ -668,7 +715,8 @@ class EfficientTTSCNN(torch.nn.Module):
         ralpha = torch.empty(B, T1, T2, dtype=torch.float32, device=dev)
 
         main.wait_event(v_ready)
-        mel = self._expand_decode(ws, pk, B, T1, rs1, rs2, val_f, e, tl, ml, ralpha, len2.data_ptr(), gap2, vt=vt)   # :184-200
+        mel = self._expand_decode(ws, pk, B, T1, rs1, rs2, val_f, e, tl, ml, ralpha, len2.data_ptr(), gap2, vt=vt,
+                                  rider=dec_rider, after=dec_after)                                          # :184-200
         main.wait_stream(side)                                                     # duration predictor done
 
         out3 = torch.empty(3, dtype=torch.float32, device=dev)                     # :220-227

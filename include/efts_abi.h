@@ -186,6 +186,10 @@ typedef struct efts_resconv5_args {
     int64_t ldy;        /* bytes, both planes */
     int32_t y_split;    /* 1 or 2 */
     const int32_t* plan; /* HOST pointer: explicit tile schedule (format of efts_resconv5_plan) or NULL = automatic */
+    int32_t taps;        /* 0 / 5: the k5 layer; 3: a k3 convolution with a [3][n][K] weight plane (duration_predictor.py:57, or a
+                          * ResConv1d stack built with k_size = 3) on the same kernel: window and tile geometry of the k5 layer */
+    int32_t no_residual; /* 1: y = LeakyReLU(conv + bias, slope) * rowmask without the residual term (slope 0 = ReLU): the
+                          * duration predictor's Conv1d + ReLU, riding in a decoder launch (efts_resconv5_multi) */
 } efts_resconv5_args;
 
 int efts_resconv5(const efts_resconv5_args* a, void* stream);

@@ -202,3 +202,64 @@ def test_resconv5_multi_two_layers_in_one_launch(split, shapes, classes):
             n = c.rs.alloc
             assert torch.equal(y.buf.view(torch.bfloat16).view(n, -1)[:, :C], rh)
             assert torch.equal(yl.buf.view(torch.bfloat16).view(n, -1)[:, :C], rl)
+
+
+class Case3(Case):
+    """a k3 layer on the same operands: weights [C][C][3], reference = efts_gemm taps 3 (residual layer, or Conv1d + ReLU without
+    the residual term and without a mask: the duration predictor's layer, nntts/layers/duration_predictor.py:57)"""
+
+    def __init__(self, B, T, split, seed=0, plain=False):
+        super().__init__(B, T, split, seed)
+        L, P, rs, dev = self.L, self.P, self.rs, _dev()
+        self.plain = plain
+        self.w = (torch.randn(C, C, 3, device=dev) * 0.03).contiguous()
+        self.pw = P.PackedWeight(C, C, 3, split, dev); self.pw.pack(self.w)
+        self.o_ref, self.p_ref = P.F32Rows(rs, C, dev), P.Plane.for_rows(rs, C, 2, dev)
+        if plain:
+            P.gemm(a=self.a, b_ptr=self.pw.ptr, ldb=self.pw.ld, b_tap_stride=self.pw.tap_stride, taps=3, m=rs.rows, n=C, act=L.ACT_RELU,
+                   bias=self.bias, out_f32_ptr=self.o_ref.ptr, ldo=C, out_plane=self.p_ref, tiling=L.TILING_GENERIC)
+        else:
+            P.gemm(a=self.a, b_ptr=self.pw.ptr, ldb=self.pw.ld, b_tap_stride=self.pw.tap_stride, taps=3, m=rs.rows, n=C, act=L.ACT_LEAKY,
+                   slope=0.1, bias=self.bias, resid_ptr=self.xf.ptr, ldr=C, rowmask_ptr=self.mask.data_ptr(), out_f32_ptr=self.o_ref.ptr, ldo=C,
+                   out_plane=self.p_ref, tiling=L.TILING_GENERIC)
+        torch.cuda.synchronize()
+
+    def kwargs(self, o, y):
+        if self.plain:
+            return dict(x=self.a, x_lo=self.a_lo, w=self.pw, m=self.rs.rows, n=C, bias=self.bias, slope=0.0, y_f32_ptr=o.ptr, ldo=C, y=y,
+                        taps=3, no_residual=True)
+        return dict(x=self.a, x_lo=self.a_lo, w=self.pw, m=self.rs.rows, n=C, bias=self.bias, rowmask_ptr=self.mask.data_ptr(),
+                    y_f32_ptr=o.ptr, ldo=C, y=y, taps=3)
+
+
+@pytest.mark.parametrize("split", [1, 2])
+@pytest.mark.parametrize("B,T", [(3, 37), (5, 300), (2, 801), (1, 1)])
+@pytest.mark.parametrize("plain", [False, True])
+def test_resconv5_k3_layers_equal_gemm(split, B, T, plain):
+    """efts_resconv5_args.taps = 3 (a k_size = 3 ResConv1d layer; with no_residual and slope 0 the duration predictor's Conv1d + ReLU)
+    == efts_gemm taps 3 on the same operands, bit for bit"""
+    c = Case3(B, T, split, seed=5, plain=plain)
+    P, dev = c.P, _dev()
+    o, y = P.F32Rows(c.rs, C, dev), P.Plane.for_rows(c.rs, C, 2, dev)
+    P.resconv5(**c.kwargs(o, y))
+    torch.cuda.synchronize()
+    live = slice(c.L.GUARD_LO, c.L.GUARD_LO + c.rs.rows)
+    assert torch.equal(o.buf[live], c.o_ref.buf[live]), f"fp32 differs: {(o.buf - c.o_ref.buf).abs().max().item():.3e}"
+    assert torch.equal(y.buf[live].view(torch.bfloat16), c.p_ref.buf[live].view(torch.bfloat16))
+
+
+@pytest.mark.parametrize("split", [1, 2])
+def test_resconv5_multi_k5_layer_with_a_k3_rider(split):
+    """a decoder-like k5 residual layer and the duration predictor's k3 Conv1d + ReLU (no residual, no mask, fp32 output) in one
+    grouped launch: each equals its own efts_gemm launch bit for bit"""
+    ca, cb = Case(16, 800, split, seed=3), Case3(16, 128, split, seed=11, plain=True)
+    P, dev = ca.P, _dev()
+    oa, ya = P.F32Rows(ca.rs, C, dev), P.Plane.for_rows(ca.rs, C, 2, dev)
+    ob, yb = P.F32Rows(cb.rs, C, dev), P.Plane.for_rows(cb.rs, C, 2, dev)
+    ka = dict(x=ca.a, x_lo=ca.a_lo, w=ca.pw, m=ca.rs.rows, n=C, bias=ca.bias, rowmask_ptr=ca.mask.data_ptr(), y_f32_ptr=oa.ptr, ldo=C, y=ya)
+    P.resconv5_multi([ka, cb.kwargs(ob, yb)])
+    torch.cuda.synchronize()
+    assert torch.equal(oa.buf, ca.o_ref.buf)
+    live = slice(cb.L.GUARD_LO, cb.L.GUARD_LO + cb.rs.rows)
+    assert torch.equal(ob.buf[live], cb.o_ref.buf[live])
+    assert torch.equal(yb.buf[live].view(torch.bfloat16), cb.p_ref.buf[live].view(torch.bfloat16))
