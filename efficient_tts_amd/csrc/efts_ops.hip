@@ -97,6 +97,44 @@ __global__ void embed_kernel(const long* __restrict__ ids, const float* __restri
     if (plane) plane_store4(plane + (long)row * ldp, c4, v.x, v.y, v.z, v.w, split);
 }
 
+// Embedding + the FIRST residual convolution of the text encoder as table look-ups.  The input of that layer takes only
+// num_symbols distinct values per position, and the convolution is linear, so tap k's contribution W_k . emb[v] can be tabulated
+// once per weight set for every symbol v (tap_table [taps][V][c], built by the caller with `taps` one-tap efts_gemm launches on the
+// embedding rows); the layer is then
+//   y[b, t] = emb[id_t] + LeakyReLU( bias + sum_k tap_table[k][ id_{t + k - pad} ] )     (positions outside [0, lim) contribute 0)
+// -- 21 GFLOP of MFMA work at 64 x 128 tokens become 8 320 x (taps + 1) row gathers from a 0.9 MB table.
+// lim = T (lens == NULL: the teacher-forced forward, where padded ids are real symbols and leak: efficient_tts.py:144-148) or the
+// item's length (batched free-running inference: zero embedding and zero output beyond it).
+__global__ void embed_conv_kernel(const long* __restrict__ ids, const int* __restrict__ lens, const float* __restrict__ table,
+                                  const float* __restrict__ taptab, const float* __restrict__ bias, float slope, float* __restrict__ f32o,
+                                  char* __restrict__ plane, long ldp, int T, int Tp, int c, int nsym, int taps, int split) {
+    const int row = blockIdx.x;
+    const int b = row / Tp, t = row - b * Tp;
+    const int c4 = threadIdx.x << 2;
+    if (c4 >= c) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int lim = lens ? min(lens[b], T) : T;
+    if (t < lim) {
+        const long* idr = ids + (long)b * T;
+        auto sym = [&](int tt) { long id = idr[tt]; return (int)(id < 0 ? 0 : (id >= nsym ? nsym - 1 : id)); };
+        float4 acc = bias ? *(const float4*)(bias + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int pad = (taps - 1) >> 1;
+        for (int k = 0; k < taps; ++k) {
+            const int tt = t + k - pad;
+            if (tt < 0 || tt >= lim) continue;
+            const float4 p = *(const float4*)(taptab + ((long)k * nsym + sym(tt)) * c + c4);
+            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+        }
+        const float4 e = *(const float4*)(table + (long)sym(t) * c + c4);
+        v.x = e.x + (acc.x > 0.f ? acc.x : acc.x * slope);
+        v.y = e.y + (acc.y > 0.f ? acc.y : acc.y * slope);
+        v.z = e.z + (acc.z > 0.f ? acc.z : acc.z * slope);
+        v.w = e.w + (acc.w > 0.f ? acc.w : acc.w * slope);
+    }
+    if (f32o) *(float4*)(f32o + (long)row * c + c4) = v;
+    if (plane) plane_store4(plane + (long)row * ldp, c4, v.x, v.y, v.z, v.w, split);
+}
+
 __global__ void pack_rows_kernel(const float* __restrict__ x, float* __restrict__ f32o, char* __restrict__ plane,
                                  long ldp, int T, int Tp, int c, int kp, int split) {
     const int row = blockIdx.x;
@@ -514,6 +552,18 @@ extern "C" int efts_embed(const int64_t* ids, const float* table, float* f32_out
     hipLaunchKernelGGL(embed_kernel, dim3(B * Tp), dim3(((c / 4) + 63) & ~63), 0, ST, (const long*)ids, table, f32_out, (char*)plane,
                        (long)ld_plane, T, Tp, c, num_symbols, split);
     return efts_check_launch("efts_embed");
+}
+
+extern "C" int efts_embed_conv(const int64_t* ids, const int32_t* lengths, const float* table, const float* tap_table, const float* bias, float slope,
+                               float* f32_out, void* plane, int64_t ld_plane, int32_t B, int32_t T, int32_t Tp, int32_t c, int32_t num_symbols,
+                               int32_t taps, int32_t split, void* stream) {
+    if (!ids || !table || !tap_table || (!f32_out && !plane)) return efts_fail(EFTS_EINVAL, "efts_embed_conv: null pointer");
+    if (c % 4 || c > 4096 || B <= 0 || T <= 0 || Tp < T || num_symbols <= 0 || !(taps == 1 || taps == 3 || taps == 5))
+        return efts_fail(EFTS_ESHAPE, "efts_embed_conv: c must be a multiple of 4 (<= 4096), taps 1 / 3 / 5");
+    if (((uintptr_t)table | (uintptr_t)tap_table | (uintptr_t)bias | (uintptr_t)f32_out) & 15) return efts_fail(EFTS_EALIGN, "efts_embed_conv: 16-byte aligned tables and output");
+    hipLaunchKernelGGL(embed_conv_kernel, dim3(B * Tp), dim3(((c / 4) + 63) & ~63), 0, ST, (const long*)ids, lengths, table, tap_table, bias, slope, f32_out,
+                       (char*)plane, (long)ld_plane, T, Tp, c, num_symbols, taps, split);
+    return efts_check_launch("efts_embed_conv");
 }
 
 extern "C" int efts_pack_rows(const float* x, float* f32_out, void* plane, int64_t ld_plane, int32_t B, int32_t T, int32_t Tp,

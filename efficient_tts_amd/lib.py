@@ -79,6 +79,7 @@ _SIGS = {
     "efts_pack_weight": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "efts_row_masks": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "efts_embed": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
+    "efts_embed_conv": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp]),
     "efts_pack_rows": (i32, [vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
     "efts_attn_soft_index": (i32, [vp, i64, vp, vp, vp, vp, i32, i32, i32, vp]),
     "efts_imv_scan": (i32, [vp, vp, vp, vp, i32, i32, vp]),

@@ -202,6 +202,7 @@ class EfficientTTSCNN(torch.nn.Module):
         self.fuse_soft_index = True         # T1 <= 128: q.k^T, softmax and soft index in one launch (False: scores stored, efts_attn_soft_index)
         self.small_m = True                 # free-running inference on short row spaces (<= SMALL_M_ROWS rows): the K-split small-M tiling of efts_gemm
         self._free_running = False          # set while inference() / inference_batch() enqueue their launches
+        self.embed_conv = True              # eval paths: embedding + text-encoder layer 0 as table look-ups (efts_embed_conv) instead of a 21-GFLOP launch
         self.ride_duration = False          # merged mode: the duration predictor's k3 convolutions ride in decoder launches 0, 2, LayerNorms on the second stream
                                             # (measured 1.665 vs 1.633 ms: a rider costs a whole tile step of the 13, off by default)
         self.share_cus = True               # merged mode: the prenet and the first text layers run side by side on disjoint halves of the CUs
@@ -310,6 +311,38 @@ class EfficientTTSCNN(torch.nn.Module):
             self._folded_gen = self._packed_gen      # this repack also wrote the training engine's derived copies
         return pk
 
+    def _te0_table(self, pk) -> Optional[torch.Tensor]:
+        """tap_table [k_size][num_symbols][C] of text-encoder layer 0: tap k's weights applied to every symbol's embedding, in the
+        operand format the model runs in (k_size one-tap efts_gemm launches over the embedding rows); rebuilt when the weights were
+        re-packed.  None when the look-up form does not apply."""
+        if not self.embed_conv or len(self.text_encoder.layers) == 0 or self.n_channels % 32:
+            return None
+        if getattr(self, "_te0_gen", None) == self._packed_gen and getattr(self, "_te0_tab", None) is not None:
+            return self._te0_tab
+        table = self.text_embedding_table.weight.detach()
+        V, C, K = table.shape[0], self.n_channels, self.k_size
+        dev = table.device
+        rsv = Rows(1, V)
+        plane = Plane.for_rows(rsv, C, self.split, dev)
+        with O.stream_scope():
+            O.embed(torch.arange(V, device=dev)[None], table, None, plane, rsv)
+            tab = torch.empty(K, V, C, dtype=torch.float32, device=dev)
+            w = pk["text_encoder.0"]
+            for k in range(K):
+                O.gemm(a=plane, b_ptr=w.ptr + k * w.tap_stride, ldb=w.ld, m=V, n=C, out_f32_ptr=tab[k].data_ptr(), ldo=C, tiling=L.TILING_GENERIC)
+        object.__setattr__(self, "_te0_tab", tab)
+        object.__setattr__(self, "_te0_gen", self._packed_gen)
+        object.__setattr__(self, "_te0_plane", plane)               # (kept alive: the launches above may still be in flight)
+        return tab
+
+    def _embed_te0(self, ws, pk, text, rs1: Rows, lens_i32: Optional[torch.Tensor], tab: torch.Tensor):
+        """embedding + text-encoder layer 0 in one gather launch -> (fp32 stream, operand plane) of layer 0's output"""
+        C = self.n_channels
+        x_f, x_p = ws.f32("te_f0", rs1, C), ws.plane("te_p0", rs1, C, self.split)
+        O.embed_conv(text, lens_i32, self.text_embedding_table.weight.detach(), tab, self.text_encoder.layers[0].conv[0].bias, self.slope,
+                     x_f, x_p, rs1)
+        return x_f, x_p
+
     def _side_stream(self, device) -> "torch.cuda.Stream":
         if not self.side_stream:
             return torch.cuda.current_stream(device)
@@ -376,18 +409,19 @@ class EfficientTTSCNN(torch.nn.Module):
         return kw, o_f32, y, y_lo
 
     def _res_stack(self, ws, tag, blk, pk, rs: Rows, x_f32: Optional[F32Rows], x_pl: Plane, gap_ptr, last_split: int,
-                   last_f32: bool, x_lo: Optional[Plane] = None, rider=None, after=None):
+                   last_f32: bool, x_lo: Optional[Plane] = None, rider=None, after=None, start: int = 0):
         """n x ( x + LeakyReLU(conv1d_k5(x)) ) on the row space (efts_modules.py:48-51,77-79).
         `rider(i)`: optional, returns the efts_resconv5 keyword set of an independent layer of the same geometry that shares
-        layer i's persistent launch (or None); `after(i)`: optional, called when layer i's launch has been enqueued."""
+        layer i's persistent launch (or None); `after(i)`: optional, called when layer i's launch has been enqueued; `start`: first
+        layer to run (x is then the output of layer start - 1)."""
         n = len(getattr(self, blk).layers)
         C = self.n_channels
         if self._on_resconv(rs):
             # The stream between the layers is a pair of bf16 planes (hi = the next layer's MFMA operand, lo = the
             # remainder; split 2 planes carry both): 4 B read + 4 B written per element and layer instead of 4 + 6..8 B.
             o_f32 = None
-            for i in range(n):
-                kw, o_f32, y, y_lo = self._res_layer_args(ws, tag, blk, pk, rs, i, n, x_f32 if i == 0 else None, x_pl, x_lo, gap_ptr, last_split, last_f32)
+            for i in range(start, n):
+                kw, o_f32, y, y_lo = self._res_layer_args(ws, tag, blk, pk, rs, i, n, x_f32 if i == start else None, x_pl, x_lo, gap_ptr, last_split, last_f32)
                 extra = rider(i) if rider is not None else None
                 if extra is not None:
                     O.resconv5_multi([kw, extra])
@@ -398,7 +432,7 @@ class EfficientTTSCNN(torch.nn.Module):
                 x_pl, x_lo = y, y_lo
             return o_f32, x_pl
         assert rider is None and after is None
-        for i in range(n):
+        for i in range(start, n):
             last = i == n - 1
             w = pk[f"{blk}.{i}"]
             o_split = last_split if last else self.split
@@ -416,10 +450,19 @@ class EfficientTTSCNN(torch.nn.Module):
         (efficient_tts.py:144-157 / :246-255).  `on_key()` is called as soon as the key projection is enqueued (the q.k^T launch
         of the other stream waits for that, not for the value); `vt`: also pack V^T for the alpha'.V launch here."""
         C = self.n_channels
-        x_f = ws.f32("emb_f", rs1, C)
-        x_p = ws.plane("emb_p", rs1, C, self.split)
-        O.embed(text, self.text_embedding_table.weight.detach(), x_f, x_p, rs1)
-        _, h_p = self._res_stack(ws, "te", "text_encoder", pk, rs1, x_f, x_p, gap1.data_ptr(), self.split, False)
+        tab = self._te0_table(pk)
+        if tab is not None:                                    # embedding + layer 0 as table look-ups; padded ids are real symbols here
+            x_f, x_p = self._embed_te0(ws, pk, text, rs1, None, tab)
+            start = 1
+        else:
+            x_f = ws.f32("emb_f", rs1, C)
+            x_p = ws.plane("emb_p", rs1, C, self.split)
+            O.embed(text, self.text_embedding_table.weight.detach(), x_f, x_p, rs1)
+            start = 0
+        if start < len(self.text_encoder.layers):
+            _, h_p = self._res_stack(ws, "te", "text_encoder", pk, rs1, x_f, x_p, gap1.data_ptr(), self.split, False, start=start)
+        else:
+            h_p = x_p
         key_p = self._key_proj(ws, pk, rs1, h_p, gap1, len1)
         if on_key is not None:
             on_key()
@@ -542,11 +585,12 @@ class EfficientTTSCNN(torch.nn.Module):
             return self._forward_impl(text, text_lengths, speech, speech_lengths)[0]
         # per-shape hipGraph: the launches of this shape are replayed as one graph (efficient_tts_amd/graphs.py)
         pk = self._weights()                                  # (re)packing stays outside the graph
+        self._te0_table(pk)                                   # ... and so does the tap table of text-encoder layer 0
         dev = text.device
         key = ("fwd", tuple(text.shape), tuple(speech.shape), text.dtype, speech.dtype, text_lengths.dtype, speech_lengths.dtype)
         ws = self._workspace(("fwd", text.shape[0], text.shape[1], speech.shape[1]), dev)
         # the graph is valid while the buffers its launches point at live: this workspace, the packed planes, the parameters
-        tag = (ws.serial, self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.side_stream, self.RESCONV_MIN_ROWS, self.fuse_soft_index, self.fuse_prenet, self.fuse_align, self.fuse_expand, self.merge_text, self.share_cus, self.ride_duration)
+        tag = (ws.serial, self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.side_stream, self.RESCONV_MIN_ROWS, self.fuse_soft_index, self.fuse_prenet, self.fuse_align, self.fuse_expand, self.merge_text, self.share_cus, self.ride_duration, self.embed_conv)
 
         def body(t, tl, sp, sl):
             (_, stats, imv, ralpha, mel_pred, _), _ = self._forward_impl(t, tl, sp, sl)
@@ -615,22 +659,28 @@ class EfficientTTSCNN(torch.nn.Module):
             # A persistent launch owns every CU's LDS, so a text-length launch of its own beside it would get the 4 spare CUs:
             # only the first nt - nm text layers run by themselves (efts_resconv5 on the short row space), beside the HBM-bound
             # prenet on the second stream.
-            nr = min(nt, nm)
+            nr = min(nt - (1 if self._te0_table(pk) is not None else 0), nm)       # (layer 0 may be table look-ups: it never rides)
             ns = nt - nr                                                           # text layers that run by themselves first
             pre_ready, te_done = torch.cuda.Event(), torch.cuda.Event()
             # The first text layers and the prenet share the chip by halves: both kinds of workgroup take a whole CU (LDS), the
             # prenet is bound by HBM -- which half the CUs saturate -- and a text-length layer by streaming its weights, so the
             # prenet's grid is capped at half the CUs and the text layers are scheduled onto the other half.
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
-            share = self.share_cus and ns > 0 and cus >= 64
+            share = self.share_cus and ns > (1 if self._te0_table(pk) is not None else 0) and cus >= 64
             with O.on_stream(side):
                 pre = prenet(cus // 2 if share else 0)
                 pre_ready.record(side)
             te_plan = O.resconv5_plan_buf(rs1.rows, C, cus // 2 - 2) if share else None
             O.row_masks(tl, rs1, gap1, len1)                                      # :137
-            x_f = ws.f32("emb_f", rs1, C)
-            x_p = ws.plane("emb_p", rs1, C, self.split)
-            O.embed(text, self.text_embedding_table.weight.detach(), x_f, x_p, rs1)          # :144
+            tab = self._te0_table(pk)
+            if tab is not None:                                                   # :144 + layer 0 of :148 as table look-ups
+                x_f, x_p = self._embed_te0(ws, pk, text, rs1, None, tab)
+                first = 1
+            else:
+                x_f = ws.f32("emb_f", rs1, C)
+                x_p = ws.plane("emb_p", rs1, C, self.split)
+                O.embed(text, self.text_embedding_table.weight.detach(), x_f, x_p, rs1)      # :144
+                first = 0
             tstate = dict(x_f=x_f, x_p=x_p, x_lo=None)
 
             def text_layer(i):                                                    # efts_resconv5 keyword set of text layer i (:148)
@@ -639,7 +689,7 @@ class EfficientTTSCNN(torch.nn.Module):
                 tstate.update(x_f=None, x_p=y, x_lo=y_lo)
                 return kw
 
-            for i in range(ns):
+            for i in range(first, ns):
                 O.resconv5(plan=te_plan, **text_layer(i))
             main.wait_event(pre_ready)
             q_p = mel_stack(*pre, rider=lambda i: text_layer(ns + i - (nm - nr)) if i >= nm - nr else None)
@@ -793,11 +843,20 @@ class EfficientTTSCNN(torch.nn.Module):
         gap1, len1 = ws.tensor("gap1", (rs1.rows,)), ws.tensor("len1", (rs1.rows,))
         O.row_masks(tl, rs1, gap1, len1)
         # embedding with padded positions zeroed, then every layer masked by the item length
-        e_f = ws.f32("emb_raw", rs1, C)
-        O.embed(text.contiguous(), self.text_embedding_table.weight.detach(), e_f, None, rs1)
-        x_f, x_p = ws.f32("emb_f", rs1, C), ws.plane("emb_p", rs1, C, self.split)
-        O.mask_rows(e_f.ptr, len1.data_ptr(), x_f, x_p, rs1.rows, C)
-        _, h_p = self._res_stack(ws, "te", "text_encoder", pk, rs1, x_f, x_p, len1.data_ptr(), self.split, False)
+        tab = self._te0_table(pk)
+        if tab is not None:                                    # embedding + layer 0 as table look-ups, zero beyond each item's length
+            x_f, x_p = self._embed_te0(ws, pk, text.contiguous(), rs1, tl, tab)
+            start = 1
+        else:
+            e_f = ws.f32("emb_raw", rs1, C)
+            O.embed(text.contiguous(), self.text_embedding_table.weight.detach(), e_f, None, rs1)
+            x_f, x_p = ws.f32("emb_f", rs1, C), ws.plane("emb_p", rs1, C, self.split)
+            O.mask_rows(e_f.ptr, len1.data_ptr(), x_f, x_p, rs1.rows, C)
+            start = 0
+        if start < len(self.text_encoder.layers):
+            _, h_p = self._res_stack(ws, "te", "text_encoder", pk, rs1, x_f, x_p, len1.data_ptr(), self.split, False, start=start)
+        else:
+            h_p = x_p
         val_f, val_p = ws.f32("val_f", rs1, C), ws.plane("val_p", rs1, C, self.split)
         shared = self.share_text_encoder_key_value            # (:252-253)
         wv = pk["key"] if shared else pk["value"]
@@ -859,7 +918,8 @@ class EfficientTTSCNN(torch.nn.Module):
             if T1b != T1:
                 text = torch.nn.functional.pad(text, (0, T1b - T1))
             pk = self._weights()
-            wsig = (self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.RESCONV_MIN_ROWS, self.fuse_expand, self.small_m, self.SMALL_M_ROWS)
+            self._te0_table(pk)                               # (built outside the graphs, like the packed planes)
+            wsig = (self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.RESCONV_MIN_ROWS, self.fuse_expand, self.small_m, self.SMALL_M_ROWS, self.embed_conv)
             ws = self._workspace(("infb", B, T1b), dev)
             if graphs:
                 def phase1(t, l):

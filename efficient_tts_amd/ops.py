@@ -303,6 +303,15 @@ def embed(ids: torch.Tensor, table: torch.Tensor, out: Optional[F32Rows], plane:
             "efts_embed")
 
 
+def embed_conv(ids: torch.Tensor, lens: Optional[torch.Tensor], table: torch.Tensor, tap_table: torch.Tensor, bias: Optional[torch.Tensor],
+               slope: float, out: Optional[F32Rows], plane: Optional[Plane], rs: Rows) -> None:
+    """embedding + the first residual convolution of the text encoder as table look-ups (efts_embed_conv); tap_table [taps][V][c]"""
+    taps, nsym, c = tap_table.shape
+    L.check(L.load().efts_embed_conv(ids.data_ptr(), _p(lens), table.data_ptr(), tap_table.data_ptr(), _p(bias), slope,
+                                     None if out is None else out.ptr, None if plane is None else plane.ptr, 0 if plane is None else plane.ld,
+                                     rs.B, rs.T, rs.Tp, c, nsym, taps, 1 if plane is None else plane.split, _stream()), "efts_embed_conv")
+
+
 def pack_rows(x: torch.Tensor, out: Optional[F32Rows], plane: Optional[Plane], rs: Rows) -> None:
     c = x.shape[-1]
     kp = roundup(c, 4) if plane is None else plane.nchunk * chunk_k(plane.split)

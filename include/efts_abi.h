@@ -262,6 +262,18 @@ int efts_embed(const int64_t* ids, const float* table, float* f32_out, void* pla
                void* stream);
 int efts_pack_rows(const float* x, float* f32_out, void* plane, int64_t ld_plane, int32_t B, int32_t T,
                    int32_t Tp, int32_t c, int32_t kp, int32_t split, void* stream);
+/* Embedding AND the first residual convolution of the text encoder (efficient_tts.py:144 + the first ResConv1d of :148,
+ * nntts/layers/efts_modules.py:48-51) as table look-ups: that layer's input takes only num_symbols distinct values per position and
+ * the convolution is linear, so tap k's product with every symbol's embedding is tabulated once per weight set --
+ * tap_table[k][v][:] = W_k . table[v] (fp32 [taps][num_symbols][c]; build it with `taps` one-tap efts_gemm launches over the
+ * embedding rows, in the operand format the model runs in) -- and the layer becomes
+ *   y[b * Tp + t] = table[id_t] + LeakyReLU( bias + sum_k tap_table[k][ id_{t + k - (taps-1)/2} ], slope )
+ * with positions outside [0, lim) contributing nothing: lim = T (lengths NULL: padded ids are real symbols, the reference's
+ * teacher-forced semantics) or lengths[b] (zero embedding and zero output beyond an item's length: batched free-running inference).
+ * Same outputs as efts_embed (fp32 rows and / or operand plane, gap rows zero). */
+int efts_embed_conv(const int64_t* ids, const int32_t* lengths, const float* table, const float* tap_table, const float* bias, float slope,
+                    float* f32_out, void* plane, int64_t ld_plane, int32_t B, int32_t T, int32_t Tp, int32_t c, int32_t num_symbols,
+                    int32_t taps, int32_t split, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Alignment block (fp32 VALU, HBM-bound).

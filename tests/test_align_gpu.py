@@ -171,3 +171,50 @@ def test_hardware_bf16_rounding_equals_the_integer_form():
     assert torch.equal(y1[big], want[big])
     bad = (y0 != y1)
     assert int(bad.sum()) == 0, f"{int(bad.sum())} of {n} differ, e.g. {x[bad][:4].tolist()}"
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("masked", [False, True])
+def test_embed_conv_equals_embedding_plus_first_text_layer(precision, masked):
+    """efts_embed_conv (embedding + text-encoder layer 0 as table look-ups over the 76 symbols) against efts_embed + the layer's
+    efts_gemm launch on the same packed weights: equal to fp32 summation-order noise (same operand rounding: the tap table is built
+    with one-tap efts_gemm launches in the model's operand format); masked mode = zero embedding and zero output beyond a length"""
+    from efficient_tts_amd import EfficientTTSCNN, lib as L, ops as P
+    from oracle import efts_oracle as O
+    dev = _dev()
+    m = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, sigma=0.01, precision=precision)
+    m.load_state_dict(O.fill_params())
+    m = m.to(dev).eval()
+    pk = m._weights()
+    tab = m._te0_table(pk)
+    assert tab is not None and tab.shape == (5, 76, 512)
+    B, T = 5, 61
+    g = torch.Generator().manual_seed(9)
+    text = torch.randint(0, 76, (B, T), generator=g).to(dev)
+    lens = torch.tensor([61, 40, 1, 17, 60], dtype=torch.int32, device=dev)
+    rs = P.Rows(B, T)
+    C = 512
+    gap, lenm = torch.zeros(rs.rows, device=dev), torch.zeros(rs.rows, device=dev)
+    P.row_masks(lens, rs, gap, lenm)
+    # reference chain: embedding (masked mode: zeroed beyond the length), then the layer through efts_gemm
+    e_f, x_f, x_p = P.F32Rows(rs, C, dev), P.F32Rows(rs, C, dev), P.Plane.for_rows(rs, C, m.split, dev)
+    if masked:
+        P.embed(text, m.text_embedding_table.weight.detach(), e_f, None, rs)
+        P.mask_rows(e_f.ptr, lenm.data_ptr(), x_f, x_p, rs.rows, C)
+    else:
+        P.embed(text, m.text_embedding_table.weight.detach(), x_f, x_p, rs)
+    w = pk["text_encoder.0"]
+    y_ref, p_ref = P.F32Rows(rs, C, dev), P.Plane.for_rows(rs, C, m.split, dev)
+    P.gemm(a=x_p, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=5, m=rs.rows, n=C, act=L.ACT_LEAKY, slope=m.slope,
+           bias=m.text_encoder.layers[0].conv[0].bias, resid_ptr=x_f.ptr, ldr=C, rowmask_ptr=(lenm if masked else gap).data_ptr(),
+           out_f32_ptr=y_ref.ptr, ldo=C, out_plane=p_ref)
+    y, p = P.F32Rows(rs, C, dev), P.Plane.for_rows(rs, C, m.split, dev)
+    P.embed_conv(text, lens if masked else None, m.text_embedding_table.weight.detach(), tab, m.text_encoder.layers[0].conv[0].bias, m.slope, y, p, rs)
+    torch.cuda.synchronize()
+    scale = float(y_ref.buf.abs().max())
+    assert float((y.buf - y_ref.buf).abs().max()) <= 2e-6 * scale
+    assert float(y.buf[:L.GUARD_LO].abs().max()) == 0.0 and float(y.view()[2, 1:].abs().max() if masked else 0.0) == 0.0
+    gaprows = y.buf[L.GUARD_LO:L.GUARD_LO + rs.rows].view(B, rs.Tp, C)[:, T:]
+    assert float(gaprows.abs().max()) == 0.0
+    pa, pb = p.buf.view(torch.bfloat16).float(), p_ref.buf.view(torch.bfloat16).float()
+    assert float((pa - pb).abs().max()) <= 2.0 ** -7 * scale          # same values up to one bf16 ulp where the fp32 sums differ in the last bit
