@@ -117,7 +117,8 @@ __global__ void embed_conv_kernel(const long* __restrict__ ids, const int* __res
     if (t < lim) {
         const long* idr = ids + (long)b * T;
         auto sym = [&](int tt) { long id = idr[tt]; return (int)(id < 0 ? 0 : (id >= nsym ? nsym - 1 : id)); };
-        float4 acc = bias ? *(const float4*)(bias + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // (bias and the embedding table are parameters: inside a fused optimizer's flat buffer they are only 4-byte aligned)
+        float4 acc = bias ? make_float4(bias[c4], bias[c4 + 1], bias[c4 + 2], bias[c4 + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         const int pad = (taps - 1) >> 1;
         for (int k = 0; k < taps; ++k) {
             const int tt = t + k - pad;
@@ -125,7 +126,8 @@ __global__ void embed_conv_kernel(const long* __restrict__ ids, const int* __res
             const float4 p = *(const float4*)(taptab + ((long)k * nsym + sym(tt)) * c + c4);
             acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
         }
-        const float4 e = *(const float4*)(table + (long)sym(t) * c + c4);
+        const float* er = table + (long)sym(t) * c + c4;
+        const float4 e = make_float4(er[0], er[1], er[2], er[3]);
         v.x = e.x + (acc.x > 0.f ? acc.x : acc.x * slope);
         v.y = e.y + (acc.y > 0.f ? acc.y : acc.y * slope);
         v.z = e.z + (acc.z > 0.f ? acc.z : acc.z * slope);
@@ -560,7 +562,7 @@ extern "C" int efts_embed_conv(const int64_t* ids, const int32_t* lengths, const
     if (!ids || !table || !tap_table || (!f32_out && !plane)) return efts_fail(EFTS_EINVAL, "efts_embed_conv: null pointer");
     if (c % 4 || c > 4096 || B <= 0 || T <= 0 || Tp < T || num_symbols <= 0 || !(taps == 1 || taps == 3 || taps == 5))
         return efts_fail(EFTS_ESHAPE, "efts_embed_conv: c must be a multiple of 4 (<= 4096), taps 1 / 3 / 5");
-    if (((uintptr_t)table | (uintptr_t)tap_table | (uintptr_t)bias | (uintptr_t)f32_out) & 15) return efts_fail(EFTS_EALIGN, "efts_embed_conv: 16-byte aligned tables and output");
+    if (((uintptr_t)tap_table | (uintptr_t)f32_out) & 15) return efts_fail(EFTS_EALIGN, "efts_embed_conv: 16-byte aligned tap table and output");
     hipLaunchKernelGGL(embed_conv_kernel, dim3(B * Tp), dim3(((c / 4) + 63) & ~63), 0, ST, (const long*)ids, lengths, table, tap_table, bias, slope, f32_out,
                        (char*)plane, (long)ld_plane, T, Tp, c, num_symbols, taps, split);
     return efts_check_launch("efts_embed_conv");
