@@ -12,8 +12,13 @@ from .model import LazyStats
 from .train import TrainEngine
 
 
-def engine_of(model) -> TrainEngine:
+def engine_of(model, params=None) -> TrainEngine:
+    """the model's training engine; `params` = tuple(model.parameters()) when the caller already walked the module tree (the
+    per-step path: one walk per step instead of one per check)"""
     eng = getattr(model, "_engine", None)
+    if eng is not None and params is not None and len(params) == len(eng.params) and params[0].device == eng.dev \
+            and all(a is b for a, b in zip(params, eng.params)):
+        return eng                                           # same Parameter objects on the same device: the layout still holds
     if eng is None or eng.dev != next(model.parameters()).device or eng.stale(model):
         if eng is not None and getattr(eng, "bound", None):
             # a fused optimizer / bucket reducer holds the OLD engine's flat gradient buffer: rebuilding silently would
@@ -28,10 +33,12 @@ def engine_of(model) -> TrainEngine:
 class _FusedStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, text, text_lengths, speech, speech_lengths, *params):
-        eng = engine_of(model)
+        eng = engine_of(model, params)
+        eng.step_params = params
         out3, _ = eng.forward_backward(text, text_lengths, speech, speech_lengths)
+        eng.step_params = None
         ctx.eng = eng
-        ctx.named = list(model.named_parameters())
+        ctx.named = eng.named                                # (name, Parameter) in model.parameters() order, as `params`
         ctx.mark_non_differentiable(out3)
         return out3[0].clone(), out3
 
@@ -57,7 +64,6 @@ class _FusedStep(torch.autograd.Function):
 def training_forward(model, text, text_lengths, speech, speech_lengths):
     params = tuple(model.parameters())
     loss, out3 = _FusedStep.apply(model, text, text_lengths, speech, speech_lengths, *params)
-    eng = engine_of(model)
     ws = model._workspace(("train", text.shape[0], text.shape[1], speech.shape[1]), text.device)
     rs2 = ws.bufs[("f", "Tmel_pred", text.shape[0], speech.shape[1], model.odim)]
     imv = ws.bufs[("t", "Timv", (text.shape[0], speech.shape[1]), torch.float32)]

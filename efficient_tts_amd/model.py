@@ -249,7 +249,7 @@ class EfficientTTSCNN(torch.nn.Module):
         return out
 
     def _weights(self, folded: Optional[Dict[str, torch.Tensor]] = None,
-                 wt: Optional[Dict[str, PackedWeight]] = None) -> Dict[str, PackedWeight]:
+                 wt: Optional[Dict[str, PackedWeight]] = None, params=None) -> Dict[str, PackedWeight]:
         """B operand planes of every Conv1d/Linear; repacked (weight-norm fold fused) whenever
         a parameter changed (optimizer step, load_state_dict, .to()).  Training engine extras, produced by the same
         launches: `folded[name]` (fp32 [cout][cin][taps]) receives the folded weight g * v / ||v|| of a weight-normed
@@ -257,7 +257,7 @@ class EfficientTTSCNN(torch.nn.Module):
         call (`efts_pack_weights_grouped`, a device-side item table) instead of a launch each.
         `_packed_sig` cannot see in-place updates made by the fused optimizer kernel (no version bump), which is
         why EftsAdam resets it and why consumers of derived data compare `_packed_gen`, never the signature."""
-        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        sig = tuple((p.data_ptr(), p._version) for p in (params if params is not None else self.parameters()))
         if sig == self._packed_sig:
             return self._packed
         self._ptr_sig = hash(tuple(a for a, _ in sig))       # parameter storage identity (captured graphs hold these pointers)
@@ -571,7 +571,7 @@ class EfficientTTSCNN(torch.nn.Module):
                 speech_lengths: torch.Tensor):
         """Teacher-forced forward.  Returns (loss, stats, imv[B,T2], reconst_alpha[B,T1,T2],
         mel_pred[B,T2,odim], speech) exactly like the reference (:228)."""
-        training_path = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        training_path = torch.is_grad_enabled() and (self.text_embedding_table.weight.requires_grad or any(p.requires_grad for p in self.parameters()))
         if not training_path and self.training and self.dropout_rate >= 1e-5:
             # the reference would apply ResConv1d's / the prenet's Dropout here (efts_modules.py:38-47, efficient_tts.py:76-80); the
             # masks live in the fused training pass only: refuse instead of returning a dropout-free result in train() mode

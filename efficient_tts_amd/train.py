@@ -30,6 +30,7 @@ _SIGN_MIN_ROWS = 16384       # row spaces from here on: the forward convolutions
 _WGRAD_TN_SMALL = 1          # key / value / query Linears and the duration predictor's k3 convolutions: weight gradient straight from
                              # the row-major planes too (taps 1 / 3) instead of two transposed copies + a split-K efts_gemm (0: the latter)
 _BIAS_PARTS = 1              # direct-wgrad layers: bias gradient as per-row-block sums finished by the wgrad reduction (0: atomics in act_bwd)
+_FRAME_PRENET = 1            # prenet without Dropout straight from the caller's frames (efts_frame_linear); 0: efts_gemm over the packed mel plane
 _WGRAD_WGS = 480             # split-K target: 480 workgroups per wgrad launch measured best (6.30 vs 6.60 ms/step at 640)
 
 
@@ -82,6 +83,9 @@ class TrainEngine:
     def __init__(self, model):
         self.m = model
         self.layout = grad_layout(model)
+        self.named = list(model.named_parameters())     # model.parameters() order (what autograd's Function receives)
+        self.params = tuple(p for _, p in self.named)
+        self.step_params = None                         # tuple(model.parameters()) of the running step (autograd.py), saves re-walks
         self.dev = next(model.parameters()).device
         self.numel = sum(p.numel() for _, p in self.layout)
         pad = (-self.numel) % 4
@@ -134,10 +138,10 @@ class TrainEngine:
         for name, lin in lins:
             if name not in self.wt:
                 self.wt[name] = PackedWeight(lin.in_features, lin.out_features, 1, m.split, dev)
-        pk = m._weights(self.folded, self.wt)
+        pk = m._weights(self.folded, self.wt, self.step_params)
         if m._folded_gen != m._packed_gen:
             m._packed_sig = None                # the last repack (an eval forward) did not write the copies kept here
-            pk = m._weights(self.folded, self.wt)
+            pk = m._weights(self.folded, self.wt, self.step_params)
         return pk
 
     # ------------------------------------------------------------------ small wrappers
@@ -350,12 +354,17 @@ class TrainEngine:
             self._ws_tag = ""
 
         mel_in_f, mel_in = ws.f32("Tmel_in_f", rs2, odim), ws.plane("Tmel_in", rs2, odim, split)
-        O.pack_rows(speech, mel_in_f, mel_in, rs2)
+        O.pack_rows(speech, mel_in_f, mel_in, rs2)                  # (the backward's wgrad of the prenet reads both)
         pre_f, pre_p = ws.f32("Tpre_f", rs2, C), ws.plane("Tpre_p", rs2, C, split)
         wp = pk["prenet"]
         pre_dp, pre_seed = self._conv_drop(40)                       # mel_prenet's Dropout (efficient_tts.py:76-80)
-        O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, act=L.ACT_LEAKY, slope=m.slope, bias=m.mel_prenet[0].bias,
-               rowmask_ptr=gap2.data_ptr(), out_f32_ptr=pre_f.ptr, ldo=C, out_plane=pre_p, drop_p=pre_dp, drop_seed=pre_seed)
+        if _FRAME_PRENET and pre_dp == 0.0 and m.fuse_prenet and odim % 8 == 0 and odim <= 128 and C % 128 == 0:
+            # no Dropout on the prenet (the shipped recipe): straight from the caller's frames, whole-line stores (efts_frame_linear;
+            # bit-identical to the launch below)
+            O.frame_linear(x=speech, w=wp, bias=m.mel_prenet[0].bias, act=L.ACT_LEAKY, slope=m.slope, rs=rs2, y=pre_p, y_f32=pre_f)
+        else:
+            O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, act=L.ACT_LEAKY, slope=m.slope, bias=m.mel_prenet[0].bias,
+                   rowmask_ptr=gap2.data_ptr(), out_f32_ptr=pre_f.ptr, ldo=C, out_plane=pre_p, drop_p=pre_dp, drop_seed=pre_seed)
         if m.mel_query_fc is None:
             q_f, q_p, me_saved = self._stack_fwd(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2)
         else:                                                       # efficient_tts.py:163-164: Linear(C, C) in front of the attention
