@@ -14,6 +14,22 @@ from typing import Callable, Sequence, Tuple
 import torch
 
 
+class PadTo:
+    """an input of GraphCache.run that is copied into the leading corner of a zero-filled static buffer of `shape` (a ragged batch
+    padded up to its bucket without a pad launch of its own)"""
+
+    def __init__(self, t: torch.Tensor, shape):
+        self.t, self.shape = t, tuple(shape)
+
+    def padded(self) -> torch.Tensor:
+        out = torch.zeros(self.shape, dtype=self.t.dtype, device=self.t.device)
+        out[tuple(slice(0, n) for n in self.t.shape)].copy_(self.t)
+        return out
+
+    def into(self, static: torch.Tensor) -> None:
+        static[tuple(slice(0, n) for n in self.t.shape)].copy_(self.t, non_blocking=True)
+
+
 class _Entry:
     __slots__ = ("calls", "graph", "static_in", "static_out", "tag", "keepalive", "eager_only")
 
@@ -30,11 +46,15 @@ class GraphCache:
     def clear(self) -> None:
         self.entries.clear()
 
-    def run(self, key: tuple, tag, inputs: Sequence[torch.Tensor], fn: Callable[..., Tuple[torch.Tensor, ...]], keepalive=None, clone: bool = True):
-        """fn(*inputs) -> tuple of tensors, pure device work on the current stream (no host sync).  `tag` invalidates the
+    def run(self, key: tuple, tag, inputs: Sequence, fn: Callable[..., Tuple[torch.Tensor, ...]], keepalive=None, clone: bool = True,
+            refs: Sequence[torch.Tensor] = ()):
+        """fn(*inputs, *refs) -> tuple of tensors, pure device work on the current stream (no host sync).  `tag` invalidates the
         captured graph when it changes (the buffers the launches point at were re-allocated); `keepalive` is held as long as
         the graph is (the owner of those buffers).  clone=False returns the graph's static output tensors themselves (valid until
-        the next replay of this entry) instead of fresh copies."""
+        the next replay of this entry) instead of fresh copies.  An input may be a PadTo.  `refs`: inputs the graph reads IN PLACE
+        (no static copies): buffers that are stable from call to call -- another entry's static outputs -- whose addresses join
+        the tag, so a new buffer means a new capture."""
+        tag = (tag, tuple(t.data_ptr() for t in refs))
         ent = self.entries.get(key)
         if ent is None:
             ent = self.entries[key] = _Entry()
@@ -44,25 +64,32 @@ class GraphCache:
         if ent.graph is not None and ent.tag != tag:
             ent.graph, ent.static_in, ent.static_out, ent.keepalive, ent.calls = None, None, None, None, 1
         ent.calls += 1
+
+        def plain():
+            return fn(*[t.padded() if isinstance(t, PadTo) else t for t in inputs], *refs)
+
         if ent.calls == 1 or ent.eager_only:                 # first sight of this shape: plain eager run (also the warm-up)
-            return fn(*inputs)
+            return plain()
         if ent.graph is None:
-            ent.static_in = [t.clone() for t in inputs]
+            ent.static_in = [t.padded() if isinstance(t, PadTo) else t.clone() for t in inputs]
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
             try:
                 # thread_local: HIP calls of OTHER threads (a DataLoader's pin-memory thread, the allocator, RCCL's proxy) during
                 # the capture do not invalidate it
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    ent.static_out = fn(*ent.static_in)
+                    ent.static_out = fn(*ent.static_in, *refs)
             except Exception as exc:                         # noqa: BLE001 -- any capture failure: this shape runs eagerly from now on
                 logging.warning("hipGraph capture failed for %s (%s): the shape stays on eager launches", key[0], exc)
                 ent.eager_only, ent.static_in, ent.static_out, ent.keepalive = True, None, None, None
                 torch.cuda.synchronize()
-                return fn(*inputs)
-            ent.graph, ent.tag, ent.keepalive = g, tag, keepalive
+                return plain()
+            ent.graph, ent.tag, ent.keepalive = g, tag, (keepalive, tuple(refs))
         else:
             for s, t in zip(ent.static_in, inputs):
-                s.copy_(t, non_blocking=True)
+                if isinstance(t, PadTo):
+                    t.into(s)
+                else:
+                    s.copy_(t, non_blocking=True)
         ent.graph.replay()
         return tuple(ent.static_out) if not clone else tuple(t.clone() for t in ent.static_out)

@@ -17,7 +17,7 @@ import torch
 
 from . import lib as L
 from . import ops as O
-from .graphs import GraphCache
+from .graphs import GraphCache, PadTo
 from .ops import F32Rows, PackedWeight, Plane, Rows, roundup
 
 
@@ -211,6 +211,7 @@ class EfficientTTSCNN(torch.nn.Module):
         self.fuse_expand = True             # T1 <= 256: alpha' generated in registers inside the expand contraction (efts_expand); False: reconst_alpha + pack_vt + efts_gemm
         self.graphs = True                  # plain eval calls replay a per-shape hipGraph (False: every kernel launched eagerly)
         self._graph_cache = GraphCache()
+        self._len1 = {}
         self._infer_cache = GraphCache(capacity=64)      # free-running inference: two phases per (bucketed) shape
         self.side_stream = True             # text-length work on a second HIP stream beside the mel-length kernels
         self.resconv = True                 # long row spaces: residual stacks on efts_resconv5 (False: efts_gemm + fp32 stream, A/B and tests)
@@ -801,8 +802,13 @@ class EfficientTTSCNN(torch.nn.Module):
             # below to ~1e-4), on bucketed shapes whose launches replay as two hipGraphs around the one host sync
             # (text_lengths is accepted and ignored, like the reference's inference(): efficient_tts.py:233, :243 -- every position
             # of `text` is synthesised; ragged batches go through inference_batch())
-            tl1 = torch.full((1,), text.shape[1], dtype=torch.int64, device=text.device)
-            mel, _, ralpha = self.inference_batch(text, tl1)
+            key = (text.device, text.shape[1])
+            tl1 = self._len1.get(key)
+            if tl1 is None:                                  # one int32 [T1] per length: no fill + cast launches per call
+                if len(self._len1) > 4096:
+                    self._len1.clear()
+                tl1 = self._len1[key] = torch.full((1,), text.shape[1], dtype=torch.int32, device=text.device)
+            mel, _, ralpha = self._inference_batch_impl(text, None, None, tl_i32=tl1, want_lengths=False)
             return mel, ralpha
         dev = text.device
         T1, C = text.shape[1], self.n_channels
@@ -907,16 +913,16 @@ class EfficientTTSCNN(torch.nn.Module):
         finally:
             self._free_running = prev
 
-    def _inference_batch_impl(self, text, text_lengths, force_delta):
+    def _inference_batch_impl(self, text, text_lengths, force_delta, tl_i32: Optional[torch.Tensor] = None, want_lengths: bool = True):
+        """tl_i32: the lengths already as an int32 device tensor (inference() keeps one per length); want_lengths=False: the caller
+        drops the mel lengths (inference()), so they are not converted"""
         self._require(text)
         with O.stream_scope():
             dev = text.device
             B, T1 = text.shape
-            tl = text_lengths.to(device=dev, dtype=torch.int32)
+            tl = tl_i32 if tl_i32 is not None else text_lengths.to(device=dev, dtype=torch.int32)
             graphs = self.graphs and not torch.cuda.is_current_stream_capturing()
             T1b = roundup(T1, self.T1_BUCKET) if graphs else T1
-            if T1b != T1:
-                text = torch.nn.functional.pad(text, (0, T1b - T1))
             pk = self._weights()
             self._te0_table(pk)                               # (built outside the graphs, like the packed planes)
             wsig = (self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.RESCONV_MIN_ROWS, self.fuse_expand, self.small_m, self.SMALL_M_ROWS, self.embed_conv)
@@ -924,13 +930,17 @@ class EfficientTTSCNN(torch.nn.Module):
             if graphs:
                 def phase1(t, l):
                     with O.stream_scope():              # resolved INSIDE the capture: the launches must go to the capturing stream
-                        return self._infer_text(ws, t, l, force_delta)
-                # (the graph's static outputs are handed on as they are: phase 2 copies them into ITS static inputs before anything
-                # can overwrite them, and nothing else keeps them)
-                e, ml = self._infer_cache.run(("text", B, T1b, force_delta), (ws.serial, wsig), (text.contiguous(), tl), phase1, keepalive=ws, clone=False)
+                        return self._infer_text(ws, t, l, force_delta) + (l,)
+                stable = tl_i32 is not None             # (inference()'s per-length constant: read in place, not copied per call)
+                # The graph's static outputs -- and its static copy of the lengths -- are handed on as they are: phase 2 reads them in
+                # place (`refs`: no copies into inputs of its own; a re-captured phase 1 means new buffers, hence a new phase-2 capture).
+                # The ids go straight into the zero-filled bucket-wide static input (positions beyond an item's length are ignored).
+                ids = PadTo(text, (B, T1b)) if T1b != T1 else text.contiguous()
+                e, ml, tl = self._infer_cache.run(("text", B, T1b, force_delta, stable), (ws.serial, wsig), (ids,) if stable else (ids, tl), phase1,
+                                                  keepalive=ws, clone=False, refs=(tl,) if stable else ())
             else:
                 e, ml = self._infer_text(ws, text, tl, force_delta)
-            t2 = int(ml.max().item())                                                      # the one host sync
+            t2 = int((ml if B == 1 else ml.max()).item())                                  # the one host sync
             if t2 <= 0:
                 raise ValueError("predicted total durations round to 0 frames")
             T2b = roundup(t2, self.T2_BUCKET) if graphs else t2
@@ -939,9 +949,14 @@ class EfficientTTSCNN(torch.nn.Module):
                 def phase2(e_, l, m):
                     with O.stream_scope():
                         return self._infer_mel(ws, ws2, e_, l, m, T2b)
-                mel, ralpha = self._infer_cache.run(("mel", B, T1b, T2b), (ws.serial, ws2.serial, wsig), (e, tl, ml), phase2, keepalive=(ws, ws2))
+                trim = T2b != t2 or T1b != T1
+                mel, ralpha = self._infer_cache.run(("mel", B, T1b, T2b), (ws.serial, ws2.serial, wsig), (), phase2, keepalive=(ws, ws2),
+                                                    refs=(e, tl, ml), clone=not trim)
+                if trim:                                       # (the trimmed copies are the fresh tensors the caller gets)
+                    mel, ralpha = mel[:, :t2].contiguous(), ralpha[:, :T1, :t2].contiguous()
+                if want_lengths:
+                    ml = ml.to(torch.int64)                    # (a new tensor: `ml` is the text graph's static output)
             else:
                 mel, ralpha = self._infer_mel(ws, ws2, e, tl, ml, T2b)
-            if T2b != t2 or T1b != T1:
-                mel, ralpha = mel[:, :t2].contiguous(), ralpha[:, :T1, :t2].contiguous()
-            return mel, ml.to(torch.int64), ralpha
+                ml = ml.to(torch.int64) if want_lengths else ml
+            return mel, ml, ralpha
