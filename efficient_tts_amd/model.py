@@ -931,13 +931,11 @@ class EfficientTTSCNN(torch.nn.Module):
                 def phase1(t, l):
                     with O.stream_scope():              # resolved INSIDE the capture: the launches must go to the capturing stream
                         return self._infer_text(ws, t, l, force_delta) + (l,)
-                stable = tl_i32 is not None             # (inference()'s per-length constant: read in place, not copied per call)
                 # The graph's static outputs -- and its static copy of the lengths -- are handed on as they are: phase 2 reads them in
                 # place (`refs`: no copies into inputs of its own; a re-captured phase 1 means new buffers, hence a new phase-2 capture).
                 # The ids go straight into the zero-filled bucket-wide static input (positions beyond an item's length are ignored).
                 ids = PadTo(text, (B, T1b)) if T1b != T1 else text.contiguous()
-                e, ml, tl = self._infer_cache.run(("text", B, T1b, force_delta, stable), (ws.serial, wsig), (ids,) if stable else (ids, tl), phase1,
-                                                  keepalive=ws, clone=False, refs=(tl,) if stable else ())
+                e, ml, tl = self._infer_cache.run(("text", B, T1b, force_delta), (ws.serial, wsig), (ids, tl), phase1, keepalive=ws, clone=False)
             else:
                 e, ml = self._infer_text(ws, text, tl, force_delta)
             t2 = int((ml if B == 1 else ml.max()).item())                                  # the one host sync

@@ -365,6 +365,34 @@ def test_inference_graph_path_equals_exact_path(golden_dir, model):
         assert float((outs[2][0][0, ::2].cpu() - torch.from_numpy(g[f"mel_pred{n}"])[0]).abs().max()) <= MEL_TOL
 
 
+def test_inference_graphs_are_shared_by_the_lengths_of_a_bucket(golden_dir, model):
+    """utterances of different lengths inside one T1 bucket replay the SAME two captured graphs (the ids are written into the
+    bucket-wide static input, phase 2 reads phase 1's outputs in place): alternating lengths must neither re-capture per call nor
+    leak one call's ids / positions into the next, and the tensors handed back must not be overwritten by later calls."""
+    g = _golden(golden_dir, "inference_lj")
+    dev = _dev()
+    base = torch.from_numpy(g["text0"]).to(dev)
+    T1 = base.shape[1]
+    lo = (T1 - 1) // 16 * 16 + 1                                   # the shortest length of the bucket T1 is in
+    ids = [base[:, :n] for n in sorted({max(lo, T1 - 7), T1})]
+    assert len(ids) == 2
+    model.graphs = False
+    try:
+        exact = [model.inference(x)[0] for x in ids]
+    finally:
+        model.graphs = True
+    for x in ids * 2:                                                # eager, then captured
+        model.inference(x)
+    held = {k: (e.graph, e.calls) for k, e in model._infer_cache.entries.items()}
+    outs = [model.inference(x)[0] for x in ids * 3]
+    for k, (graph, calls) in held.items():
+        assert model._infer_cache.entries[k].graph is graph, f"{k} was captured again"
+    for i, mel in enumerate(outs):
+        assert mel.shape == exact[i % 2].shape
+        assert float((mel - exact[i % 2]).abs().max()) <= 2e-4
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[5])      # (still intact after the later calls)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(3, 37, 211), (2, 128, 800), (4, 100, 124)])
 def test_soft_index_in_the_gemm_epilogue_equals_the_two_kernel_path(shape):
