@@ -618,10 +618,14 @@ def run_forward(a, world, rank, dev, wl):
                    dtype="bf16" if a.precision == "bf16" else "bf16x3 (split-bf16 MFMA, fp32-class)", data="synthetic",
                    config=dict(workload=wl["desc"], batch_per_gpu=B, phoneme_len=T1, mel_len=T2, precision=a.precision,
                                parallelism=f"replicas x{world}",
-                               hipgraph={"graph": "bench-level hipGraph of the eager launches", "call": "plain model() calls (per-shape hipGraph cache inside the model)",
+                               hipgraph={"graph": "bench-level hipGraph of the eager launches", "call": "plain model() calls (the model decides per shape from its first calls: replay a hipGraph, or stay on eager launches where the host runs far ahead of the device anyway -- see call_policy)",
                                          "eager": "none: every kernel launched from the host"}[mode]),
                    loss=loss, roofline=roof)
         res.update(line(a.precision, dt, a.steps))
+        pol = [e.policy for e in model._graph_cache.entries.values() if e.policy is not None]
+        if mode == "call" and pol:
+            res["config"]["call_policy"] = dict(chosen=pol[-1][0], host_ms_to_issue=pol[-1][1] * 1e3, device_ms=pol[-1][2] * 1e3,
+                                                rule=f"eager when host <= {type(model._graph_cache).EAGER_MAX_HOST_SHARE} x device")
     # ---- the parity-grade mode under the same clock: bf16x3 (mel max-abs <= 1e-3 vs the fp32 oracle), same K / W, same inputs
     parity_model = None
     if a.precision == "bf16" and a.parity_mode:
@@ -636,7 +640,7 @@ def run_forward(a, world, rank, dev, wl):
         for md in ("call", "graph", "eager"):
             d, _, _ = timed(model, 10, 2, md)
             cm[md + "_ms"] = d / 10 * 1e3
-        res["call_modes"] = dict(cm, note="10 steps each after the timed region: plain model() call (internal per-shape hipGraph) / bench-level hipGraph / eager launches")
+        res["call_modes"] = dict(cm, note="10 steps each after the timed region: plain model() call (the model's own per-shape choice) / bench-level hipGraph / eager launches")
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             checks = {}

@@ -211,6 +211,8 @@ class EfficientTTSCNN(torch.nn.Module):
         self.fuse_expand = True             # T1 <= 256: alpha' generated in registers inside the expand contraction (efts_expand); False: reconst_alpha + pack_vt + efts_gemm
         self.graphs = True                  # plain eval calls replay a per-shape hipGraph (False: every kernel launched eagerly)
         self._graph_cache = GraphCache()
+        self.graph_policy = "auto"          # teacher-forced forward: "auto" = a shape replays a graph only where launch latency is not
+                                            # hidden by the device time anyway (graphs.GraphCache.run, adaptive); "always" = every shape
         self._len1 = {}
         self._infer_cache = GraphCache(capacity=64)      # free-running inference: two phases per (bucketed) shape
         self.side_stream = True             # text-length work on a second HIP stream beside the mel-length kernels
@@ -597,7 +599,8 @@ class EfficientTTSCNN(torch.nn.Module):
             (_, stats, imv, ralpha, mel_pred, _), _ = self._forward_impl(t, tl, sp, sl)
             return stats._t, imv, ralpha, mel_pred
 
-        out3, imv, ralpha, mel_pred = self._graph_cache.run(key, tag, (text, text_lengths.to(dev), speech, speech_lengths.to(dev)), body, keepalive=ws)
+        out3, imv, ralpha, mel_pred = self._graph_cache.run(key, tag, (text, text_lengths.to(dev), speech, speech_lengths.to(dev)), body, keepalive=ws,
+                                                            adaptive=self.graph_policy == "auto")
         return out3[0], LazyStats(out3), imv, ralpha, mel_pred, speech
 
     def _forward_impl(self, text, text_lengths, speech, speech_lengths, keep: bool = False):

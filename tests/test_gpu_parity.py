@@ -365,6 +365,44 @@ def test_inference_graph_path_equals_exact_path(golden_dir, model):
         assert float((outs[2][0][0, ::2].cpu() - torch.from_numpy(g[f"mel_pred{n}"])[0]).abs().max()) <= MEL_TOL
 
 
+@pytest.mark.parametrize("share,want", [(0.0, "graph"), (1e9, "eager")])
+def test_forward_call_policy_graph_or_eager_gives_the_same_fresh_tensors(share, want):
+    """The teacher-forced forward decides per shape, from its second call, whether it replays a hipGraph or stays on eager launches
+    (graphs.GraphCache.run, adaptive).  Forced either way, call after call must return the same numbers as a graph-free model, in
+    tensors the later calls do not overwrite; graph_policy="always" captures on the second call as before."""
+    from efficient_tts_amd import EfficientTTSCNN
+    from efficient_tts_amd.graphs import GraphCache
+    dev = _dev()
+    torch.manual_seed(3)
+    m = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, sigma=0.01).to(dev).eval()
+    B, T1, T2 = 3, 40, 130
+    gen = torch.Generator().manual_seed(5)
+    text = torch.randint(0, 76, (B, T1), generator=gen).to(dev)
+    mel = torch.randn(B, T2, 80, generator=gen).to(dev)
+    tl, sl = torch.tensor([40, 33, 9]).to(dev), torch.tensor([130, 77, 20]).to(dev)
+    m.graphs = False
+    with torch.no_grad():
+        ref = m(text, tl, mel, sl)
+    m.graphs = True
+    m._graph_cache = GraphCache()
+    m._graph_cache.EAGER_MAX_HOST_SHARE = share
+    with torch.no_grad():
+        outs = [m(text, tl, mel, sl) for _ in range(5)]
+    ent = next(iter(m._graph_cache.entries.values()))
+    assert ent.policy[0] == want and (ent.graph is not None) == (want == "graph")
+    for o in outs:
+        assert float(o[0]) == float(ref[0])
+        for a, b in zip(o[2:5], ref[2:5]):
+            assert torch.equal(a, b)
+    assert outs[3][4].data_ptr() != outs[4][4].data_ptr()
+    m.graph_policy = "always"
+    m._graph_cache = GraphCache()
+    with torch.no_grad():
+        outs = [m(text, tl, mel, sl) for _ in range(2)]
+    ent = next(iter(m._graph_cache.entries.values()))
+    assert ent.graph is not None and ent.policy is None and torch.equal(outs[1][4], ref[4])
+
+
 def test_inference_graphs_are_shared_by_the_lengths_of_a_bucket(golden_dir, model):
     """utterances of different lengths inside one T1 bucket replay the SAME two captured graphs (the ids are written into the
     bucket-wide static input, phase 2 reads phase 1's outputs in place): alternating lengths must neither re-capture per call nor

@@ -19,6 +19,9 @@ python bench.py --workload train32 > $O/bench_train32_bf16_r03.json 2> $O/bench_
 python bench.py --workload train32 --precision bf16x3 --no-cpu-baseline > $O/bench_train32_bf16x3_r03.json 2>> $O/bench_train32.err
 python bench.py --workload infer64 --no-cpu-baseline > $O/bench_infer64_bf16_r03.json 2> $O/bench_infer.err
 python bench.py --workload infer_lj --no-cpu-baseline > $O/bench_infer_lj_bf16_r03.json 2>> $O/bench_infer.err
+bash tools/prof_infer.sh > $O/infer_b1.log 2>&1
+cp gpurun_out/prof_inf/summary_inf.txt $O/rocprofv3_r03_infer_b1_summary.txt
+python tools/gpu_probe_train_host.py > $O/train_host_r03.txt 2>&1
 if [ -f lab/rc_stamp.so ]; then
   for sp in 1 2; do PSPLIT=$sp EFTS_LIB=$R/lab/rc_stamp.so timeout 200 python tools/gpu_probe_rc_stamp.py; done > $O/rc_stamps_r03.txt 2>&1
 fi
