@@ -78,7 +78,8 @@ struct RcProb {
     float slope;
     int taps;               // 5 | 3
     int no_resid;           // 1: y = act(conv + bias) * mask (no residual term)
-    int pad_;
+    int ldsg;               // bytes per row of `sign` (n / 8)
+    char* sign;             // training: sign bits of the activated conv output (bit j of byte c = column 8 c + j), or null
 };
 
 constexpr int RC_MAXPROB = 2;
@@ -346,6 +347,7 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, const RcProb& pq, const
     const __amdgpu_buffer_rsrc_t r_of = make_rsrc(pq.out_f32 ? pq.out_f32 + (long)m0 * pq.ldo : nullptr, pq.out_f32 ? (long)rows_out * pq.ldo * 4 : 0);
     const __amdgpu_buffer_rsrc_t r_ob = make_rsrc(pq.ob ? pq.ob + (long)m0 * pq.ldob : nullptr, pq.ob ? (long)rows_out * pq.ldob : 0);
     const __amdgpu_buffer_rsrc_t r_ol = make_rsrc(pq.ob_lo ? pq.ob_lo + (long)m0 * pq.ldob : nullptr, pq.ob_lo ? (long)rows_out * pq.ldob : 0);
+    const __amdgpu_buffer_rsrc_t r_sg = make_rsrc(pq.sign ? pq.sign + (long)m0 * pq.ldsg : nullptr, pq.sign ? (long)rows_out * pq.ldsg : 0);
     const bool res_f32 = pq.resid != nullptr;
     const bool has_mask = pq.rowmask != nullptr && !(RC_EXP & 8);
     const int srow = lane >> 3;                       // row of the 8-row pass this lane handles
@@ -363,6 +365,7 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, const RcProb& pq, const
     const unsigned vof = lrow0 * (unsigned)pq.ldo * 4 + col0 * 4, sof_row = (unsigned)pq.ldo * 4;
     const unsigned vob = lrow0 * (unsigned)pq.ldob + (pq.out_split == 1 ? col0 * 2 : (col0 >> 5) * 128 + (col0 & 31) * 2);
     const unsigned sob_row = (unsigned)pq.ldob;
+    const unsigned vsg = lrow0 * (unsigned)pq.ldsg + (col0 >> 3);
 
     // (split-2 planes keep 64-byte hi / lo halves per instruction.  Measured and dropped: lanes 0-3 of a row on the hi slots and
     // lanes 4-7 on the lo slots of the same 32 columns, words swapped through ds_bpermute, both lanes computing the same outputs --
@@ -434,6 +437,11 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, const RcProb& pq, const
             const unsigned brow = i * 32 + ps * 8;
             if ((int)(lrow0 + brow) >= rows_out) continue;      // rows of the next tile / past the matrix (the descriptors clip them too)
             if (RC_EXP & 8) { asm volatile("" ::"v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7])); continue; }
+            if (pq.sign) {                                      // training: one byte of sign bits per lane (its 8 columns)
+                const unsigned sb = (d0.x > 0.f ? 1u : 0u) | (d0.y > 0.f ? 2u : 0u) | (d0.z > 0.f ? 4u : 0u) | (d0.w > 0.f ? 8u : 0u) |
+                                    (d1.x > 0.f ? 16u : 0u) | (d1.y > 0.f ? 32u : 0u) | (d1.z > 0.f ? 64u : 0u) | (d1.w > 0.f ? 128u : 0u);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)sb, r_sg, vsg, brow * (unsigned)pq.ldsg, 0);
+            }
             if (pq.out_f32) {
                 const u32x4 o0 = {__float_as_uint(y[0]), __float_as_uint(y[1]), __float_as_uint(y[2]), __float_as_uint(y[3])};
                 const u32x4 o1 = {__float_as_uint(y[4]), __float_as_uint(y[5]), __float_as_uint(y[6]), __float_as_uint(y[7])};
@@ -705,7 +713,7 @@ extern "C" int efts_resconv5_multi(const efts_resconv5_args* a, int32_t count, v
         r.a = (const char*)q->x; r.a_lo = (const char*)q->x_lo; r.resid = q->x_f32; r.w = (const char*)q->w;
         r.bias = q->bias; r.rowmask = q->rowmask; r.out_f32 = q->y_f32; r.ob = (char*)q->y; r.ob_lo = (char*)q->y_lo;
         r.lda = q->ldx; r.ldw = q->ldw; r.w_tap_stride = q->w_tap_stride; r.ldr = q->ldr; r.ldo = q->ldo; r.ldob = q->ldy;
-        r.m = q->m; r.out_split = q->y_split; r.slope = q->slope; r.taps = q->taps == 3 ? 3 : 5; r.no_resid = q->no_residual ? 1 : 0; r.pad_ = 0;
+        r.m = q->m; r.out_split = q->y_split; r.slope = q->slope; r.taps = q->taps == 3 ? 3 : 5; r.no_resid = q->no_residual ? 1 : 0; r.ldsg = q->n >> 3; r.sign = (char*)q->sign_bits;
         mtot += q->m;
     }
     for (int i = count; i < RC_MAXPROB; ++i) k.pr[i] = k.pr[0];

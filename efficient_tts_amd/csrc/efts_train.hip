@@ -71,6 +71,7 @@ __global__ void loss_bwd_kernel(const float* __restrict__ mp, long ldm, const fl
 //   mode 2 (ReLU, h = relu(z))                        : h > 0
 //   mode 3 (LeakyReLU, no residual, out = leaky(z))   : out > 0
 //   mode 4 (LeakyReLU, sign words from the forward)    : y points at efts_gemm's `sign_mask` words (row stride c / 8 bytes)
+//   mode 5 (LeakyReLU, sign bits from the forward)     : y points at efts_resconv5's `sign_bits` rows (row stride c / 8 bytes)
 //   mode 0 : identity
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
@@ -104,6 +105,10 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
                 const uint4 w = *(const uint4*)((const char*)y + (long)r * (c >> 3) + blockIdx.y * 16);
                 m.x = (w.x >> q) & 1u ? 1.f : slope; m.y = (w.y >> q) & 1u ? 1.f : slope;
                 m.z = (w.z >> q) & 1u ? 1.f : slope; m.w = (w.w >> q) & 1u ? 1.f : slope;
+            } else if (mode == 5) {
+                // plain bit rows (efts_resconv5 `sign_bits`): bit j of byte cc = column 8 cc + j
+                const unsigned b = ((const unsigned char*)y)[(long)r * (c >> 3) + (c4 >> 3)] >> (c4 & 4);
+                m.x = b & 1u ? 1.f : slope; m.y = b & 2u ? 1.f : slope; m.z = b & 4u ? 1.f : slope; m.w = b & 8u ? 1.f : slope;
             } else if (mode == 2 || mode == 3) {
                 const float4 yv = *(const float4*)(y + o);
                 const float neg = mode == 2 ? 0.f : slope;
@@ -786,7 +791,7 @@ extern "C" int efts_act_bwd_dropout(const float* g, const float* y, const float*
     if (!g || (!dz && !plane)) return efts_fail(EFTS_EINVAL, "efts_act_bwd: null pointer");
     const int parts = mode & EFTS_ACT_BWD_BIAS_PARTS ? 1 : 0;
     mode &= ~EFTS_ACT_BWD_BIAS_PARTS;
-    if (c % 4 || (mode == 1 && (!x || !y)) || ((mode == 2 || mode == 3) && !y) || (mode == 4 && (!y || c % 128 || ((uintptr_t)y & 15))) || mode < 0 || mode > 4 ||
+    if (c % 4 || (mode == 1 && (!x || !y)) || ((mode == 2 || mode == 3) && !y) || (mode == 4 && (!y || c % 128 || ((uintptr_t)y & 15))) || (mode == 5 && (!y || c % 8)) || mode < 0 || mode > 5 ||
         (parts && !dbias))
         return efts_fail(EFTS_EINVAL, "efts_act_bwd: bad mode/shape");
     unsigned thresh = 0, seed_h = 0;

@@ -64,7 +64,7 @@ class ResConv5Args(C.Structure):
         ("split", i32), ("m", i32), ("n", i32), ("nchunk", i32),
         ("bias", vp), ("slope", f32), ("rowmask", vp),
         ("y_f32", vp), ("ldo", i64), ("y", vp), ("y_lo", vp), ("ldy", i64), ("y_split", i32),
-        ("plan", C.POINTER(i32)), ("taps", i32), ("no_residual", i32),
+        ("plan", C.POINTER(i32)), ("taps", i32), ("no_residual", i32), ("sign_bits", vp),
     ]
 
 

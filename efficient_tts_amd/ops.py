@@ -161,10 +161,10 @@ def gemm(*, a: Plane, a_ptr: Optional[int] = None, b_ptr: int, ldb: int, b_tap_s
 def _resconv5_fill(g, *, x: Plane, x_lo: Optional[Plane] = None, x_f32_ptr: Optional[int] = None, ldr: int = 0, w: "PackedWeight",
                    m: int, n: int, bias: Optional[torch.Tensor] = None, slope: float = 0.1, rowmask_ptr: Optional[int] = None,
                    y_f32_ptr: Optional[int] = None, ldo: int = 0, y: Optional[Plane] = None, y_lo: Optional[Plane] = None,
-                   plan=None, taps: int = 5, no_residual: bool = False) -> None:
+                   plan=None, taps: int = 5, no_residual: bool = False, sign_bits_ptr: Optional[int] = None) -> None:
     if plan is not None:
         g.plan = plan
-    g.taps, g.no_residual = taps, int(no_residual)
+    g.taps, g.no_residual, g.sign_bits = taps, int(no_residual), sign_bits_ptr
     g.x, g.x_lo, g.ldx = x.ptr, (None if x_lo is None else x_lo.ptr), x.ld
     g.x_f32, g.ldr = x_f32_ptr, ldr
     g.w, g.ldw, g.w_tap_stride = w.ptr, w.ld, w.tap_stride

@@ -30,6 +30,10 @@ _SIGN_MIN_ROWS = 16384       # row spaces from here on: the forward convolutions
 _WGRAD_TN_SMALL = 1          # key / value / query Linears and the duration predictor's k3 convolutions: weight gradient straight from
                              # the row-major planes too (taps 1 / 3) instead of two transposed copies + a split-K efts_gemm (0: the latter)
 _BIAS_PARTS = 1              # direct-wgrad layers: bias gradient as per-row-block sums finished by the wgrad reduction (0: atomics in act_bwd)
+_RESCONV_FWD = 3             # residual stacks whose FORWARD runs on efts_resconv5 when their row space is long enough: bit 0 decoder,
+                             # bit 1 mel encoder (A/B: bench.py --train-set _RESCONV_FWD=...)
+_RESCONV_DGRAD = -1          # ... and whose DGRAD does (same bits as efts_gemm's); -1: decoder (bf16) / decoder + mel encoder (bf16x3), measured best:
+                             # 3.72 -> 3.58-3.61 ms per B = 32 step with both switches (bf16), 6.96 -> 6.62-6.64 (bf16x3), tools/train_ab.sh
 _FRAME_PRENET = 1            # prenet without Dropout straight from the caller's frames (efts_frame_linear); 0: efts_gemm over the packed mel plane
 _WGRAD_WGS = 480             # split-K target: 480 workgroups per wgrad launch measured best (6.30 vs 6.60 ms/step at 640)
 
@@ -219,6 +223,25 @@ class TrainEngine:
         m, C = self.m, self.m.n_channels
         saved = []
         layers = getattr(m, blk).layers
+        if (_RESCONV_FWD & dict(dec=1, me=2, te=0)[tag]) and m._on_resconv(rs) and self._conv_drop(0)[0] == 0.0 and _WGRAD_TN_SPLITS > 0 and C % 128 == 0:
+            # mel-length stack on efts_resconv5 (the inference kernel): the stream between the layers is hi + lo bf16 planes (every
+            # hi plane is kept: it is the layer's operand in the wgrad), the activation's sign leaves the epilogue as bit rows
+            # (efts_act_bwd mode 5); fp32 only into the first layer (the producer's stream) and out of the last one
+            n = len(layers)
+            x_lo = None
+            for i, layer in enumerate(layers):
+                last = i == n - 1
+                o_split = last_split if last else m.split
+                o_p = ws.plane(f"T{tag}_p{i}", rs, C, o_split)
+                o_l = ws.plane(f"T{tag}_l{i & 1}", rs, C, 1) if (o_split == 1 and not last) else None
+                o_f = ws.f32(f"T{tag}_f{n - 1}", rs, C) if last else None
+                sg = ws.tensor(f"T{tag}_sb{i}", (rs.rows, C // 8), torch.uint8)
+                O.resconv5(x=x_p, x_lo=x_lo, x_f32_ptr=x_f.ptr if i == 0 else None, ldr=C, w=pk[f"{blk}.{i}"], taps=m.k_size, m=rs.rows, n=C,
+                           bias=layer.conv[0].bias, slope=m.slope, rowmask_ptr=gap_ptr, y_f32_ptr=None if o_f is None else o_f.ptr, ldo=C,
+                           y=o_p, y_lo=o_l, sign_bits_ptr=sg.data_ptr())
+                saved.append((None, None, x_p, (sg, 5), 0.0, 0))
+                x_p, x_lo = o_p, o_l
+            return o_f, x_p, saved
         for i, layer in enumerate(layers):
             last = i == len(layers) - 1
             w = pk[f"{blk}.{i}"]
@@ -230,7 +253,7 @@ class TrainEngine:
             O.gemm(a=x_p, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=m.k_size, m=rs.rows, n=C, act=L.ACT_LEAKY, slope=m.slope,
                    bias=layer.conv[0].bias, resid_ptr=x_f.ptr, ldr=C, rowmask_ptr=gap_ptr, out_f32_ptr=o_f.ptr, ldo=C, out_plane=o_p,
                    sign_mask_ptr=None if sg is None else sg.data_ptr(), drop_p=dp, drop_seed=dseed)
-            saved.append((x_f, o_f, x_p, sg, dp, dseed))
+            saved.append((x_f, o_f, x_p, None if sg is None else (sg, 4), dp, dseed))
             x_f, x_p = o_f, o_p
         return x_f, x_p, saved
 
@@ -251,8 +274,8 @@ class TrainEngine:
             # (no same-address atomics: ~8 of 22 us per launch at mel length)
             bp = ws.tensor(f"B{tag}_bp", ((rs.rows + 63) // 64, C)) if (direct and _BIAS_PARTS) else None
             db, parts = (bp, L.ACT_BWD_BIAS_PARTS) if bp is not None else (self.g[pre + "bias"], 0)
-            if sg is not None:
-                self._act_bwd(G.ptr, sg.data_ptr(), None, gap_ptr, 4 | parts, dz_f, dz_p, db, rs.rows, C, dp, dseed)
+            if sg is not None:                                   # (sign words of efts_gemm: mode 4; sign bits of efts_resconv5: mode 5)
+                self._act_bwd(G.ptr, sg[0].data_ptr(), None, gap_ptr, sg[1] | parts, dz_f, dz_p, db, rs.rows, C, dp, dseed)
             else:
                 self._act_bwd(G.ptr, y_f.ptr, x_f.ptr, gap_ptr, 1 | parts, dz_f, dz_p, db, rs.rows, C, dp, dseed)
             wn = hasattr(conv, "weight_g")
@@ -265,9 +288,15 @@ class TrainEngine:
             wt = self.wt[f"{blk}.{i}"]
             Gn = ws.f32(f"B{tag}_G{i & 1}", rs, C)
             last = i == 0
-            O.gemm(a=dz_p, b_ptr=wt.ptr, ldb=wt.ld, b_tap_stride=wt.tap_stride, taps=m.k_size, m=rs.rows, n=C, resid_ptr=G.ptr, ldr=C,
-                   rowmask_ptr=final_mask_ptr if last else gap_ptr, out_f32_ptr=Gn.ptr, ldo=C,
-                   out_plane=final_plane if last else None)
+            if ((_RESCONV_DGRAD if _RESCONV_DGRAD >= 0 else (1 if m.split == 1 else 3)) & dict(dec=1, me=2, te=0)[tag]) and m._on_resconv(rs) and dz_p.split == m.split:
+                # dgrad on the persistent kernel: G' = (G + conv_T(dZ)) * mask = a residual layer with the transposed weights, no bias
+                # and slope 1, fp32 gradient stream in and out (bit-identical to the efts_gemm launch)
+                O.resconv5(x=dz_p, x_f32_ptr=G.ptr, ldr=C, w=wt, taps=m.k_size, m=rs.rows, n=C, slope=1.0,
+                           rowmask_ptr=final_mask_ptr if last else gap_ptr, y_f32_ptr=Gn.ptr, ldo=C, y=final_plane if last else None)
+            else:
+                O.gemm(a=dz_p, b_ptr=wt.ptr, ldb=wt.ld, b_tap_stride=wt.tap_stride, taps=m.k_size, m=rs.rows, n=C, resid_ptr=G.ptr, ldr=C,
+                       rowmask_ptr=final_mask_ptr if last else gap_ptr, out_f32_ptr=Gn.ptr, ldo=C,
+                       out_plane=final_plane if last else None)
             G = Gn
         return G
 

@@ -190,6 +190,9 @@ typedef struct efts_resconv5_args {
                           * ResConv1d stack built with k_size = 3) on the same kernel: window and tile geometry of the k5 layer */
     int32_t no_residual; /* 1: y = LeakyReLU(conv + bias, slope) * rowmask without the residual term (slope 0 = ReLU): the
                           * duration predictor's Conv1d + ReLU, riding in a decoder launch (efts_resconv5_multi) */
+    void* sign_bits;     /* training forward, optional: the sign of every activated output BEFORE the residual add as plain bit rows for
+                          * efts_act_bwd mode 5 -- row stride n / 8 bytes, bit j of byte c = column 8 c + j is positive (the same
+                          * information as efts_gemm_args.sign_mask, in the order this kernel's epilogue holds it).  NULL: not written */
 } efts_resconv5_args;
 
 int efts_resconv5(const efts_resconv5_args* a, void* stream);
@@ -421,6 +424,7 @@ int efts_loss_bwd(const float* mel_pred, int64_t ldm, const float* speech, const
                   int32_t T1p, int32_t T2, int32_t T2p, int32_t odim, void* stream);
 /* dZ = G * act'(.) * rowmask, bias grad += column sums.  mode 1: residual LeakyReLU layer
  * (sign from y - x); 2: ReLU (sign of y); 3: LeakyReLU without residual (sign of y); 0: identity;
+ * 5: LeakyReLU with the plain sign bits efts_resconv5 wrote (`sign_bits`) passed as y (row stride c / 8 bytes);
  * 4: LeakyReLU with the sign words efts_gemm wrote (`sign_mask` of the forward launch) passed as y (row stride c / 8 bytes,
  * c % 128 == 0), x unused.
  * mode | EFTS_ACT_BWD_BIAS_PARTS: dbias is a [ceil(rows / 64)][c] workspace that receives one column sum per 64-row block

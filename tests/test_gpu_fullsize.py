@@ -87,7 +87,11 @@ def test_training_step_b32_equals_the_two_item_run(golden_dir):
             continue                                                                  # identically zero: fp noise only
         worst = max(worst, d)
     print("B=32 vs B=2 gradients: worst relative difference", worst)
-    assert worst <= 1e-4                                                              # summation order over 16x the rows
+    # summation order over 16x the rows: <= 5e-6 with both runs on the same kernels.  The 32-item row space is long enough for the
+    # mel-length stacks to take efts_resconv5 (hi + lo bf16 stream between the layers: 16 mantissa bits instead of the 24 of
+    # the fp32 stream the 2-item run keeps), and the alignment turns that rounding into ~6e-4 on the mel-encoder side; that path
+    # against the reference's autograd: tests/test_gpu_train.py::test_full_size_param_grads_vs_oracle_autograd[efts_resconv5]
+    assert worst <= 1.5e-3
     perm = torch.randperm(32, generator=torch.Generator().manual_seed(3)).to(_dev())
     outp, _ = eng.forward_backward(*[a[perm] for a in a32])
     torch.cuda.synchronize()
@@ -229,7 +233,11 @@ def test_one_optimizer_step_b32_vs_oracle_and_torch_adam():
         frac = float((same | ~moved).float().mean())
         # gradients well above the operand-rounding noise of the split-bf16 kernels (elementwise up to ~1e-2 of the tensor's
         # largest gradient on the text side, tests/test_gpu_train.py::test_full_size_param_grads_vs_oracle_autograd)
-        big = g_ref[n].abs() > 0.1 * g_ref[n].abs().max()
+        # ("gradient" = what Adam normalises: the clipped gradient PLUS the coupled weight decay 1e-5 * p -- the two cancel to ~1e-8 in a
+        # few embedding entries, where a 3e-4 relative difference in the gradient then moves the update by 0.08 lr)
+        coef = min(1.0, 1.0 / (gn_ref + 1e-6))
+        ghat = g_ref[n] * coef + 1e-5 * p0[n].cpu()
+        big = ghat.abs() > 0.1 * g_ref[n].abs().max() * coef
         print(f"  {n}: max |dp| {float(d.max()):.2e}, same update on {100 * frac:.2f} % of the elements")
         assert frac >= 0.97, (n, frac)
         assert bool(same[big & moved].all()), n                                        # ... and wherever the gradient is not marginal

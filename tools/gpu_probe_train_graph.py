@@ -4,6 +4,9 @@ sys.path.insert(0, ".")
 from efficient_tts_amd import EfficientTTSCNN
 from efficient_tts_amd.autograd import engine_of
 from efficient_tts_amd.optim import EftsAdam, WarmupLR
+from efficient_tts_amd import train as TR
+for kv in sys.argv[2:]:                      # module switches of efficient_tts_amd.train: NAME=INT
+    k, v = kv.split("="); assert hasattr(TR, k); setattr(TR, k, int(v))
 dev = torch.device("cuda:0")
 B, T1, T2 = 32, 128, 800
 torch.manual_seed(0)
