@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--graph", type=int, default=0, help="forward workloads. 0 (default): the timed step is a plain model(...) call, as a drop-in caller issues it (the model replays a per-shape hipGraph internally); 1: a bench-level hipGraph of the eager launches")
     ap.add_argument("--model-graphs", type=int, default=1, help="0 with --graph 0: the model's internal graph cache off = every kernel launched eagerly")
     ap.add_argument("--parity-mode", type=int, default=1, help="forward workloads in bf16: also time the bf16x3 parity-grade mode (same K / W) -> `parity_mode` in the JSON line")
+    ap.add_argument("--train-graph", type=int, default=1, help="train32, one process: the step as one hipGraph replay (0: eager launches)")
     ap.add_argument("--call-modes", type=int, default=1, help="forward workloads, N=1: 10 extra steps per call mode (plain call / bench graph / eager) -> `call_modes`")
     ap.add_argument("--train-record", type=int, default=1, help="fwd64, N=1: also time BASELINE config 3 (training step B=32, 10 steps) under the same invocation -> `train32` in the JSON line")
     ap.add_argument("--measure-traffic", type=int, default=1, help="forward workloads, N=1: roofline.traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) over a 2-step child run, when rocprofv3 is on the box; 0: the committed profiles/traffic.json")

@@ -81,6 +81,17 @@ def measure_train(a, world, rank, dev, wl, steps, warmup):
         sch.step()
         return loss
 
+    # one process: the step as ONE hipGraph replay (step_graph.GraphedStep -- what the trainer runs with `graph_steps: true`): the host
+    # issues a replay in tens of microseconds, so a loaded host no longer sets the step time; data parallel keeps the eager loop
+    # (the bucketed all-reduce is launched from hooks)
+    graphed = None
+    if world == 1 and getattr(a, "train_graph", 1):
+        from .step_graph import GraphedStep
+        graphed = GraphedStep(model, opt, sch)
+
+    def gstep():
+        return graphed(text, tl, mel, sl)[0]
+
     selfcheck = None
     if world > 1:
         # ---- self-validation before anything is timed
@@ -96,17 +107,19 @@ def measure_train(a, world, rank, dev, wl, steps, warmup):
         assert same, "data-parallel replicas diverged after 2 steps: " + str([e.tolist() for e in every])
         selfcheck = dict(backend=backend, world_seen_by_rccl=dist.get_world_size(), steps=2, replicas_bit_identical=same,
                          fingerprint=[int(v) for v in every[0].tolist()])
-    for _ in range(warmup):
-        loss = step()
+    run = gstep if graphed is not None else step
+    for _ in range(max(warmup, 2)):
+        loss = run()
     torch.cuda.synchronize()
     rows = P.Rows(B, T2).rows
-    P.PROFILE, P.PROFILE_TAG = [], (5, rows, 512)
+    if graphed is None:
+        P.PROFILE, P.PROFILE_TAG = [], (5, rows, 512)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = step()
+        loss = run()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -115,15 +128,35 @@ def measure_train(a, world, rank, dev, wl, steps, warmup):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    eager_ms = None
+    if graphed is not None:
+        # the same step issued eagerly (what the reference's loop does), with the conv launches bracketed by events for the roofline
+        assert graphed.replays >= steps, "the timed steps were not graph replays"
+        P.PROFILE, P.PROFILE_TAG = [], (5, rows, 512)
+        k = max(3, min(steps, 10))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k):
+            step()
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t1) / k * 1e3
     lv = float(loss)
     assert lv == lv, "NaN loss"
     durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in P.PROFILE if tag == (5, rows, 512)]
     P.PROFILE, P.PROFILE_TAG = None, None
     avg = sum(durs) / max(len(durs), 1)
     conv_flop = 2.0 * B * T2 * 512 * 512 * 5
+    from . import train as _tr
     split = model.split
+    dg = _tr._RESCONV_DGRAD if _tr._RESCONV_DGRAD >= 0 else (1 if split == 1 else 3)
+    on_rc = model._on_resconv(P.Rows(B, T2))
     big = split == 1 and ((rows + 251) // 252) * 4 >= 400           # efts_gemm's own rule for the 256-row kernel
-    kname = "conv5_kernel<split=1> (256-row tiles)" if big else f"gemm_kernel<taps=5,split={split}> (124-row tiles)"
+    other = "conv5_kernel<split=1> (256-row tiles)" if big else f"gemm_kernel<taps=5,split={split}> (124-row tiles)"
+    if on_rc and _tr._RESCONV_FWD:
+        kname = (f"the k5 launches at mel length: resconv5_kernel<split={split}> (forward of the stacks selected by _RESCONV_FWD={_tr._RESCONV_FWD}, "
+                 f"dgrad of those selected by {dg}: bit 0 decoder, bit 1 mel encoder) and {other} (the rest)")
+    else:
+        kname = other
     if rank != 0:
         return None
     frames = world * B * T2 * steps
@@ -133,9 +166,10 @@ def measure_train(a, world, rank, dev, wl, steps, warmup):
                dtype="bf16" if a.precision == "bf16" else "bf16x3 (split-bf16 MFMA, fp32-class)", data="synthetic",
                config=dict(workload=wl["desc"], batch_per_gpu=B, phoneme_len=T1, mel_len=T2, precision=a.precision,
                            parallelism=f"dp{world}", optimizer="Adam-amsgrad fused, clip 1.0, WarmupLR 4000",
-                           allreduce="RCCL, 3 buckets overlapped with backward" if world > 1 else "none"),
-               per_gpu=frames / dt / world, tflops=TRAIN_FLOP_PER_ITEM * B * world * steps / dt / 1e12, loss=lv,
-               roofline=dict(bound="mfma", kernel=f"{kname}: fwd + dgrad launches at mel length (timed while the text-length stream runs beside them)",
+                           allreduce="RCCL, 3 buckets overlapped with backward" if world > 1 else "none",
+                           step_issue="one hipGraph replay per step (step_graph.GraphedStep)" if graphed is not None else "eager launches"),
+               eager_ms_per_step=eager_ms, per_gpu=frames / dt / world, tflops=TRAIN_FLOP_PER_ITEM * B * world * steps / dt / 1e12, loss=lv,
+               roofline=dict(bound="mfma", kernel=f"{kname}; fwd + dgrad launches, timed with events in the eager loop while the text-length stream runs beside them",
                              achieved=conv_flop / avg / 1e12 if avg else None, peak=2500.0, unit="TFLOP/s",
                              frac=conv_flop / avg / 1e12 / 2500.0 if avg else None, traffic=None,
                              avg_launch_us=avg * 1e6, launches_measured=len(durs)))

@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         char* __restrict__ plane, long ldp, int rows, int c, int split,
                                                         const float* __restrict__ w, const float* __restrict__ bptr,
                                                         int mode, float offset, float* __restrict__ out, float drop_p,
-                                                        unsigned drop_seed) {
+                                                        unsigned drop_seed, const unsigned* __restrict__ seed_add) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -418,7 +418,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float rstd = 1.f / sqrtf(wave_sum(q) / (float)c + eps);
     const float rm = rowmask ? rowmask[row] : 1.f;
     const bool drop = drop_p > 0.f;
-    const unsigned thresh = drop ? (unsigned)(drop_p * 4294967296.0) : 0u, seed_h = hash_u32(drop_seed);
+    // (seed_add: a device word added to the seed -- the step counter of a training step replayed as a hipGraph, whose kernel
+    //  arguments are frozen at capture time)
+    const unsigned thresh = drop ? (unsigned)(drop_p * 4294967296.0) : 0u, seed_h = hash_u32(drop_seed + (seed_add ? *seed_add : 0u));
     const float inv_keep = drop ? 1.f / (1.f - drop_p) : 1.f;
     float dot = 0.f;
 #pragma unroll
@@ -632,21 +634,21 @@ extern "C" int efts_cumsum_rows(const float* x, float* y, int32_t B, int32_t T, 
 
 extern "C" int efts_layernorm_rows(const float* x, const float* gamma, const float* beta, float eps, const float* rowmask,
                                    float* f32_out, void* plane, int64_t ld_plane, int32_t rows, int32_t c, int32_t split, float drop_p,
-                                   uint32_t drop_seed, void* stream) {
+                                   uint32_t drop_seed, const uint32_t* drop_seed_add, void* stream) {
     if (!x || !gamma || !beta || (!f32_out && !plane)) return efts_fail(EFTS_EINVAL, "efts_layernorm_rows: null pointer");
     if (c % 256 || c > 2048 || rows <= 0) return efts_fail(EFTS_ESHAPE, "efts_layernorm_rows: c must be a multiple of 256, <= 2048");
     hipLaunchKernelGGL((layernorm_kernel<false>), dim3((rows + 3) / 4), dim3(256), 0, ST, x, gamma, beta, eps, rowmask, f32_out, (char*)plane,
-                       (long)ld_plane, rows, c, split, (const float*)nullptr, (const float*)nullptr, 0, 0.f, (float*)nullptr, drop_p, drop_seed);
+                       (long)ld_plane, rows, c, split, (const float*)nullptr, (const float*)nullptr, 0, 0.f, (float*)nullptr, drop_p, drop_seed, drop_seed_add);
     return efts_check_launch("efts_layernorm_rows");
 }
 
 extern "C" int efts_layernorm_dot(const float* x, const float* gamma, const float* beta, float eps, const float* w, const float* b,
                                   const float* rowmask, int32_t mode, float offset, float* out, int32_t rows, int32_t c, float drop_p,
-                                  uint32_t drop_seed, void* stream) {
+                                  uint32_t drop_seed, const uint32_t* drop_seed_add, void* stream) {
     if (!x || !gamma || !beta || !w || !b || !out) return efts_fail(EFTS_EINVAL, "efts_layernorm_dot: null pointer");
     if (c % 256 || c > 2048 || rows <= 0) return efts_fail(EFTS_ESHAPE, "efts_layernorm_dot: c must be a multiple of 256, <= 2048");
     hipLaunchKernelGGL((layernorm_kernel<true>), dim3((rows + 3) / 4), dim3(256), 0, ST, x, gamma, beta, eps, rowmask, (float*)nullptr, (char*)nullptr,
-                       0L, rows, c, 1, w, b, mode, offset, out, drop_p, drop_seed);
+                       0L, rows, c, 1, w, b, mode, offset, out, drop_p, drop_seed, drop_seed_add);
     return efts_check_launch("efts_layernorm_dot");
 }
 

@@ -267,7 +267,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             float* __restrict__ dz, char* __restrict__ plane, long ldp, int split,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             float* __restrict__ dbias, float* __restrict__ dw, float* __restrict__ db,
-                                                            int rows, int c, float drop_p, unsigned drop_seed, int ROWS) {
+                                                            int rows, int c, float drop_p, unsigned drop_seed, const unsigned* __restrict__ seed_add,
+                                                            int ROWS) {
     extern __shared__ float acc_s[];                   // [4 waves][4][c]: dgamma, dbeta, dbias, dw partials of each wave
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // per-lane accumulators of the channels this lane owns in every row (u * 256 + lane * 4 + e): the column sums
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         for (int e = 0; e < 4; ++e) ag[u][e] = ab[u][e] = ac[u][e] = aw[u][e] = 0.f;
     const int nv = c >> 8;
     const bool drop = drop_p > 0.f;
-    const unsigned thresh = drop ? (unsigned)(drop_p * 4294967296.0) : 0u, seed_h = hash_u32(drop_seed);
+    const unsigned thresh = drop ? (unsigned)(drop_p * 4294967296.0) : 0u, seed_h = hash_u32(drop_seed + (seed_add ? *seed_add : 0u));
     const float inv_keep = drop ? 1.f / (1.f - drop_p) : 1.f;
     float db_loc = 0.f;
     // each wave walks rows blockIdx.x*ROWS + wv, +4, ...
@@ -603,10 +604,13 @@ __global__ __launch_bounds__(256) void scale_unless_one_kernel(float* __restrict
         else for (long k = i; k < n; ++k) x[k] *= sv;
     }
 }
+// hyper (optional): {lr, 1 - beta1^t, sqrt(1 - beta2^t)} in device memory instead of the by-value arguments -- the step as a hipGraph
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, float* __restrict__ vmax, long n,
                                                    const float* __restrict__ sumsq, float max_norm, float gscale, float lr,
-                                                   float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+                                                   float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                   const float* __restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2]; }
     float coef = gscale;
     if (sumsq && max_norm > 0.f) {
         const float nrm = sqrtf(sumsq[0]) * gscale;    // norm of the (already averaged) gradient
@@ -840,13 +844,13 @@ extern "C" int efts_wgrad_reduce(const float* part, int32_t nsplit, const float*
 extern "C" int efts_layernorm_bwd(const float* x, const float* gamma, const float* beta, float eps, const float* dy, const float* ddur,
                                   const float* w, const float* rowmask, float* dz, void* plane, int64_t ld_plane, int32_t split,
                                   float* dgamma, float* dbeta, float* dbias, float* dw, float* db, int32_t rows, int32_t c, float drop_p,
-                                  uint32_t drop_seed, void* stream) {
+                                  uint32_t drop_seed, const uint32_t* drop_seed_add, void* stream) {
     if (!x || !gamma || !beta || (!dy && !ddur) || (ddur && !w) || !dgamma || !dbeta) return efts_fail(EFTS_EINVAL, "efts_layernorm_bwd: null pointer");
     if (c % 256 || c > 2048) return efts_fail(EFTS_ESHAPE, "efts_layernorm_bwd: c must be a multiple of 256, <= 2048");
     int rpb = LNB_ROWS;                        // rows per block
     if (c > 768) (void)hipFuncSetAttribute((const void*)layernorm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * c * (int)sizeof(float));
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), (size_t)16 * c * sizeof(float), ST, x, gamma, beta, eps, dy, ddur, w,
-                       rowmask, dz, (char*)plane, (long)ld_plane, split, dgamma, dbeta, dbias, dw, db, rows, c, drop_p, drop_seed, rpb);
+                       rowmask, dz, (char*)plane, (long)ld_plane, split, dgamma, dbeta, dbias, dw, db, rows, c, drop_p, drop_seed, drop_seed_add, rpb);
     return efts_check_launch("efts_layernorm_bwd");
 }
 
@@ -914,6 +918,32 @@ extern "C" int efts_adam_amsgrad(float* p, const float* g, float* m, float* v, f
     if (!p || !g || !m || !v || !vmax || n <= 0 || step < 1) return efts_fail(EFTS_EINVAL, "efts_adam_amsgrad: bad arguments");
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, ST, p, g, m, v, vmax, (long)n, sumsq, max_norm, gscale, lr, beta1, beta2, eps, weight_decay,
-                       bc1, sqrtf(bc2));
+                       bc1, sqrtf(bc2), (const float*)nullptr);
     return efts_check_launch("efts_adam_amsgrad");
+}
+
+extern "C" int efts_adam_hyper(float lr, float beta1, float beta2, int32_t step, float* out3) {
+    if (!out3 || step < 1) return efts_fail(EFTS_EINVAL, "efts_adam_hyper: bad arguments");
+    out3[0] = lr; out3[1] = 1.f - powf(beta1, (float)step); out3[2] = sqrtf(1.f - powf(beta2, (float)step));
+    return EFTS_OK;
+}
+
+extern "C" int efts_adam_amsgrad_dev(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, const float* sumsq, float max_norm,
+                                     float gscale, const float* hyper, float beta1, float beta2, float eps, float weight_decay, void* stream) {
+    if (!p || !g || !m || !v || !vmax || !hyper || n <= 0) return efts_fail(EFTS_EINVAL, "efts_adam_amsgrad_dev: bad arguments");
+    hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, ST, p, g, m, v, vmax, (long)n, sumsq, max_norm, gscale, 0.f, beta1, beta2, eps, weight_decay,
+                       1.f, 1.f, hyper);
+    return efts_check_launch("efts_adam_amsgrad_dev");
+}
+
+struct Words8 { uint32_t w[8]; };
+__global__ void store_words_kernel(uint32_t* __restrict__ dst, Words8 v, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = v.w[threadIdx.x];
+}
+extern "C" int efts_store_words(uint32_t* dst, const uint32_t* words, int32_t n, void* stream) {
+    if (!dst || !words || n < 1 || n > 8) return efts_fail(EFTS_EINVAL, "efts_store_words: 1..8 words");
+    Words8 v;
+    for (int i = 0; i < 8; ++i) v.w[i] = i < n ? words[i] : 0u;
+    hipLaunchKernelGGL(store_words_kernel, dim3(1), dim3(64), 0, ST, dst, v, n);
+    return efts_check_launch("efts_store_words");
 }

@@ -92,8 +92,8 @@ _SIGS = {
     "efts_expand": (i32, [C.POINTER(ExpandArgs), vp]),
     "efts_duration_positions": (i32, [vp, i64, vp, f32, i32, vp, vp, i32, i32, vp]),
     "efts_bf16_round": (i32, [vp, vp, i64, i32, vp]),
-    "efts_layernorm_rows": (i32, [vp, vp, vp, f32, vp, vp, vp, i64, i32, i32, i32, f32, C.c_uint32, vp]),
-    "efts_layernorm_dot": (i32, [vp, vp, vp, f32, vp, vp, vp, i32, f32, vp, i32, i32, f32, C.c_uint32, vp]),
+    "efts_layernorm_rows": (i32, [vp, vp, vp, f32, vp, vp, vp, i64, i32, i32, i32, f32, C.c_uint32, vp, vp]),
+    "efts_layernorm_dot": (i32, [vp, vp, vp, f32, vp, vp, vp, i32, f32, vp, i32, i32, f32, C.c_uint32, vp, vp]),
     "efts_losses_workspace_bytes": (C.c_size_t, []),
     "efts_masked_losses": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     # training step
@@ -106,7 +106,7 @@ _SIGS = {
     "efts_wgrad_reduce": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
     "efts_wgrad_reduce_bias": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp, vp]),
     "efts_wgrad_tn": (i32, [vp, i64, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp]),
-    "efts_layernorm_bwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, i32, i32, f32, C.c_uint32, vp]),
+    "efts_layernorm_bwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, i32, i32, f32, C.c_uint32, vp, vp]),
     "efts_alpha_bwd": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, vp]),
     "efts_e_bwd": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, vp]),
     "efts_imv_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
@@ -117,6 +117,9 @@ _SIGS = {
     "efts_sumsq": (i32, [vp, i64, vp, vp, vp]),
     "efts_scale_unless_one": (i32, [vp, i64, vp, vp]),
     "efts_adam_amsgrad": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
+    "efts_adam_hyper": (i32, [f32, f32, f32, i32, C.POINTER(f32)]),
+    "efts_adam_amsgrad_dev": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, vp, f32, f32, f32, f32, vp]),
+    "efts_store_words": (i32, [vp, C.POINTER(C.c_uint32), i32, vp]),
     # log-mel front-end
     "efts_frame_pack": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
     "efts_logmel": (i32, [vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

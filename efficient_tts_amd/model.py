@@ -300,13 +300,22 @@ class EfficientTTSCNN(torch.nn.Module):
             ref = pk[members[0][0]]
             launches.append((first, len(members), ref.ld, wt[members[0][0]].ld if with_t else 0, cout, cin, taps, int(with_t)))
         key = tuple(table_rows)
-        if getattr(self, "_pack_table_key", None) != key:              # pointers are stable across steps: built once
-            object.__setattr__(self, "_pack_table", torch.tensor(table_rows, dtype=torch.int64, device=dev))
-            object.__setattr__(self, "_pack_scale", torch.empty(max(n * co for _, n, _, _, co, _, _, _ in launches), device=dev))
-            object.__setattr__(self, "_pack_table_key", key)
-        base = self._pack_table.data_ptr()
+        tables = getattr(self, "_pack_tables", None)
+        if tables is None:
+            tables = {}
+            object.__setattr__(self, "_pack_tables", tables)
+        if key not in tables:
+            # Pointers are stable across steps: built once per item list.  Tables are KEPT (the eval forward and the training engine
+            # alternate between two lists -- with and without the dgrad planes -- and a training step captured as a hipGraph keeps
+            # launching with the table it was captured with: a replaced table would be freed memory under that graph)
+            if len(tables) >= 8:
+                tables.clear()                                           # (parameters re-homed / re-created many times over)
+            tables[key] = (torch.tensor(table_rows, dtype=torch.int64, device=dev),
+                           torch.empty(max(n * co for _, n, _, _, co, _, _, _ in launches), device=dev))
+        table, scale = tables[key]
+        base = table.data_ptr()
         for first, n, ld, ld_t, cout, cin, taps, with_t in launches:
-            L.check(lib.efts_pack_weights_grouped(base + first * 40, n, self._pack_scale.data_ptr(), ld, ld_t, cout, cin, taps,
+            L.check(lib.efts_pack_weights_grouped(base + first * 40, n, scale.data_ptr(), ld, ld_t, cout, cin, taps,
                                                   self.split, with_t, O._stream()), "efts_pack_weights_grouped")
         self._packed_sig = sig
         self._packed_gen += 1

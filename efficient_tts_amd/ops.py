@@ -384,18 +384,24 @@ def duration_positions(dur: torch.Tensor, ld: int, tl, force_delta, method1: boo
 
 
 def layernorm_rows(x_ptr, gamma, beta, eps, rowmask_ptr, out_f32_ptr, plane: Optional[Plane], rows, c, drop_p: float = 0.0,
-                   drop_seed: int = 0) -> None:
+                   drop_seed: int = 0, seed_add_ptr: Optional[int] = None) -> None:
     L.check(L.load().efts_layernorm_rows(x_ptr, gamma.data_ptr(), beta.data_ptr(), eps, rowmask_ptr, out_f32_ptr,
                                          None if plane is None else plane.ptr, 0 if plane is None else plane.ld,
-                                         rows, c, 1 if plane is None else plane.split, drop_p, drop_seed & 0xFFFFFFFF, _stream()),
+                                         rows, c, 1 if plane is None else plane.split, drop_p, drop_seed & 0xFFFFFFFF, seed_add_ptr, _stream()),
             "efts_layernorm_rows")
 
 
 def layernorm_dot(x_ptr, gamma, beta, eps, w, b, rowmask_ptr, mode, offset, out, rows, c, drop_p: float = 0.0,
-                  drop_seed: int = 0) -> None:
+                  drop_seed: int = 0, seed_add_ptr: Optional[int] = None) -> None:
     L.check(L.load().efts_layernorm_dot(x_ptr, gamma.data_ptr(), beta.data_ptr(), eps, w.data_ptr(), b.data_ptr(),
-                                        rowmask_ptr, mode, offset, out.data_ptr(), rows, c, drop_p, drop_seed & 0xFFFFFFFF, _stream()),
+                                        rowmask_ptr, mode, offset, out.data_ptr(), rows, c, drop_p, drop_seed & 0xFFFFFFFF, seed_add_ptr, _stream()),
             "efts_layernorm_dot")
+
+
+def store_words(dst: torch.Tensor, words) -> None:
+    """up to 8 32-bit words, passed by value, into device memory in stream order (efts_store_words)"""
+    arr = (C.c_uint32 * len(words))(*[int(w) & 0xFFFFFFFF for w in words])
+    L.check(L.load().efts_store_words(dst.data_ptr(), arr, len(words), _stream()), "efts_store_words")
 
 
 def mask_rows(x_ptr, rowmask_ptr, out: Optional[F32Rows], plane: Optional[Plane], rows, c) -> None:

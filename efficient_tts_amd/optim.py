@@ -9,6 +9,8 @@
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 from torch.optim.lr_scheduler import _LRScheduler
 
@@ -45,22 +47,39 @@ class EftsAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         """clip (global norm of grad_scale * flat grads) + Adam-amsgrad, all on the device."""
+        self.t += 1
+        self.launch(grad_scale)
+        # parameters changed in place through the flat view: invalidate packed-weight caches
+        self.model._packed_sig = None
+
+    def hyper_words(self, step: int):
+        """{lr, 1 - beta1^step, sqrt(1 - beta2^step)} as the kernel derives them from its by-value arguments, as 32-bit words"""
+        grp = self.param_groups[0]
+        arr = (C.c_float * 3)()
+        L.check(L.load().efts_adam_hyper(float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]), int(step), arr), "efts_adam_hyper")
+        return list((C.c_uint32 * 3).from_buffer(arr))
+
+    @torch.no_grad()
+    def launch(self, grad_scale: float = 1.0, hyper_ptr=None):
+        """the launches of step() for step number `self.t`, nothing else.  hyper_ptr: device floats {lr, 1 - beta1^t, sqrt(1 - beta2^t)}
+        read by the kernel instead of the by-value scalars (a step captured as a hipGraph: step_graph.GraphedStep)."""
         eng = self.eng
         grp = self.param_groups[0]
-        self.t += 1
         n = eng.numel
         st = O._stream()
         lib = L.load()
         if self.grad_norm > 0:
             self.sumsq.zero_()
             L.check(lib.efts_sumsq(eng.flat.data_ptr(), n, self.sumsq.data_ptr(), self.sumsq_ws.data_ptr(), st), "efts_sumsq")
-        L.check(lib.efts_adam_amsgrad(self.flat_p.data_ptr(), eng.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                                      self.vmax.data_ptr(), n, self.sumsq.data_ptr() if self.grad_norm > 0 else None,
-                                      self.grad_norm, float(grad_scale), float(grp["lr"]), float(grp["betas"][0]),
-                                      float(grp["betas"][1]), float(grp["eps"]), float(grp["weight_decay"]), self.t, st),
-                "efts_adam_amsgrad")
-        # parameters changed in place through the flat view: invalidate packed-weight caches
-        self.model._packed_sig = None
+        sq = self.sumsq.data_ptr() if self.grad_norm > 0 else None
+        if hyper_ptr is None:
+            L.check(lib.efts_adam_amsgrad(self.flat_p.data_ptr(), eng.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.vmax.data_ptr(), n, sq,
+                                          self.grad_norm, float(grad_scale), float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]),
+                                          float(grp["eps"]), float(grp["weight_decay"]), self.t, st), "efts_adam_amsgrad")
+        else:
+            L.check(lib.efts_adam_amsgrad_dev(self.flat_p.data_ptr(), eng.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.vmax.data_ptr(), n, sq,
+                                              self.grad_norm, float(grad_scale), hyper_ptr, float(grp["betas"][0]), float(grp["betas"][1]),
+                                              float(grp["eps"]), float(grp["weight_decay"]), st), "efts_adam_amsgrad_dev")
 
     def zero_grad(self, set_to_none: bool = True):
         for _, p in self.eng.layout:

@@ -89,6 +89,8 @@ class TrainEngine:
         self.layout = grad_layout(model)
         self.named = list(model.named_parameters())     # model.parameters() order (what autograd's Function receives)
         self.params = tuple(p for _, p in self.named)
+        self.step_words = None                          # device uint32[4] {lr, 1 - b1^t, sqrt(1 - b2^t) as float bits, 2 * dropout step}: set while
+                                                        # a step is captured / replayed as a hipGraph (step_graph.GraphedStep)
         self.step_params = None                         # tuple(model.parameters()) of the running step (autograd.py), saves re-walks
         self.dev = next(model.parameters()).device
         self.numel = sum(p.numel() for _, p in self.layout)
@@ -346,7 +348,14 @@ class TrainEngine:
         m.dropout_calls = int(getattr(m, "dropout_calls", 0)) + 1
         self.drop_calls = m.dropout_calls
         self.seed_base = self._seed_base()
-        seed0, seed1 = (self.seed_base + 2 * self.drop_calls) & 0xFFFFFFFF, (self.seed_base + 2 * self.drop_calls + 1) & 0xFFFFFFFF
+        if self.step_words is not None:
+            # a step that is being captured (step_graph.GraphedStep): the counter's contribution comes from device word 3 of
+            # `step_words` (= 2 * dropout_calls, refreshed in front of every replay), the by-value seeds stay constant
+            sadd = self.step_words.data_ptr() + 12
+            seed0, seed1 = self.seed_base & 0xFFFFFFFF, (self.seed_base + 1) & 0xFFFFFFFF
+        else:
+            sadd = None
+            seed0, seed1 = (self.seed_base + 2 * self.drop_calls) & 0xFFFFFFFF, (self.seed_base + 2 * self.drop_calls + 1) & 0xFFFFFFFF
 
         # ============================ forward (efficient_tts.py:144-227), activations kept
         with O.on_stream(side):
@@ -373,11 +382,11 @@ class TrainEngine:
             O.gemm(a=val_p, b_ptr=w0.ptr, ldb=w0.ld, b_tap_stride=w0.tap_stride, taps=3, m=rs1.rows, n=C, act=L.ACT_RELU,
                    bias=dp.conv[0][0].bias, out_f32_ptr=h1_f.ptr, ldo=C)
             O.layernorm_rows(h1_f.ptr, ln0.weight.detach(), ln0.bias.detach(), ln0.eps, gap1.data_ptr(), l1_f.ptr, l1_p, rs1.rows, C,
-                             drop_p, seed0)
+                             drop_p, seed0, sadd)
             O.gemm(a=l1_p, b_ptr=w1.ptr, ldb=w1.ld, b_tap_stride=w1.tap_stride, taps=3, m=rs1.rows, n=C, act=L.ACT_RELU,
                    bias=dp.conv[1][0].bias, out_f32_ptr=h2_f.ptr, ldo=C)
             O.layernorm_dot(h2_f.ptr, ln1.weight.detach(), ln1.bias.detach(), ln1.eps, dp.linear.weight.detach(),
-                            dp.linear.bias.detach(), len1.data_ptr(), 0, float(dp.offset), dur, rs1.rows, C, drop_p, seed1)
+                            dp.linear.bias.detach(), len1.data_ptr(), 0, float(dp.offset), dur, rs1.rows, C, drop_p, seed1, sadd)
             ev_dur = torch.cuda.Event()
             ev_dur.record(side)
             self._ws_tag = ""
@@ -476,7 +485,7 @@ class TrainEngine:
                                               dp.linear.weight.data_ptr(), None, dz2_f.ptr, dz2_p.ptr, dz2_p.ld, split,
                                               g[gname(1, "2.weight")].data_ptr(), g[gname(1, "2.bias")].data_ptr(),
                                               g[gname(1, "0.bias")].data_ptr(), g["duration_predictor.linear.weight"].data_ptr(),
-                                              g["duration_predictor.linear.bias"].data_ptr(), rs1.rows, C, drop_p, seed1, O._stream()),
+                                              g["duration_predictor.linear.bias"].data_ptr(), rs1.rows, C, drop_p, seed1, sadd, O._stream()),
                     "efts_layernorm_bwd")
             self._wgrad_any(ws, dz2_f.ptr, dz2_p, l1_f.ptr, l1_p, C, C, 3, rs1.rows, g[gname(1, "0.weight")])
             G1 = ws.f32("Bdur_G1", rs1, C)
@@ -486,7 +495,7 @@ class TrainEngine:
             L.check(_lib().efts_layernorm_bwd(h1_f.ptr, ln0.weight.data_ptr(), ln0.bias.data_ptr(), ln0.eps, G1.ptr, None, None,
                                               gap1.data_ptr(), dz1_f.ptr, dz1_p.ptr, dz1_p.ld, split,
                                               g[gname(0, "2.weight")].data_ptr(), g[gname(0, "2.bias")].data_ptr(),
-                                              g[gname(0, "0.bias")].data_ptr(), None, None, rs1.rows, C, drop_p, seed0, O._stream()),
+                                              g[gname(0, "0.bias")].data_ptr(), None, None, rs1.rows, C, drop_p, seed0, sadd, O._stream()),
                     "efts_layernorm_bwd")
             self._wgrad_any(ws, dz1_f.ptr, dz1_p, val_f.ptr, val_p, C, C, 3, rs1.rows, g[gname(0, "0.weight")])
             dV_dur = ws.f32("BdV_dur", rs1, C)

@@ -147,8 +147,31 @@ class EfficientTTSTrainer:
             self.scheduler.load_state_dict(payload["scheduler"])
 
     # ------------------------------------------------------------------------------------------ one optimisation step
+    def _graphed_step(self):
+        """the GraphedStep of this run, or None: off unless the YAML asks for it, and only for the fused optimizer on one process"""
+        if not self.config.get("graph_steps", False) or hasattr(self.model, "finish_reduce") or not hasattr(self.optimizer, "launch"):
+            return None
+        if getattr(self, "_graph", None) is None:
+            from .step_graph import GraphedStep
+            self._graph = GraphedStep(self._net, self.optimizer, self.scheduler, grad_scale=getattr(self.model, "grad_scale", 1.0),
+                                      capacity=int(self.config.get("graph_shapes", 4)))
+        return self._graph
+
     def _train_step(self, batch) -> None:
         text, text_lengths, mel, mel_lengths = self._stage(batch)
+        if self._graphed_step() is not None:
+            # `graph_steps: true` (YAML): forward + backward + clip + Adam + schedule as one hipGraph replay per batch shape
+            # (efficient_tts_amd/step_graph.py; same results as the launches below).  Pays with a fixed set of batch shapes
+            # (bucketed / padded loaders): every new shape is captured once and keeps its activation workspace.
+            self._graph.opt.grad_norm = float(self.config["grad_norm"])
+            loss, stats = self._graph(text, text_lengths, mel, mel_lengths)
+            if int(self.config.get("rank", 0)) == 0:
+                self._unread.append(stats)
+            self.steps += 1
+            if self._bar is not None:
+                self._bar.update(1)
+            self.finish_train = self.steps >= int(self.config["train_max_steps"])
+            return
         loss, stats, *_ = self.model(text=text, text_lengths=text_lengths, speech=mel, speech_lengths=mel_lengths)
         if int(self.config.get("rank", 0)) == 0:
             self._unread.append(stats)                          # drained by _after_step, which only rank 0 runs

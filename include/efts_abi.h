@@ -370,13 +370,15 @@ int efts_bf16_round(const float* x, uint16_t* y, int64_t n, int32_t mode, void* 
  *   mode 1: inference, max(exp(.) - offset, 0)  (:78-83, to_round=False), * rowmask if given.
  * drop_p > 0 applies the module's Dropout(0.1) after the LayerNorm (:61, train mode): a stateless
  * counter-based mask from (drop_seed, element index), regenerated identically by efts_layernorm_bwd.
+ * drop_seed_add (optional, device): one word added to drop_seed when the kernel runs -- the step counter of a training step that
+ * is replayed as a hipGraph, where by-value arguments are frozen at capture time.
  * ---------------------------------------------------------------------------------- */
 int efts_layernorm_rows(const float* x, const float* gamma, const float* beta, float eps,
                         const float* rowmask, float* f32_out, void* plane, int64_t ld_plane,
-                        int32_t rows, int32_t c, int32_t split, float drop_p, uint32_t drop_seed, void* stream);
+                        int32_t rows, int32_t c, int32_t split, float drop_p, uint32_t drop_seed, const uint32_t* drop_seed_add, void* stream);
 int efts_layernorm_dot(const float* x, const float* gamma, const float* beta, float eps, const float* w,
                        const float* b, const float* rowmask, int32_t mode, float offset, float* out,
-                       int32_t rows, int32_t c, float drop_p, uint32_t drop_seed, void* stream);
+                       int32_t rows, int32_t c, float drop_p, uint32_t drop_seed, const uint32_t* drop_seed_add, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * FastSpeechLoss with use_masking=True (nntts/losses/fastspeech_loss.py:54-67):
@@ -463,7 +465,7 @@ int efts_wgrad_reduce_bias(const float* part, int32_t nsplit, const float* v, co
 int efts_layernorm_bwd(const float* x, const float* gamma, const float* beta, float eps, const float* dy,
                        const float* ddur, const float* w, const float* rowmask, float* dz, void* plane,
                        int64_t ld_plane, int32_t split, float* dgamma, float* dbeta, float* dbias, float* dw, float* db,
-                       int32_t rows, int32_t c, float drop_p, uint32_t drop_seed, void* stream);
+                       int32_t rows, int32_t c, float drop_p, uint32_t drop_seed, const uint32_t* drop_seed_add, void* stream);
 /* alignment block backward (efficient_tts.py:287-398 under autograd): */
 int efts_alpha_bwd(const float* ralpha, const float* dalpha, const float* e, const int32_t* text_len,
                    const int32_t* mel_len, float sigma, float* r_ws /* [B*T2] */, float* de, int32_t B, int32_t T1,
@@ -490,6 +492,16 @@ int efts_scale_unless_one(float* x, int64_t n, const float* scale, void* stream)
 int efts_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, const float* sumsq,
                       float max_norm, float gscale, float lr, float beta1, float beta2, float eps, float weight_decay,
                       int32_t step, void* stream);
+/* The same update with its per-step scalars in DEVICE memory -- hyper = {lr, 1 - beta1^step, sqrt(1 - beta2^step)}, as
+ * efts_adam_hyper (host) computes them, bit for bit what efts_adam_amsgrad derives from its by-value arguments -- so that a whole
+ * training step (nntts/trainers/efficient_tts_trainer.py:139-160) can be captured once and replayed as a hipGraph: the host only
+ * refreshes the words in front of every replay (efts_store_words: up to 8 32-bit words passed by value, stream-ordered; the same
+ * call carries the dropout step word of efts_layernorm_rows / _dot / _bwd `drop_seed_add`). */
+int efts_adam_hyper(float lr, float beta1, float beta2, int32_t step, float* out3 /* host */);
+int efts_adam_amsgrad_dev(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, const float* sumsq,
+                          float max_norm, float gscale, const float* hyper, float beta1, float beta2, float eps,
+                          float weight_decay, void* stream);
+int efts_store_words(uint32_t* dst /* device */, const uint32_t* words /* host */, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Log-mel front-end: the data format right before the path.
