@@ -464,6 +464,13 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, const RcProb& pq, const
     }
 }
 
+#ifndef RC_W4
+#define RC_W4 0
+#endif
+#if RC_W4
+#include "efts_resconv_w4.h"   // lab variant: one wave per SIMD (slower; see the header)
+#endif
+
 template <int SPLIT>
 __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -740,6 +747,19 @@ extern "C" int efts_resconv5_multi(const efts_resconv5_args* a, int32_t count, v
         static int launch = 0;
         if (!base) { const char* e = getenv("EFTS_RC_STAMP"); if (e) base = (unsigned long long*)strtoull(e, nullptr, 16); }
         if (base) { k.stamp = base + (size_t)(launch % 64) * 1024; ++launch; }
+    }
+#endif
+#if RC_W4
+    {
+        static bool attr4 = false;
+        if (!attr4) {
+            (void)hipFuncSetAttribute((const void*)resconv5w4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
+            (void)hipFuncSetAttribute((const void*)resconv5w4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
+            attr4 = true;
+        }
+        if (a->split == 1) hipLaunchKernelGGL(resconv5w4_kernel<1>, grid, dim3(256), RC_LDS, (hipStream_t)stream, k);
+        else hipLaunchKernelGGL(resconv5w4_kernel<2>, grid, dim3(256), RC_LDS, (hipStream_t)stream, k);
+        return efts_check_launch("efts_resconv5");
     }
 #endif
     if (a->split == 1) hipLaunchKernelGGL(resconv5_kernel<1>, grid, dim3(512), RC_LDS, (hipStream_t)stream, k);
