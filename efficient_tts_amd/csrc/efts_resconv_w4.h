@@ -1,9 +1,9 @@
 // efts_resconv_w4.h -- LAB VARIANT of efts_resconv5's kernel (included by efts_resconv.hip under -DRC_W4=1 | 2 only; never part of the
-// product library): one wave per SIMD.  Bit-identical to the product kernel on every shape tried, and SLOWER: 197 us per B = 64
-// launch against 130 (bf16), 349 against 292 (bf16x3) -- hipcc spills inside the main loop once 256 accumulator registers are live
-// (105 VGPR + 124 SGPR spills; every scratch reload sits behind an s_waitcnt vmcnt(0) that also drains the LDS-DMA queue), and four
-// waves issue half the epilogue's memory requests of eight.  An earlier form of it without the shared odd row block (wave rows of 4 + 3
-// blocks: the SIMDs of the taller row set the pace) had a clean loop and ran at 153 us.  Kept as the starting point of DESIGN.md
+// product library): one wave per SIMD.  Bit-identical to the product kernel on every shape tried, and SLOWER: 196 us per B = 64
+// launch against 129 (bf16) even with spill-free steady-state steps (tools/rc_w4_loops.sh counts scratch / accumulator-move /
+// lane-spill instructions per step from the ISA) -- hipcc does not keep the fragment reads a whole k-slice ahead of their MFMAs
+// (it re-sinks them next to their uses behind partial lgkmcnt waits), so the LDS latency is exposed several times per slice.
+// An earlier form without the shared odd row block (wave rows of 4 + 3 blocks: the SIMDs of the taller row set the pace) ran at 153 us.  Kept as the starting point of DESIGN.md
 // section 9 item 1; build: EFTS_CFLAGS=-DRC_W4=1 EFTS_LIB_OUT=lab/rc_w4.so python -m efficient_tts_amd.build --force
 // =================================================================================================================
 // The same layer with ONE wave per SIMD (lab variant, -DRC_W4=1): 2 x 2 waves of up to 128 x 128 outputs on the same (32 h) x 256 tile.
@@ -117,9 +117,23 @@ __device__ __forceinline__ void rc4_tile(const RcArgs& p, const RcProb& pq, cons
 #pragma unroll
             for (int j = 0; j < 4; ++j) mma3(acc[i][j], buf, i, j);
         if constexpr (XT) {
-            // this wave's two 32-column blocks of the shared row block: 2 wm, 2 wm + 1 of its own 128 columns (wm is wave-uniform)
-            if (wm == 0) { mma3(accx[0], buf, NF, 0); mma3(accx[1], buf, NF, 1); }
-            else { mma3(accx[0], buf, NF, 2); mma3(accx[1], buf, NF, 3); }
+            // this wave's two 32-column blocks of the shared row block: 2 wm, 2 wm + 1 of its own 128 columns.  The B fragments are
+            // SELECTED (8 v_cndmask per slice), not branched on: with a branch the accumulators of the two arms met in phi nodes and
+            // were copied between the accumulator and the vector file every step (160-190 v_accvgpr moves per step)
+#pragma unroll
+            for (int jx = 0; jx < 2; ++jx) {
+                bf16x8 b0, b1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    b0[e] = wm ? fb[buf][0][2 + jx][e] : fb[buf][0][jx][e];
+                    if constexpr (SPLIT == 2) b1[e] = wm ? fb[buf][1][2 + jx][e] : fb[buf][1][jx][e];
+                }
+                if constexpr (SPLIT == 2) {
+                    accx[jx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][1][NF], b0, accx[jx], 0, 0, 0);
+                    accx[jx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][0][NF], b1, accx[jx], 0, 0, 0);
+                }
+                accx[jx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][0][NF], b0, accx[jx], 0, 0, 0);
+            }
         }
     };
     auto interleave = [&]() {                              // the DS reads of the next slice between the MFMAs of this one
