@@ -3,6 +3,9 @@
 // launch against 129 (bf16) even with spill-free steady-state steps (tools/rc_w4_loops.sh counts scratch / accumulator-move /
 // lane-spill instructions per step from the ISA) -- hipcc does not keep the fragment reads a whole k-slice ahead of their MFMAs
 // (it re-sinks them next to their uses behind partial lgkmcnt waits), so the LDS latency is exposed several times per slice.
+// (A further form with the main loop's reads and MFMAs as volatile asm in a fixed interleaved order produced exactly the intended
+// ISA and the same time -- so the schedule is not what holds it back; the DMA issue block and the barrier of every step sit in the
+// single wave's instruction stream with nothing to overlap them, which the ping-pong partner of the product kernel hides.)
 // An earlier form without the shared odd row block (wave rows of 4 + 3 blocks: the SIMDs of the taller row set the pace) ran at 153 us.  Kept as the starting point of DESIGN.md
 // section 9 item 1; build: EFTS_CFLAGS=-DRC_W4=1 EFTS_LIB_OUT=lab/rc_w4.so python -m efficient_tts_amd.build --force
 // =================================================================================================================
