@@ -81,6 +81,26 @@ __global__ void row_masks_kernel(const int* __restrict__ len, float* gap, float*
     if (lm) lm[row] = (t < T && t < len[b]) ? 1.f : 0.f;
 }
 
+// both row spaces of a teacher-forced pass in one launch, straight from the caller's length tensors (int64 as torch makes them, or
+// int32): their int32 copies (what every later launch reads), gap masks and length masks
+__global__ void row_masks_pair_kernel(const void* __restrict__ l1, const void* __restrict__ l2, int is64, int* __restrict__ o1, int* __restrict__ o2,
+                                      float* gap1, float* lm1, float* gap2, float* lm2, int B, int T1, int Tp1, int T2, int Tp2) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n1 = B * Tp1, n2 = B * Tp2;
+    auto len_of = [&](const void* l, int b) { return is64 ? (int)((const long*)l)[b] : ((const int*)l)[b]; };
+    if (row < B) { o1[row] = len_of(l1, row); o2[row] = len_of(l2, row); }
+    if (row < n1) {
+        const int b = row / Tp1, t = row - b * Tp1;
+        if (gap1) gap1[row] = t < T1 ? 1.f : 0.f;
+        if (lm1) lm1[row] = (t < T1 && t < len_of(l1, b)) ? 1.f : 0.f;
+    }
+    if (row < n2) {
+        const int b = row / Tp2, t = row - b * Tp2;
+        if (gap2) gap2[row] = t < T2 ? 1.f : 0.f;
+        if (lm2) lm2[row] = (t < T2 && t < len_of(l2, b)) ? 1.f : 0.f;
+    }
+}
+
 __global__ void embed_kernel(const long* __restrict__ ids, const float* __restrict__ table, float* __restrict__ f32o,
                              char* __restrict__ plane, long ldp, int T, int Tp, int c, int nsym, int split) {
     const int row = blockIdx.x;
@@ -547,6 +567,16 @@ extern "C" int efts_row_masks(const int32_t* lengths, float* gapmask, float* len
     if (!lengths || B <= 0 || T <= 0 || Tp < T) return efts_fail(EFTS_EINVAL, "efts_row_masks: bad arguments");
     hipLaunchKernelGGL(row_masks_kernel, dim3((B * Tp + 255) / 256), dim3(256), 0, ST, lengths, gapmask, lenmask, B, T, Tp);
     return efts_check_launch("efts_row_masks");
+}
+
+extern "C" int efts_row_masks_pair(const void* len1, const void* len2, int32_t is_int64, int32_t* len1_i32, int32_t* len2_i32, float* gap1,
+                                   float* lenmask1, float* gap2, float* lenmask2, int32_t B, int32_t T1, int32_t Tp1, int32_t T2, int32_t Tp2, void* stream) {
+    if (!len1 || !len2 || !len1_i32 || !len2_i32 || B <= 0 || T1 <= 0 || T2 <= 0 || Tp1 < T1 || Tp2 < T2)
+        return efts_fail(EFTS_EINVAL, "efts_row_masks_pair: bad arguments");
+    const int n = B * (Tp1 > Tp2 ? Tp1 : Tp2);
+    hipLaunchKernelGGL(row_masks_pair_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, len1, len2, is_int64 ? 1 : 0, len1_i32, len2_i32, gap1, lenmask1, gap2,
+                       lenmask2, B, T1, Tp1, T2, Tp2);
+    return efts_check_launch("efts_row_masks_pair");
 }
 
 extern "C" int efts_embed(const int64_t* ids, const float* table, float* f32_out, void* plane, int64_t ld_plane, int32_t B,

@@ -78,6 +78,7 @@ _SIGS = {
     "efts_resconv5_plan": (i32, [i32, i32, i32, C.POINTER(i32), i32]),
     "efts_pack_weight": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "efts_row_masks": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "efts_row_masks_pair": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "efts_embed": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
     "efts_embed_conv": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp]),
     "efts_pack_rows": (i32, [vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]),

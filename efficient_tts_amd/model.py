@@ -623,19 +623,25 @@ class EfficientTTSCNN(torch.nn.Module):
         C = self.n_channels
         text = text.contiguous()
         speech = speech.contiguous().float()
-        tl = text_lengths.to(device=dev, dtype=torch.int32)
-        ml = speech_lengths.to(device=dev, dtype=torch.int32)
         pk = self._weights()
         ws = self._workspace(("fwd", B, T1, T2), dev)
         rs1, rs2 = Rows(B, T1), Rows(B, T2)
         gap1, len1 = ws.tensor("gap1", (rs1.rows,)), ws.tensor("len1", (rs1.rows,))
         gap2, len2 = ws.tensor("gap2", (rs2.rows,)), ws.tensor("len2", (rs2.rows,))
+        tl_d, ml_d = text_lengths.to(dev), speech_lengths.to(dev)
+        masks_done = tl_d.dtype == ml_d.dtype and tl_d.dtype in (torch.int64, torch.int32) and tl_d.is_contiguous() and ml_d.is_contiguous()
+        if masks_done:
+            # :137-139 for both row spaces + the int32 copies of the lengths in ONE launch (two casts + two mask launches before)
+            tl, ml = O.row_masks_pair(tl_d, ml_d, rs1, rs2, gap1, len1, gap2, len2)
+        else:
+            tl, ml = tl_d.to(torch.int32), ml_d.to(torch.int32)
         # The text side (masks, embed, 5 convs, K/V) and the duration predictor do not depend on the mel side (prenet, 3 convs).
         main = torch.cuda.current_stream(dev)
         side = self._side_stream(dev)
         side.wait_stream(main)
         vt = None if self._fused_expand(T1) else ws.raw_plane("vt", B * C, T1, 2)
-        O.row_masks(ml, rs2, gap2, len2)                                          # :139
+        if not masks_done:
+            O.row_masks(ml, rs2, gap2, len2)                                      # :139
         dec_rider = dec_after = None
         nt, nm = len(self.text_encoder.layers), len(self.mel_encoder.layers)
         merged = self.merge_text and self._on_resconv(rs2) and nt >= 1 and nm >= 1
@@ -684,7 +690,8 @@ class EfficientTTSCNN(torch.nn.Module):
                 pre = prenet(cus // 2 if share else 0)
                 pre_ready.record(side)
             te_plan = O.resconv5_plan_buf(rs1.rows, C, cus // 2 - 2) if share else None
-            O.row_masks(tl, rs1, gap1, len1)                                      # :137
+            if not masks_done:
+                O.row_masks(tl, rs1, gap1, len1)                                  # :137
             tab = self._te0_table(pk)
             if tab is not None:                                                   # :144 + layer 0 of :148 as table look-ups
                 x_f, x_p = self._embed_te0(ws, pk, text, rs1, None, tab)
@@ -745,7 +752,8 @@ class EfficientTTSCNN(torch.nn.Module):
             # second HIP stream: the text-side launches fill the tail rounds of the mel-length kernels
             k_ready = torch.cuda.Event()
             with O.on_stream(side):
-                O.row_masks(tl, rs1, gap1, len1)                                  # :137
+                if not masks_done:
+                    O.row_masks(tl, rs1, gap1, len1)                              # :137
                 key_p, val_f, val_p = self._text_side(ws, pk, text, rs1, gap1, len1, on_key=lambda: k_ready.record(side), vt=vt)  # :144-157
                 v_ready.record(side)
                 dur = self._duration(ws, pk, rs1, val_p, gap1, len1.data_ptr(), 0)    # :219

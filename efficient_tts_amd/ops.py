@@ -295,6 +295,16 @@ def row_masks(lengths_i32: torch.Tensor, rs: Rows, gap: Optional[torch.Tensor], 
             "efts_row_masks")
 
 
+def row_masks_pair(len1: torch.Tensor, len2: torch.Tensor, rs1: Rows, rs2: Rows, gap1, lm1, gap2, lm2):
+    """masks of both row spaces + int32 copies of the (int64 or int32, device) length tensors in one launch -> (tl, ml) int32"""
+    assert len1.dtype == len2.dtype and len1.dtype in (torch.int64, torch.int32) and len1.is_contiguous() and len2.is_contiguous()
+    o1 = torch.empty(rs1.B, dtype=torch.int32, device=len1.device)
+    o2 = torch.empty(rs1.B, dtype=torch.int32, device=len1.device)
+    L.check(L.load().efts_row_masks_pair(len1.data_ptr(), len2.data_ptr(), int(len1.dtype == torch.int64), o1.data_ptr(), o2.data_ptr(), _p(gap1), _p(lm1),
+                                         _p(gap2), _p(lm2), rs1.B, rs1.T, rs1.Tp, rs2.T, rs2.Tp, _stream()), "efts_row_masks_pair")
+    return o1, o2
+
+
 def embed(ids: torch.Tensor, table: torch.Tensor, out: Optional[F32Rows], plane: Optional[Plane], rs: Rows) -> None:
     c = table.shape[1]
     L.check(L.load().efts_embed(ids.data_ptr(), table.data_ptr(), None if out is None else out.ptr,

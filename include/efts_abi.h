@@ -260,6 +260,11 @@ int efts_pack_weight(const float* w, const float* g, float* w_f32_out, void* pla
  * ---------------------------------------------------------------------------------- */
 int efts_row_masks(const int32_t* lengths, float* gapmask, float* lenmask, int32_t B, int32_t T,
                    int32_t Tp, void* stream);
+/* both row spaces of a teacher-forced pass (text: T1, mel: T2) in ONE launch, straight from the caller's length tensors (int64 as
+ * torch makes them -- is_int64 -- or int32): int32 copies of the lengths (what every later entry point takes) + the four masks. */
+int efts_row_masks_pair(const void* len1, const void* len2, int32_t is_int64, int32_t* len1_i32, int32_t* len2_i32, float* gap1,
+                        float* lenmask1, float* gap2, float* lenmask2, int32_t B, int32_t T1, int32_t Tp1, int32_t T2,
+                        int32_t Tp2, void* stream);
 int efts_embed(const int64_t* ids, const float* table, float* f32_out, void* plane, int64_t ld_plane,
                int32_t B, int32_t T, int32_t Tp, int32_t c, int32_t num_symbols, int32_t split,
                void* stream);

@@ -218,3 +218,27 @@ def test_embed_conv_equals_embedding_plus_first_text_layer(precision, masked):
     assert float(gaprows.abs().max()) == 0.0
     pa, pb = p.buf.view(torch.bfloat16).float(), p_ref.buf.view(torch.bfloat16).float()
     assert float((pa - pb).abs().max()) <= 2.0 ** -7 * scale          # same values up to one bf16 ulp where the fp32 sums differ in the last bit
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.int64, torch.int32])
+def test_row_masks_pair_equals_two_row_masks_launches(dtype):
+    """efts_row_masks_pair (make_non_pad_mask for both row spaces of a teacher-forced pass + the int32 copies of the caller's int64
+    lengths, one launch) against efts_row_masks per row space (nntts/utils/nets_utils.py:170-254, efficient_tts.py:137-139)."""
+    from efficient_tts_amd import ops as P
+    dev = torch.device("cuda:0")
+    B, T1, T2 = 7, 37, 211
+    g = torch.Generator().manual_seed(3)
+    l1 = torch.randint(1, T1 + 1, (B,), generator=g).to(dtype).to(dev)
+    l2 = torch.randint(1, T2 + 1, (B,), generator=g).to(dtype).to(dev)
+    rs1, rs2 = P.Rows(B, T1), P.Rows(B, T2)
+    ref = [torch.full((r.rows,), -1.0, device=dev) for r in (rs1, rs1, rs2, rs2)]
+    got = [torch.full((r.rows,), -1.0, device=dev) for r in (rs1, rs1, rs2, rs2)]
+    with P.stream_scope():
+        P.row_masks(l1.to(torch.int32), rs1, ref[0], ref[1])
+        P.row_masks(l2.to(torch.int32), rs2, ref[2], ref[3])
+        o1, o2 = P.row_masks_pair(l1, l2, rs1, rs2, *got)
+        torch.cuda.synchronize()
+    assert o1.dtype == torch.int32 and torch.equal(o1, l1.to(torch.int32)) and torch.equal(o2, l2.to(torch.int32))
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
