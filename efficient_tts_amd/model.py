@@ -307,11 +307,15 @@ class EfficientTTSCNN(torch.nn.Module):
         if key not in tables:
             # Pointers are stable across steps: built once per item list.  Tables are KEPT (the eval forward and the training engine
             # alternate between two lists -- with and without the dgrad planes -- and a training step captured as a hipGraph keeps
-            # launching with the table it was captured with: a replaced table would be freed memory under that graph)
-            if len(tables) >= 8:
-                tables.clear()                                           # (parameters re-homed / re-created many times over)
+            # launching with the table it was captured with: a replaced table would be freed memory under that graph).  Least
+            # recently used ones go beyond 8: those belong to parameter storages that no longer exist (re-homed / re-created
+            # parameters), which a captured step can no longer be replayed with either (its tag holds the storage signature)
+            while len(tables) >= 8:
+                tables.pop(next(iter(tables)))
             tables[key] = (torch.tensor(table_rows, dtype=torch.int64, device=dev),
                            torch.empty(max(n * co for _, n, _, _, co, _, _, _ in launches), device=dev))
+        else:
+            tables[key] = tables.pop(key)                                # most recently used last
         table, scale = tables[key]
         base = table.data_ptr()
         for first, n, ld, ld_t, cout, cin, taps, with_t in launches:

@@ -46,6 +46,12 @@ class GraphedStep:
             self.sch.step()
         return loss.detach(), stats
 
+    def _tag(self, ws, eng):
+        """what a captured step is valid for: the buffers its launches point at and every argument they carry by value"""
+        m, g = self.model, self.opt.param_groups[0]
+        return (ws.serial, id(eng), getattr(m, "_ptr_sig", None), float(self.opt.grad_norm), self.grad_scale, tuple(g["betas"]), float(g["eps"]),
+                float(g["weight_decay"]), bool(m.training))
+
     def _refresh(self, eng) -> None:
         """the words of the step about to run: Adam's scalars for step t + 1 and the Dropout step word of call dropout_calls + 1"""
         m = self.model
@@ -66,8 +72,9 @@ class GraphedStep:
         ent["calls"] += 1
         eng = engine_of(m)
         ws = m._workspace(("train", text.shape[0], text.shape[1], speech.shape[1]), dev)
-        tag = (ws.serial, id(eng), m._ptr_sig if hasattr(m, "_ptr_sig") else None)
-        if ent["graph"] is not None and ent["tag"] != tag:          # the buffers the launches point at were re-allocated
+        tag = self._tag(ws, eng)
+        if ent["graph"] is not None and ent["tag"] != tag:          # the buffers the launches point at were re-allocated, or a by-value
+                                                                     # hyper-parameter of the captured launches changed
             ent.update(graph=None, calls=2)
         if ent["calls"] == 1 or ent.get("eager_only"):
             return self._eager(text, text_lengths, speech, speech_lengths)
@@ -96,8 +103,7 @@ class GraphedStep:
                 finally:
                     eng.step_words = None
                 m.dropout_calls = calls0                              # (a capture runs nothing)
-                ent.update(graph=g, out3=out3, tag=(m._workspace(("train", text.shape[0], text.shape[1], speech.shape[1]), dev).serial, id(eng),
-                                                    m._ptr_sig if hasattr(m, "_ptr_sig") else None), keep=(ws, eng))
+                ent.update(graph=g, out3=out3, tag=self._tag(m._workspace(("train", text.shape[0], text.shape[1], speech.shape[1]), dev), eng), keep=(ws, eng))
             else:
                 for s_, t in zip(ent["static"], (text, text_lengths, speech, speech_lengths)):
                     s_.copy_(t, non_blocking=True)
