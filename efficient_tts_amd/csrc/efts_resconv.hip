@@ -121,7 +121,10 @@ struct RcCtx {
     int ws;                 // ring slot of the next step
     int wpar;               // window buffer of the next tile's chunk 0
     unsigned long long tph[4];   // RC_STAMP 2: shader-clock cycles in read phases / their barrier / MFMA phases / their barrier
+    int nst;                // RC_STAMP 3: marks written so far
 };
+// -DRC_STAMP=3: wave 0 of every workgroup marks kernel start, end of tile 0's main loop, end of tile 0's epilogue, kernel end (100 MHz clock)
+#define RC_MARK(p, c) do { if (RC_STAMP == 3 && (p).stamp && (c).wave == 0 && (c).nst < 4) (p).stamp[blockIdx.x * 4 + (c).nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 // window pieces of one tile of h half units: piece P = q * 8 + wave, P < 4 h, covers window rows 8P .. 8P+7 (lane l: row 8P + l/8,
 // physical slot l%8); rows past the guard band after the matrix are clamped (their outputs are never stored)
@@ -323,6 +326,7 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, const RcProb& pq, const
     }
     };
     if (wm == 0) steps(RcRow<0>{}); else steps(RcRow<1>{});
+    RC_MARK(p, c);
     c.ws = ws;
     c.wpar = (c.wpar + p.nchunk) & 1;
 
@@ -480,8 +484,10 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
     const int tid = threadIdx.x;
     if (RC_STAMP == 1 && p.stamp && tid == 0) p.stamp[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
     c.tph[0] = c.tph[1] = c.tph[2] = c.tph[3] = 0;
+    c.nst = 0;
     c.lane = tid & 63;
     c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    RC_MARK(p, c);
     c.wm = c.wave >> 2; c.wn = c.wave & 3;
     c.lrow = c.lane & 31; c.lhalf = c.lane >> 5;
 
@@ -576,6 +582,7 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
                 default: rc_tile<SPLIT, 4, 5>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
             }
         }
+        RC_MARK(p, c);
         if (h1 > 0 && pi1 != pi) bias_of(pn);
         c.w_base = c.w_next; c.wts = c.wts_next;
         vrow = vnext; pi = pi1; m0 = m1; h = h1; rows_out = rows1;
@@ -583,6 +590,7 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
     // the last tile's wrapped weight requests may still be landing: LDS must not be handed to another workgroup under them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (RC_STAMP == 1 && p.stamp && tid == 0) p.stamp[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+    if (RC_STAMP == 3 && p.stamp && tid == 0) p.stamp[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     if (RC_STAMP == 2 && p.stamp && blockIdx.x < 32 && c.lane == 0) {          // [workgroup < 32][wave][4 phase counters]
 #pragma unroll
         for (int q = 0; q < 4; ++q) p.stamp[(blockIdx.x * 8 + c.wave) * 4 + q] = c.tph[q];

@@ -1,13 +1,20 @@
 // efts_resconv_w4.h -- LAB VARIANT of efts_resconv5's kernel (included by efts_resconv.hip under -DRC_W4=1 | 2 only; never part of the
-// product library): one wave per SIMD.  Bit-identical to the product kernel on every shape tried, and SLOWER: 196 us per B = 64
-// launch against 129 (bf16) even with spill-free steady-state steps (tools/rc_w4_loops.sh counts scratch / accumulator-move /
-// lane-spill instructions per step from the ISA) -- hipcc does not keep the fragment reads a whole k-slice ahead of their MFMAs
-// (it re-sinks them next to their uses behind partial lgkmcnt waits), so the LDS latency is exposed several times per slice.
-// (A further form with the main loop's reads and MFMAs as volatile asm in a fixed interleaved order produced exactly the intended
-// ISA and the same time -- so the schedule is not what holds it back; the DMA issue block and the barrier of every step sit in the
-// single wave's instruction stream with nothing to overlap them, which the ping-pong partner of the product kernel hides.)
-// An earlier form without the shared odd row block (wave rows of 4 + 3 blocks: the SIMDs of the taller row set the pace) ran at 153 us.  Kept as the starting point of DESIGN.md
-// section 9 item 1; build: EFTS_CFLAGS=-DRC_W4=1 EFTS_LIB_OUT=lab/rc_w4.so python -m efficient_tts_amd.build --force
+// product library): one wave per SIMD.  Bit-identical to the product kernel on every shape tried, and SLOWER.  Where its time goes
+// (tools/gpu_probe_rc_marks.py on -DRC_STAMP=3 builds of both kernels, one tile of 7 | 6 half units per workgroup = B = 32 x 800 frames,
+// bf16, us per workgroup, same box):
+//                                        main loop     epilogue     workgroup
+//   product kernel (8 waves, ping-pong)     61.7         13.9          75.8
+//   this one                                65.8         30.0          96.3
+//   this one without LDS-DMA in the loop    48.9         28.9          78.2      (-DRC_EXP=1; without the step barrier: no change)
+// i.e. the MFMA stream alone runs at ~70 % (34-36 us would be the issue rate), the LDS-DMA of the same 4 waves costs another 17-20 us
+// (nothing overlaps its issue: in the product kernel the partner wave's MFMA phase does), and four waves sweep a tile out in twice the
+// time of eight, however deep the prefetch (2 units ahead: no change).  The steady-state steps are free of spills (tools/rc_w4_loops.sh
+// counts scratch / accumulator-move / lane-spill instructions per step from the ISA); a form with the loop's reads and MFMAs as volatile
+// asm in a fixed interleaved order produced the intended ISA and the same time.  Other forms tried: wave rows of 4 + 3 blocks without
+// the shared odd row block (153 us per B = 64 launch against 129: the SIMDs of the taller row set the pace), each wave all h blocks x
+// 64 columns (247 us: spills), not-inlined tile functions (472 us: callees do not get the accumulator file).  Split-2 planes: 2 x slower
+// than the product kernel (the shared row block's fragment selects).
+// Build: tools/rc_w4_build.sh [1 | 2]  (2 = k5 layers only, half the compile time);  marks: add -DRC_STAMP=3.
 // =================================================================================================================
 // The same layer with ONE wave per SIMD (lab variant, -DRC_W4=1): 2 x 2 waves of up to 128 x 128 outputs on the same (32 h) x 256 tile.
 // A wave tile twice as wide needs 8 fragment reads per 16 MFMAs instead of 12, so LDS bandwidth stops being the co-limit of the
@@ -25,18 +32,29 @@ __device__ __forceinline__ void dma16u(unsigned lds_addr, unsigned voff, const c
     dma16(__builtin_amdgcn_readfirstlane(lds_addr), voff, (const char*)(((unsigned long long)hi << 32) | lo));
 }
 
+__device__ __forceinline__ void rc4_wait(int n) {           // s_waitcnt vmcnt(n), n = 0..24 at run time
+#define RC4_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    switch (n) {
+        RC4_W(1) RC4_W(2) RC4_W(3) RC4_W(4) RC4_W(5) RC4_W(6) RC4_W(7) RC4_W(8) RC4_W(9) RC4_W(10) RC4_W(11) RC4_W(12) RC4_W(13) RC4_W(14) RC4_W(15) RC4_W(16)
+        RC4_W(17) RC4_W(18) RC4_W(19) RC4_W(20) RC4_W(21) RC4_W(22) RC4_W(23) RC4_W(24)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef RC4_W
+}
+
 struct Rc4Ctx {
     char* smem;
     unsigned lds0;
     int lane, wave, wm, wn, lrow, lhalf;
     int n0;
-    unsigned vlane_w;       // this lane's source offset inside a weight piece: (lane / 8) * ldw + swizzled 16-byte slot
+    unsigned vow[8];        // per-lane source offsets of this wave's 8 weight pieces (fixed per workgroup)
     const char* w_base;
     const char* w_next;
     long wts, wts_next;
     float bv[4];
     int ws;                 // ring slot of the next step
     int wpar;               // window buffer of the next tile's chunk 0
+    int nst;
 };
 
 __device__ __forceinline__ int rc4_pieces(int h, int wave) { return (4 * h - wave + 3) >> 2; }   // pieces P = 4 q + wave < 4 h
@@ -52,28 +70,37 @@ __device__ __forceinline__ void rc4_tile(const RcArgs& p, const RcProb& pq, cons
     constexpr int NP = SPLIT == 1 ? 1 : 2;                  // fragments per operand block and slice (hi [, lo])
     constexpr int NA = NF + XT;                             // A fragment blocks per slice
 
-    // Window pieces: piece P = 4 q + wave covers window rows 8 P .. 8 P + 7, lane l row 8 P + l / 8 at the physical slot (l & 7) ^ ((row >> 1) & 7)
-    // -- which does not depend on q (32 q rows move the row index by a multiple of 16) -- so ONE per-lane offset serves every piece
-    // and the piece's row goes into the scalar base.  Pieces past the guard band behind the matrix are pulled back as a whole
-    // (their rows are never stored; they only must be readable).
-    const int lr8 = lane >> 3;
-    const int slw = (lane & 7) ^ (((wave * 8 + lr8) >> 1) & 7);
-    const unsigned vlane_a = (unsigned)(lr8 * (int)pq.lda + (slw << 4));
-    auto piece_base = [&](const RcProb& q, int mt, int P) {
-        const int rmax = q.m + 143 - (mt - 2) - 7;          // last window row a piece may start at
-        const int r = 8 * P < rmax ? 8 * P : rmax;
-        return q.a + (long)(mt - 2 + r) * q.lda;
-    };
+    // window pieces: piece P = 4 q + wave covers window rows 8 P .. 8 P + 7 (lane l: row 8 P + l / 8, physical slot (l & 7) ^ ((row >> 1) & 7));
+    // rows past the guard band after the matrix are clamped (their outputs are never stored).  Per-lane offsets, ONE scalar base
+    // per request group: (scalar per-piece bases cost more SGPRs than the kernel has -- their spills were reloaded from scratch inside
+    // the loop, each reload behind an s_waitcnt vmcnt(0) that drained the LDS-DMA queue)
+    unsigned voa[8];
+    {
+        const int rmax = pq.m + 143 - (m0 - 2);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = (q * 4 + wave) * 8 + (lane >> 3);
+            const int sl = (lane & 7) ^ ((r >> 1) & 7);
+            voa[q] = (unsigned)((r < rmax ? r : rmax) * (int)pq.lda + (sl << 4));
+        }
+    }
+    const char* a_base = pq.a + (long)(m0 - 2) * pq.lda;
     auto issue_a = [&](int cn, int buf) {
+        const char* sb = a_base + (long)cn * 128;
         const unsigned l = c.lds0 + buf * RC_WIN_BYTES + wave * 1024;
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-            if (q < nq) dma16u(l + q * 4096, vlane_a, piece_base(pq, m0, q * 4 + wave) + (long)cn * 128);
+            if (q < nq) dma16u(l + q * 4096, voa[q], sb);
     };
     auto issue_a_next = [&](int buf) {
+        const int rmax = pn.m + 143 - (m1 - 2);
+        const char* sb = pn.a + (long)(m1 - 2) * pn.lda;
         const unsigned l = c.lds0 + buf * RC_WIN_BYTES + wave * 1024;
-        const unsigned vl = (unsigned)(lr8 * (int)pn.lda + (slw << 4));
-        for (int q = 0; q < nq1; ++q) dma16u(l + q * 4096, vl, piece_base(pn, m1, q * 4 + wave));
+        for (int q = 0; q < nq1; ++q) {
+            const int r = (q * 4 + wave) * 8 + (lane >> 3);
+            const int sl = (lane & 7) ^ ((r >> 1) & 7);
+            dma16u(l + q * 4096, (unsigned)((r < rmax ? r : rmax) * (int)pn.lda + (sl << 4)), sb);
+        }
     };
 
     f32x16 acc[NF][4], accx[XT ? 2 : 1];
@@ -88,8 +115,11 @@ __device__ __forceinline__ void rc4_tile(const RcArgs& p, const RcProb& pq, cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) accx[j][r] = 0.f;
 
+    int a2 = 0, a1 = 0, g1 = 0;                            // window pieces of the groups issued two / one barrier ago, size of the latter
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // chunk 1's window (chunk 0 came with the previous tile's last chunks / the kernel prologue; the buffer was the epilogue's staging)
+    if (p.nchunk > 1 && !(RC_EXP & 1)) { issue_a(1, (c.wpar ^ 1) & 1); a1 = nq; g1 = nq; }
 
     bf16x8 fa[2][NP][NA], fb[2][NP][4];
     const int bcol = wn * 128 + lrow;
@@ -151,7 +181,6 @@ __device__ __forceinline__ void rc4_tile(const RcArgs& p, const RcProb& pq, cons
     };
 
     int ws = c.ws;
-    int pend = 0;                                          // requests issued behind the previous step's barrier
     load(0, smem + (c.wpar & 1) * RC_WIN_BYTES, smem + RC_RING + ws * RC_W_BYTES, (5 - TAPS) / 2, 0);
     int cur = 0;
     for (int ch = 0; ch < p.nchunk; ++ch) {
@@ -167,37 +196,29 @@ __device__ __forceinline__ void rc4_tile(const RcArgs& p, const RcProb& pq, cons
             for (int s = 0; s < KS; ++s) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the fragments of this slice (read under the previous MFMAs)
                 if (s == KS - 1) {
-                    // every read of this step's weight tile and (last tap) window is retired: behind the barrier the tile three steps
-                    // ahead goes into this step's slot, and the operands of the NEXT step (requested two barriers ago) are there.
-                    // Outstanding: the group requested behind the previous barrier (`pend` pieces, for the step after next) and the
-                    // one before it, which the next step needs: wait until only the former is left
-                    switch (pend) {
-                        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-                        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-                        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-                        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-                        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-                        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
-                        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-                        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-                        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-                        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                    }
-                    __builtin_amdgcn_s_barrier();
+                    // Every read of this step's weight tile and (last tap) window is retired.  Behind the barrier the weight tile three
+                    // steps ahead goes into this step's slot, and at a chunk's last tap the window TWO chunks ahead goes into this
+                    // chunk's buffer (a whole chunk of slack for the one stream that comes from HBM).  The counter retires in order --
+                    // ..., W(t-2), [A(t-2)], W(t-1), [A(t-1)] -- and the next step needs W(t-2): weights are issued in front of
+                    // the window of the same group and the wait leaves A(t-2) and the whole group t-1 outstanding.
+                    rc4_wait(a2 + g1);
+                    if (!(RC_EXP & 2)) __builtin_amdgcn_s_barrier();
                     const int kn = (k + 3) % TAPS;
                     int cn = ch + (k + 3) / TAPS;
                     const bool into_next = cn >= p.nchunk;
                     cn = into_next ? cn - p.nchunk : cn;
-                    const char* wsrc = (into_next ? c.w_next + (long)kn * c.wts_next : c.w_base + (long)kn * c.wts) + (long)cn * 128 + (long)wave * 8 * pq.ldw;
-                    const long wstep = 32 * pq.ldw;
+                    const char* wsrc = (into_next ? c.w_next + (long)kn * c.wts_next : c.w_base + (long)kn * c.wts) + (long)cn * 128;
                     const unsigned wdst = c.lds0 + RC_RING + ws * RC_W_BYTES + wave * 1024;
-                    pend = 8;
+                    int na = 0;
+                    if (!(RC_EXP & 1)) {
 #pragma unroll
-                    for (int g = 0; g < 8; ++g) dma16u(wdst + g * 4096, c.vlane_w, wsrc + g * wstep);
-                    if (k == 0) {
-                        if (!lastc) { issue_a(ch + 1, wbuf ^ 1); pend = 8 + nq; }
-                        else if (h1 > 0) { issue_a_next(wbuf ^ 1); pend = 8 + nq1; }
+                        for (int g = 0; g < 8; ++g) dma16u(wdst + g * 4096, c.vow[g], wsrc);
+                        if (k == TAPS - 1) {
+                            if (ch + 2 < p.nchunk) { issue_a(ch + 2, wbuf); na = nq; }
+                            else if (ch + 2 == p.nchunk && h1 > 0) { issue_a_next(wbuf); na = nq1; }
+                        }
                     }
+                    a2 = a1; a1 = na; g1 = (RC_EXP & 1) ? 0 : 8 + na;
                     // first fragments of the next step under this slice's MFMAs (not across the epilogue: the next tile has other rows)
                     const bool more = !(lastc && k == TAPS - 1);
                     if (more) {
@@ -217,6 +238,7 @@ __device__ __forceinline__ void rc4_tile(const RcArgs& p, const RcProb& pq, cons
             ws = (ws == 2) ? 0 : ws + 1;
         }
     }
+    RC_MARK(p, c);
     c.ws = ws;
     c.wpar = (c.wpar + p.nchunk) & 1;
 
@@ -240,8 +262,8 @@ __device__ __forceinline__ void rc4_tile(const RcArgs& p, const RcProb& pq, cons
     const unsigned sof_row = (unsigned)pq.ldo * 4, sob_row = (unsigned)pq.ldob;
     // one unit = one 32-row block x 64 columns: (first tile row, first column, the two accumulator blocks, their biases)
     constexpr int NU = NF * 2 + XT;
-    u32x4 xa[2][4], xb[2][4];
-    float rmv[2][4];
+    u32x4 xa[3][4], xb[3][4];                               // residual values of three units: two in flight ahead of the one being swept out
+    float rmv[3][4];
     auto unit_row = [&](int u) { return u < NF * 2 ? row0w + (u >> 1) * 32 : rowx; };
     auto unit_col = [&](int u) { return c.n0 + wn * 128 + (u < NF * 2 ? (u & 1) * 64 : wm * 64); };
     auto request = [&](int u, int bsel) {                  // the residual values and row masks of unit u: 4 passes of 8 rows
@@ -266,9 +288,10 @@ __device__ __forceinline__ void rc4_tile(const RcArgs& p, const RcProb& pq, cons
         }
     };
     request(0, 0);
+    if (NU > 1) request(1, 1);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        const int bsel = u & 1;
+        const int bsel = u % 3;
         const unsigned lrow0 = unit_row(u) + srow, col0 = unit_col(u) + c8 * 8;
         const unsigned vof = lrow0 * (unsigned)pq.ldo * 4 + col0 * 4;
         const unsigned vob = lrow0 * (unsigned)pq.ldob + (pq.out_split == 1 ? col0 * 2 : (col0 >> 5) * 128 + (col0 & 31) * 2);
@@ -286,7 +309,7 @@ __device__ __forceinline__ void rc4_tile(const RcArgs& p, const RcProb& pq, cons
                 *(float*)(stj + rl * 128 + ((((lrow >> 2) ^ ((rl >> 1) & 1))) << 4) + (lrow & 3) * 4) = v;
             }
         }
-        if (u + 1 < NU) request(u + 1, bsel ^ 1);
+        if (u + 2 < NU) request(u + 2, (u + 2) % 3);
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
             const int row = ps * 8 + srow;
@@ -349,6 +372,8 @@ __global__ __launch_bounds__(256, 1) void resconv5w4_kernel(RcArgs p) {
     c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     c.wm = c.wave >> 1; c.wn = c.wave & 1;
     c.lrow = c.lane & 31; c.lhalf = c.lane >> 5;
+    c.nst = 0;
+    RC_MARK(p, c);
     int v = blockIdx.x;
     {
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7;
@@ -379,10 +404,11 @@ __global__ __launch_bounds__(256, 1) void resconv5w4_kernel(RcArgs p) {
     int pi, m0, h, rows_out;
     locate(0, vrow, pi, m0, h, rows_out);
     if (h == 0) return;
-    {
-        const int lr8 = c.lane >> 3;
-        const int slw = (c.lane & 7) ^ (((c.wave * 8 + lr8) >> 1) & 7);
-        c.vlane_w = (unsigned)(lr8 * (int)p.pr[0].ldw + (slw << 4));  // (every layer of a launch has the same weight row stride)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = (q * 4 + c.wave) * 8 + (c.lane >> 3);
+        const int sl = (c.lane & 7) ^ ((r >> 1) & 7);
+        c.vow[q] = (unsigned)(r * (int)p.pr[0].ldw + (sl << 4));     // (every layer of a launch has the same weight row stride)
     }
     auto bias_of = [&](const RcProb& q) {
 #pragma unroll
@@ -394,22 +420,20 @@ __global__ __launch_bounds__(256, 1) void resconv5w4_kernel(RcArgs p) {
         c.wts = q0.w_tap_stride;
         bias_of(q0);
         c.ws = 0; c.wpar = 0;
-        const int lr8 = c.lane >> 3;
-        const int slw = (c.lane & 7) ^ (((c.wave * 8 + lr8) >> 1) & 7);
-        const unsigned vl = (unsigned)(lr8 * (int)q0.lda + (slw << 4));
-        const int rmax = q0.m + 143 - (m0 - 2) - 7;
+        const int rmax = q0.m + 143 - (m0 - 2);
+        const char* sb = q0.a + (long)(m0 - 2) * q0.lda;
         const int nq = rc4_pieces(h, c.wave);
         for (int q = 0; q < nq; ++q) {
-            const int P = q * 4 + c.wave;
-            const int r = 8 * P < rmax ? 8 * P : rmax;
-            dma16u(c.lds0 + c.wave * 1024 + q * 4096, vl, q0.a + (long)(m0 - 2 + r) * q0.lda);
+            const int r = (q * 4 + c.wave) * 8 + (c.lane >> 3);
+            const int sl = (c.lane & 7) ^ ((r >> 1) & 7);
+            dma16u(c.lds0 + c.wave * 1024 + q * 4096, (unsigned)((r < rmax ? r : rmax) * (int)q0.lda + (sl << 4)), sb);
         }
         // weights of steps 0, 1, 2: (chunk 0, taps 0, 1, 2) for 3 or 5 taps
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                dma16u(c.lds0 + RC_RING + s * RC_W_BYTES + c.wave * 1024 + q * 4096, c.vlane_w, c.w_base + (long)s * c.wts + (long)(q * 4 + c.wave) * 8 * q0.ldw);
+                dma16u(c.lds0 + RC_RING + s * RC_W_BYTES + c.wave * 1024 + q * 4096, c.vow[q], c.w_base + (long)s * c.wts);
     }
     for (int t = 0; h > 0; ++t) {
         const int vnext = vrow + rows_out;
@@ -430,10 +454,12 @@ __global__ __launch_bounds__(256, 1) void resconv5w4_kernel(RcArgs p) {
         }
 #endif
 #undef RC4_CASE
+        RC_MARK(p, c);
         if (h1 > 0 && pi1 != pi) bias_of(pn);
         c.w_base = c.w_next; c.wts = c.wts_next;
         vrow = vnext; pi = pi1; m0 = m1; h = h1; rows_out = rows1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (RC_STAMP == 3 && p.stamp && tid == 0) p.stamp[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
 }
 
