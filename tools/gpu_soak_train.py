@@ -15,16 +15,22 @@ tl = torch.randint(T1 // 2, T1 + 1, (B,), generator=g).to(dev); tl[0] = T1
 sl = torch.randint(T2 // 2, T2 + 1, (B,), generator=g).to(dev); sl[0] = T2
 for b in range(B):
     text[b, tl[b]:] = 0; mel[b, sl[b]:] = 0
-for prec, drop in (("bf16", 0.0), ("bf16x3", 0.0), ("bf16", 0.1)):
+from efficient_tts_amd.step_graph import GraphedStep
+for prec, drop, graphed in (("bf16", 0.0, False), ("bf16", 0.0, True), ("bf16x3", 0.0, True), ("bf16", 0.1, False)):
     torch.manual_seed(0)
     m = EfficientTTSCNN(num_symbols=76, dropout_rate=drop, use_masking=True, sigma=0.01, precision=prec).to(dev).train()
     opt = EftsAdam(m, lr=1e-3, betas=(0.9, 0.99), eps=1e-9, weight_decay=1e-5, amsgrad=True, grad_norm=1.0)
     sch = WarmupLR(opt, warmup_steps=50)
     hist = []
+    gs = GraphedStep(m, opt, sch)
     for step in range(int(os.environ.get("STEPS", 300))):
-        loss, stats, *_ = m(text=text, text_lengths=tl, speech=mel, speech_lengths=sl)
-        opt.zero_grad(); loss.backward(); opt.step(); sch.step()
+        if graphed:                                        # one hipGraph replay per step (the mel-length stacks run on efts_resconv5 at this size)
+            loss, stats = gs(text, tl, mel, sl)
+        else:
+            loss, stats, *_ = m(text=text, text_lengths=tl, speech=mel, speech_lengths=sl)
+            opt.zero_grad(); loss.backward(); opt.step(); sch.step()
         if step % 50 == 0 or step == int(os.environ.get("STEPS", 300)) - 1:
             hist.append((step, float(loss)))
     ok = all(v == v and v < 1e4 for _, v in hist) and hist[-1][1] < 0.5 * hist[0][1]
-    print(f"{prec} dropout {drop}: " + "  ".join(f"{s}:{v:.4f}" for s, v in hist) + ("  OK" if ok else "  FAILED"), flush=True)
+    assert (gs.replays == int(os.environ.get("STEPS", 300)) - 1) == graphed
+    print(f"{prec} dropout {drop} {'graphed' if graphed else 'eager'}: " + "  ".join(f"{s}:{v:.4f}" for s, v in hist) + ("  OK" if ok else "  FAILED"), flush=True)
