@@ -4,19 +4,23 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one synthetic batch.  Default workload =
-BASELINE.json configs[1]: EFTS-CNN teacher-forced forward (the reference's
-EfficientTTSCNN.forward under no_grad, nntts/models/efficient_tts.py:120-228) at
-batch 64 / phoneme-len 128 / mel-len 800 / 80 bins on ONE MI355X, bf16 MFMA operands with
-fp32 accumulate and an fp32 residual stream.  Inputs are resident in HBM before the timed
-region.  N > 1 runs one replica per GPU (the inference path has no exchange step): weak
-scaling, value = frames of all ranks / max-over-ranks time.  `--workload train` times the
-data-parallel training step (config 3/4) once the backward path is built.
+One "step" = one pass of the hot path over one synthetic batch.  Default workload = BASELINE.json configs[1]: the EFTS-CNN
+teacher-forced forward (the reference's EfficientTTSCNN.forward under no_grad, nntts/models/efficient_tts.py:120-228) at batch 64 /
+phoneme-len 128 / mel-len 800 / 80 bins per MI355X, bf16 MFMA operands with fp32 accumulate; the residual stream between the layers
+of the mel-length stacks is a pair of bf16 planes (hi + lo = 16 mantissa bits).  Inputs are resident in HBM
+before the timed region.
 
-Prints ONE JSON line on rank 0 (see README of the task for the field contract), with
-`roofline` for the dominant kernel (the k=5 Conv1d contraction at mel length, measured with
-HIP events on the launch stream inside the timed region) and `cpu_baseline` (the oracle's CPU
-restatement timed on this box's host cores on a bounded sample).
+`--gpus N` with N > 1: one process per GPU.  Under a launcher (WORLD_SIZE set: torch.distributed.run) the ranks are the
+launcher's and must number N; WITHOUT one this script launches the N ranks itself (re-executing under torch.distributed.run on
+127.0.0.1) and fails unless N ranks come up -- it never silently measures one GPU.  The forward has no exchange step, so its
+N-GPU value is N replicas (weak scaling, frames of all ranks / max-over-ranks time).  The same line then carries `train32`:
+BASELINE configs 3 / 4, the data-parallel training step at batch 32 per GPU with the bucketed RCCL gradient all-reduce overlapped
+with the backward (efficient_tts_amd/bench_train.py), with its `dp` record (backend, ranks, bytes and time per bucket, exposed wait,
+RCCL's own topology lines, bit-exact replica check).  `--workload train32` times only that step.
+
+Prints ONE JSON line on rank 0, with `roofline` for the dominant kernel (the k5 Conv1d contraction at mel length, measured with HIP
+events on the launch stream inside the timed region; `traffic` from two rocprofv3 PMC child passes) and `cpu_baseline` (the
+oracle's CPU restatement timed on this box's host cores on a bounded sample).
 """
 import argparse
 import glob
@@ -45,7 +49,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
-    ap.add_argument("--workload", default="fwd64", choices=["fwd64", "fwd16_long", "train32", "infer_lj", "infer64", "logmel64", "vocoder", "vocoder8"])
+    ap.add_argument("--workload", default="fwd64", choices=["fwd64", "fwd16_long", "train32", "infer_lj", "infer64", "logmel64", "vocoder", "vocoder8", "rendezvous"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-set", action="append", default=[], metavar="NAME=INT",
                     help="train32 A/B runs: set a switch of efficient_tts_amd.train (_SIGN_MIN_ROWS=0, _BIAS_PARTS=0, ...)")
@@ -133,8 +137,9 @@ def cpu_baseline(T1, T2, hip_check=None, Bc=64):
 
 def cpu_train_baseline(T1, T2):
     """the oracle (CPU restatement of the reference path, torch autograd for the backward)
-    timed on this box's host cores for one training step -- fwd + bwd + clip 1.0 + Adam-amsgrad -- on a bounded sample
-    (B=4 full-length items instead of 32; the step is linear in the batch)."""
+    timed on this box's host cores for one training step -- fwd + bwd + clip 1.0 + Adam-amsgrad -- at the config's own batch,
+    B = 32 full-length items: 1 warm-up step, then the median of 3 (one timed step if a step takes more than 8 s, so that the
+    default bench run stays bounded)."""
     from oracle import efts_oracle as O          # the cpu_baseline leg: oracle as the thing timed
     cores = os.cpu_count() or 1
     nt = min(cores, 32)
@@ -142,29 +147,30 @@ def cpu_train_baseline(T1, T2):
     P = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in O.fill_params().items()}
     params = [v for v in P.values() if v.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.99), eps=1e-9, weight_decay=1e-5, amsgrad=True)
-    Bc = 4
+    Bc = 32
     g = torch.Generator().manual_seed(1234)
     text = torch.randint(0, 76, (Bc, T1), generator=g)
     mel = torch.randn(Bc, T2, 80, generator=g)
     tl = torch.full((Bc,), T1, dtype=torch.int64)
     sl = torch.full((Bc,), T2, dtype=torch.int64)
-    times = []
-    for it in range(4):
+
+    def one():
         t0 = time.perf_counter()
         out = O.forward(P, text, tl, mel, sl)
         opt.zero_grad()
         out["loss"].backward()
         torch.nn.utils.clip_grad_norm_(params, 1.0)
         opt.step()
-        if it:
-            times.append(time.perf_counter() - t0)
-    med = sorted(times)[1]
+        return time.perf_counter() - t0
+    warm = one()
+    times = [one() for _ in range(3 if warm <= 8.0 else 1)]
+    med = sorted(times)[len(times) // 2]
     return dict(value=Bc * T2 / med, unit="mel-frames/s", cores=nt, host_cpus=cores, kind="port",
-                sample=f"oracle training step fp32 (forward, autograd backward, clip 1.0, torch Adam-amsgrad), B={Bc} x (T1={T1}, T2={T2}), "
-                       f"median of 3 after 1 warm-up ({med:.3f} s/step at {nt} threads)")
+                sample=f"oracle training step fp32 (forward, autograd backward, clip 1.0, torch Adam-amsgrad), B={Bc} x (T1={T1}, T2={T2}) = BASELINE.md "
+                       f"section 3's config-3 batch, median of {len(times)} after 1 warm-up ({med:.3f} s/step at {nt} threads)")
 
 
-def measure_traffic(a, precision):
+def measure_traffic(a, precision, workload=None):
     """HBM-side bytes per launch of the dominant kernel from the PMC counters, collected as MI355X_MICROARCH.md prescribes:
     FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 passes (--kernel-trace --pmc only), each over a 2-step child run of this very
     workload; FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of wide streaming reads at 64 B), both in KiB.
@@ -181,13 +187,14 @@ def measure_traffic(a, precision):
             out = os.path.join(tmp, ctr)
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", out, "-o", "b", "--", sys.executable, os.path.abspath(__file__),
                    "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--parity-mode", "0", "--call-modes", "0", "--train-record", "0",
-                   "--measure-traffic", "0", "--precision", precision, "--workload", a.workload]
+                   "--measure-traffic", "0", "--train-graph", "0", "--precision", precision, "--workload", workload or a.workload]
             subprocess.run(cmd, cwd="/tmp", env=env, timeout=150, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
             if not dbs:
                 return None
             con = sqlite3.connect(dbs[0])
-            # the mel-length launches WITHOUT a text-encoder rider are the most frequent grid of the kernel (6 of 9 per step)
+            # the mel-length launches WITHOUT a text-encoder rider are the most frequent grid of the kernel (6 of 9 per forward; the
+            # training step: 9 forward + 6 decoder dgrad launches of one grid)
             rows = con.execute("select grid_size, avg(value), count(*) from counters_collection where kernel_name like '%resconv5_kernel%' "
                                "and counter_name = ? group by grid_size order by 3 desc", (ctr,)).fetchall()
             con.close()
@@ -457,25 +464,71 @@ def run_infer_lj(a, world, rank, dev):
     print(json.dumps(res), flush=True)
 
 
+def _self_launch(a) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves -- this same command line under
+    torch.distributed.run on 127.0.0.1 -- and pass rank 0's JSON line through.  Fails (non-zero) unless N ranks come up."""
+    import socket
+    if a.workload != "rendezvous":
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            raise SystemExit(f"--gpus {a.gpus}: only {have} GPU(s) visible on this node; refusing to measure fewer ranks than asked for")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, EFTS_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def run_rendezvous(a, world, rank):
+    """launch check (also the CPU test of the self-launcher): every rank joins the group, one all-reduce counts them"""
+    import torch.distributed as dist
+    if world > 1:
+        t = torch.ones(1, device="cuda" if torch.cuda.is_available() else "cpu")
+        dist.all_reduce(t)
+        seen = int(t.item())
+    else:
+        seen = 1
+    if rank == 0:
+        print(json.dumps(dict(metric="ranks that joined the process group", value=seen, unit="ranks", n_gpus=world, ranks_seen=seen,
+                              backend=dist.get_backend() if world > 1 else None, self_launched=bool(os.environ.get("EFTS_BENCH_SELF_LAUNCHED")))), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    assert seen == a.gpus, f"--gpus {a.gpus} but {seen} ranks joined"
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(_self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher must start exactly --gpus ranks")
+    on_gpu = torch.cuda.is_available()
+    if a.workload != "rendezvous" or on_gpu:
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.workload == "train32":
+        if a.workload == "train32" or (a.workload == "fwd64" and a.train_record):
             # RCCL's own account of the topology and of the algorithm / protocol it picks per collective goes to per-rank FILES
             # (never to stdout: the contract is ONE JSON line); efficient_tts_amd/bench_train.py quotes it in the `dp` record
             os.environ.setdefault("NCCL_DEBUG", "INFO")
             os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING")
             os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/efts_rccl_{os.getpid()}_%h_%p.log")
-        dist.init_process_group("nccl", device_id=dev)
+        if on_gpu:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    if a.workload == "rendezvous":
+        return run_rendezvous(a, world, rank)
 
     from efficient_tts_amd import EfficientTTSCNN, ops as P
     if a.workload == "infer_lj":
@@ -642,34 +695,46 @@ def run_forward(a, world, rank, dev, wl):
             d, _, _ = timed(model, 10, 2, md)
             cm[md + "_ms"] = d / 10 * 1e3
         res["call_modes"] = dict(cm, note="10 steps each after the timed region: plain model() call (the model's own per-shape choice) / bench-level hipGraph / eager launches")
-    if rank == 0:
-        if world == 1 and not a.no_cpu_baseline:
-            checks = {}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        checks = {}
 
-            def hip_check(Pd, text_c, tl_c, mel_c, sl_c):
-                out = None
-                for prec in ("bf16", "bf16x3"):
-                    m2 = build(prec, Pd)
-                    with torch.no_grad():
-                        checks[prec] = m2(text_c.to(dev), tl_c.to(dev), mel_c.to(dev), sl_c.to(dev))[4].detach().cpu()
-                    if prec == a.precision:
-                        out = checks[prec]
-                return out
-            res["cpu_baseline"] = cpu_baseline(T1, T2, hip_check)
-            ref = res["cpu_baseline"].pop("_ref_mel", None)
-            if ref is not None and "parity_mode" in res:
-                res["parity_mode"]["hip_vs_oracle_mel_max_abs"] = float((checks["bf16x3"] - ref).abs().max())
-                res["parity_mode"]["tolerance"] = 1e-3
-            if ref is not None:
-                res["hip_vs_oracle_mel_max_abs"] = float((checks[a.precision] - ref).abs().max())
-        if world == 1 and a.workload == "fwd64" and a.train_record and not os.environ.get("EFTS_BENCH_CHILD"):
-            # ---- BASELINE config 3 under the same invocation: the training step at B=32 (fwd + bwd + clip + Adam-amsgrad), 10 steps
-            from efficient_tts_amd.bench_train import measure_train
-            torch.cuda.empty_cache()
-            tr = measure_train(a, 1, 0, dev, WORKLOADS["train32"], steps=10, warmup=3)
-            if not a.no_cpu_baseline:
-                tr["cpu_baseline"] = cpu_train_baseline(T1, T2)
+        def hip_check(Pd, text_c, tl_c, mel_c, sl_c):
+            out = None
+            for prec in ("bf16", "bf16x3"):
+                m2 = build(prec, Pd)
+                with torch.no_grad():
+                    checks[prec] = m2(text_c.to(dev), tl_c.to(dev), mel_c.to(dev), sl_c.to(dev))[4].detach().cpu()
+                if prec == a.precision:
+                    out = checks[prec]
+            return out
+        res["cpu_baseline"] = cpu_baseline(T1, T2, hip_check)
+        ref = res["cpu_baseline"].pop("_ref_mel", None)
+        if ref is not None and "parity_mode" in res:
+            res["parity_mode"]["hip_vs_oracle_mel_max_abs"] = float((checks["bf16x3"] - ref).abs().max())
+            res["parity_mode"]["tolerance"] = 1e-3
+        if ref is not None:
+            res["hip_vs_oracle_mel_max_abs"] = float((checks[a.precision] - ref).abs().max())
+    if a.workload == "fwd64" and a.train_record and not os.environ.get("EFTS_BENCH_CHILD"):
+        # ---- BASELINE configs 3 / 4 under the same invocation, on EVERY rank: the training step at B=32 per GPU (fwd + bwd + clip +
+        # Adam-amsgrad; N > 1: the bucketed RCCL gradient all-reduce overlapped with the backward -> its `dp` record), 10 steps; and
+        # its parity-grade mode (bf16x3) under the same clock
+        from efficient_tts_amd.bench_train import measure_train
+        torch.cuda.empty_cache()
+        tr = measure_train(a, world, rank, dev, WORKLOADS["train32"], steps=10, warmup=3)
+        trp = measure_train(a, world, rank, dev, WORKLOADS["train32"], steps=10, warmup=3, precision="bf16x3") if a.precision == "bf16" and a.parity_mode else None
+        if rank == 0:
+            if trp is not None:
+                tr["parity_mode"] = {k: trp[k] for k in ("value", "ms_per_step", "eager_ms_per_step", "graph_ms_per_step", "dtype", "loss", "tflops", "roofline", "steps", "warmup")}
+                tr["parity_mode"]["note"] = ("bf16x3 operands: the mode the gradient-vs-oracle tests run in (tests/test_gpu_train.py); the bf16 mode's own "
+                                             "gradient error is stated by test_bf16_mode_gradients_report_their_own_error")
+            if world == 1:
+                got = measure_traffic(a, a.precision, "train32") if (a.measure_traffic and a.gpus == 1) else None
+                if got is not None:
+                    tr["roofline"]["traffic"], tr["roofline"]["traffic_source"] = got
+                if not a.no_cpu_baseline:
+                    tr["cpu_baseline"] = cpu_train_baseline(T1, T2)
             res["train32"] = tr
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist

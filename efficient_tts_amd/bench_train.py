@@ -46,12 +46,21 @@ def _rccl_log_lines(limit: int = 12):
     return out or None
 
 
-def measure_train(a, world, rank, dev, wl, steps, warmup):
-    """K timed training steps (barrier + synchronize on both sides, max over ranks) -> the record (rank 0; None elsewhere)"""
+def measure_train(a, world, rank, dev, wl, steps, warmup, precision=None):
+    """K timed training steps (barrier + synchronize on both sides, max over ranks) -> the record (rank 0; None elsewhere).
+
+    One process: the timed steps are hipGraph replays (step_graph.GraphedStep), the eager loop is timed after them.
+    Data parallel (world > 1): (1) self-validation -- nccl backend, two eager steps, bit-exact parameter fingerprint of every rank;
+    (2) K eager steps timed (the bucketed RCCL exchange launched from the engine's hooks, per-bucket events -> `dp`); (3) the same
+    step as ONE hipGraph replay per rank, collectives captured with it, K replays timed, fingerprint compared again.  `value` is the
+    graphed loop's when every rank captured (the ranks agree on that through an all-reduce), else the eager loop's; both are
+    reported."""
     import torch.distributed as dist
     from . import EfficientTTSCNN, ops as P
     from .dist import DistributedEFTS
     from .optim import EftsAdam, WarmupLR
+    from .step_graph import GraphedStep
+    precision = precision or a.precision
     B, T1, T2 = wl["B"], wl["T1"], wl["T2"]
     for kv in getattr(a, "train_set", []):
         from . import train as _tr
@@ -60,7 +69,7 @@ def measure_train(a, world, rank, dev, wl, steps, warmup):
         setattr(_tr, k, int(v))
     torch.manual_seed(0)
     model = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, use_weighted_masking=False, sigma=0.01,
-                            precision=a.precision).to(dev).train()
+                            precision=precision).to(dev).train()
     opt = EftsAdam(model, lr=1e-3, betas=(0.9, 0.99), eps=1e-9, weight_decay=1e-5, amsgrad=True, grad_norm=1.0)
     sch = WarmupLR(opt, warmup_steps=4000)
     ddp = DistributedEFTS(model, algo=getattr(a, "dp_algo", "allreduce"), timing=True) if world > 1 else None
@@ -81,69 +90,100 @@ def measure_train(a, world, rank, dev, wl, steps, warmup):
         sch.step()
         return loss
 
-    # one process: the step as ONE hipGraph replay (step_graph.GraphedStep -- what the trainer runs with `graph_steps: true`): the host
-    # issues a replay in tens of microseconds, so a loaded host no longer sets the step time; data parallel keeps the eager loop
-    # (the bucketed all-reduce is launched from hooks)
-    graphed = None
-    if world == 1 and getattr(a, "train_graph", 1):
-        from .step_graph import GraphedStep
-        graphed = GraphedStep(model, opt, sch)
+    def timed(run, n):
+        """exactly n steps between barrier + synchronize on both sides; seconds, max over ranks"""
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss = run()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, loss
 
-    def gstep():
-        return graphed(text, tl, mel, sl)[0]
+    def fingerprints():
+        fp = _params_fingerprint(model, dev)
+        every = [torch.zeros_like(fp) for _ in range(world)]
+        dist.all_gather(every, fp)
+        return all(bool(torch.equal(e, every[0])) for e in every), every
 
-    selfcheck = None
+    rows = P.Rows(B, T2).rows
+    want_graph = bool(getattr(a, "train_graph", 1))
+    selfcheck, dp_stats, eager_dt, graph_dt, graph_note = None, None, None, None, None
     if world > 1:
-        # ---- self-validation before anything is timed
+        # ---- (1) self-validation before anything is timed
         backend = dist.get_backend()
         assert backend == "nccl", f"data-parallel runs use the RCCL backend ('nccl'), got {backend!r}"
         for _ in range(2):
             step()
         torch.cuda.synchronize()
-        fp = _params_fingerprint(model, dev)
-        every = [torch.zeros_like(fp) for _ in range(world)]
-        dist.all_gather(every, fp)
-        same = all(bool(torch.equal(e, every[0])) for e in every)
+        same, every = fingerprints()
         assert same, "data-parallel replicas diverged after 2 steps: " + str([e.tolist() for e in every])
         selfcheck = dict(backend=backend, world_seen_by_rccl=dist.get_world_size(), steps=2, replicas_bit_identical=same,
                          fingerprint=[int(v) for v in every[0].tolist()])
-    run = gstep if graphed is not None else step
-    for _ in range(max(warmup, 2)):
-        loss = run()
-    torch.cuda.synchronize()
-    rows = P.Rows(B, T2).rows
-    if graphed is None:
-        P.PROFILE, P.PROFILE_TAG = [], (5, rows, 512)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = run()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    eager_ms = None
-    if graphed is not None:
-        # the same step issued eagerly (what the reference's loop does), with the conv launches bracketed by events for the roofline
-        assert graphed.replays >= steps, "the timed steps were not graph replays"
-        P.PROFILE, P.PROFILE_TAG = [], (5, rows, 512)
-        k = max(3, min(steps, 10))
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(k):
+        # ---- (2) the eager loop (what the reference's trainer issues), conv launches bracketed by events for the roofline
+        for _ in range(max(warmup, 2)):
             step()
-        torch.cuda.synchronize()
-        eager_ms = (time.perf_counter() - t1) / k * 1e3
+        P.PROFILE, P.PROFILE_TAG = [], (5, rows, 512)
+        eager_dt, loss = timed(step, steps)
+        durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in P.PROFILE if tag == (5, rows, 512)]
+        P.PROFILE, P.PROFILE_TAG = None, None
+        dp_stats = ddp.reducer.stats()
+        # ---- (3) the step as one hipGraph replay per rank, collectives inside
+        if want_graph:
+            graphed = GraphedStep(ddp, opt, sch)
+            ok = 1
+            try:
+                for _ in range(max(warmup, 3)):               # eager, capture, replays
+                    loss = graphed(text, tl, mel, sl)[0]
+                torch.cuda.synchronize()
+                ok = int(graphed.replays >= 1)
+            except Exception as exc:                           # noqa: BLE001 -- reported, the eager measurement stands
+                ok, graph_note = 0, f"capture failed on rank {rank}: {exc}"[:300]
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # every rank replays, or none does
+            if int(flag.item()) == 1:
+                r0 = graphed.replays
+                graph_dt, loss = timed(lambda: graphed(text, tl, mel, sl)[0], steps)
+                assert graphed.replays - r0 == steps, "the timed steps were not graph replays"
+                same2, every2 = fingerprints()
+                assert same2, "data-parallel replicas diverged under graph replays: " + str([e.tolist() for e in every2])
+                selfcheck["replicas_bit_identical_after_graph_replays"] = same2
+            elif graph_note is None:
+                graph_note = "capture failed on another rank; eager loop timed"
+        dt = graph_dt if graph_dt is not None else eager_dt
+        issue = "one hipGraph replay per step and rank, bucket collectives captured (step_graph.GraphedStep)" if graph_dt is not None else "eager launches"
+    else:
+        graphed = GraphedStep(model, opt, sch) if want_graph else None
+
+        def gstep():
+            return graphed(text, tl, mel, sl)[0]
+        run = gstep if graphed is not None else step
+        for _ in range(max(warmup, 2)):
+            loss = run()
+        if graphed is None:
+            P.PROFILE, P.PROFILE_TAG = [], (5, rows, 512)
+        dt, loss = timed(run, steps)
+        if graphed is not None:
+            # the same step issued eagerly (what the reference's loop does), with the conv launches bracketed by events for the roofline
+            assert graphed.replays >= steps, "the timed steps were not graph replays"
+            graph_dt = dt
+            P.PROFILE, P.PROFILE_TAG = [], (5, rows, 512)
+            eager_dt, _ = timed(step, max(3, min(steps, 10)))
+            eager_dt = eager_dt / max(3, min(steps, 10)) * steps
+        durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in P.PROFILE if tag == (5, rows, 512)]
+        P.PROFILE, P.PROFILE_TAG = None, None
+        issue = "one hipGraph replay per step (step_graph.GraphedStep)" if graphed is not None else "eager launches"
     lv = float(loss)
     assert lv == lv, "NaN loss"
-    durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in P.PROFILE if tag == (5, rows, 512)]
-    P.PROFILE, P.PROFILE_TAG = None, None
     avg = sum(durs) / max(len(durs), 1)
     conv_flop = 2.0 * B * T2 * 512 * 512 * 5
     from . import train as _tr
@@ -163,22 +203,25 @@ def measure_train(a, world, rank, dev, wl, steps, warmup):
     res = dict(metric="mel-frames/sec (EFTS-CNN training step, batch 32/GPU, 80-mel LJSpeech shape)", value=frames / dt,
                unit="mel-frames/s", n_gpus=world, steps=steps, warmup=warmup, ms_per_step=dt / steps * 1e3,
                higher_is_better=True, scaling="weak", vs_baseline=None,
-               dtype="bf16" if a.precision == "bf16" else "bf16x3 (split-bf16 MFMA, fp32-class)", data="synthetic",
-               config=dict(workload=wl["desc"], batch_per_gpu=B, phoneme_len=T1, mel_len=T2, precision=a.precision,
+               dtype="bf16" if precision == "bf16" else "bf16x3 (split-bf16 MFMA, fp32-class)", data="synthetic",
+               config=dict(workload=wl["desc"], batch_per_gpu=B, phoneme_len=T1, mel_len=T2, precision=precision,
                            parallelism=f"dp{world}", optimizer="Adam-amsgrad fused, clip 1.0, WarmupLR 4000",
-                           allreduce="RCCL, 3 buckets overlapped with backward" if world > 1 else "none",
-                           step_issue="one hipGraph replay per step (step_graph.GraphedStep)" if graphed is not None else "eager launches"),
-               eager_ms_per_step=eager_ms, per_gpu=frames / dt / world, tflops=TRAIN_FLOP_PER_ITEM * B * world * steps / dt / 1e12, loss=lv,
+                           allreduce="RCCL, 3 buckets overlapped with backward" if world > 1 else "none", step_issue=issue),
+               eager_ms_per_step=None if eager_dt is None else eager_dt / steps * 1e3,
+               graph_ms_per_step=None if graph_dt is None else graph_dt / steps * 1e3,
+               per_gpu=frames / dt / world, tflops=TRAIN_FLOP_PER_ITEM * B * world * steps / dt / 1e12, loss=lv,
                roofline=dict(bound="mfma", kernel=f"{kname}; fwd + dgrad launches, timed with events in the eager loop while the text-length stream runs beside them",
                              achieved=conv_flop / avg / 1e12 if avg else None, peak=2500.0, unit="TFLOP/s",
                              frac=conv_flop / avg / 1e12 / 2500.0 if avg else None, traffic=None,
                              avg_launch_us=avg * 1e6, launches_measured=len(durs)))
+    if graph_note:
+        res["config"]["graph_note"] = graph_note
     if ddp is not None:
-        # the last timed step's communication: one record that explains the scaling number (backend, ranks, algorithm,
+        # the last eager step's communication: one record that explains the scaling number (backend, ranks, algorithm,
         # bytes and time per bucket, how much of it the backward did NOT hide)
         res["dp"] = dict(backend=dist.get_backend(), ranks=dist.get_world_size(), grad_mb=ddp.engine.numel * 4 / 1e6,
                          nccl_env={k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))},
-                         selfcheck=selfcheck, rccl_log=_rccl_log_lines(), **ddp.reducer.stats())
+                         selfcheck=selfcheck, rccl_log=_rccl_log_lines(), **(dp_stats or {}))
     return res
 
 

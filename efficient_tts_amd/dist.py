@@ -47,7 +47,8 @@ class BucketReducer:
         self.pending = False              # buckets handed over since the last finish()
 
     def _event(self, name: str, stream=None) -> None:
-        if self.timing and self.comm_stream is not None:
+        # (not while the step is being captured as a hipGraph: timing events are an eager-loop probe)
+        if self.timing and self.comm_stream is not None and not torch.cuda.is_current_stream_capturing():
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(stream if stream is not None else torch.cuda.current_stream(self.flat.device))
             self.events[name] = ev
@@ -57,20 +58,27 @@ class BucketReducer:
         self._event(name)
 
     def _collective(self, i: int) -> None:
+        """bucket i's exchange, enqueued on the CURRENT stream (the communication stream on a GPU).  On a GPU the collectives are
+        issued as stream-ordered SYNCHRONOUS ops (async_op=False): the NCCL backend then enqueues them on the stream they are called
+        on, so the communication stream stays a plain fork of the compute stream -- the only dependency shape ROCm 7.2 captures safely
+        (a forked stream waiting for an event of ANOTHER forked stream -- what the backend's internal stream of an async op is --
+        crashes hipStreamEndCapture: tools/gpu_probe_capture4.py) -- and the whole step, collectives included, can be one hipGraph.
+        Neither the host nor the compute stream waits: only the communication stream is ordered behind the collective."""
         view = self.flat[self.starts[i]:self.ends[i]]
+        on_gpu = self.comm_stream is not None
         if self.algo == "allreduce":
-            w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            if self.comm_stream is not None:
-                w.wait()                                          # the COMMUNICATION stream waits (the host and the compute stream do not)
-            else:
+            w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=not on_gpu)
+            if not on_gpu:
                 self.works.append(w)
             return
         pad, shard, n = self.pad[i], self.shard[i], view.numel()
         pad[:n].copy_(view)                                       # the tail beyond n stays zero
-        w = dist.reduce_scatter_tensor(shard, pad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        w.wait()                                                  # orders the stream (NCCL) / blocks the host (gloo)
-        w = dist.all_gather_into_tensor(pad, shard, group=self.group, async_op=True)
-        w.wait()
+        if on_gpu:
+            dist.reduce_scatter_tensor(shard, pad, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_gather_into_tensor(pad, shard, group=self.group)
+        else:
+            dist.reduce_scatter_tensor(shard, pad, op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
+            dist.all_gather_into_tensor(pad, shard, group=self.group, async_op=True).wait()
         view.copy_(pad[:n])
 
     def reduce(self, i: int) -> None:
@@ -118,7 +126,9 @@ class BucketReducer:
 class DistributedEFTS(torch.nn.Module):
     """DDP stand-in with the attributes the reference trainer uses (`.module`, call-through)."""
 
-    def __init__(self, module, group=None, algo: str = "allreduce", timing: bool = False):
+    def __init__(self, module, group=None, algo: str = "allreduce", timing: bool = False, force_reducer: bool = False):
+        """force_reducer: run the bucketed exchange even in a group of ONE rank (tests: the RCCL code path on a single GPU; a
+        one-rank sum is the identity, so the step must equal the wrapper-free one bit for bit)"""
         super().__init__()
         self.module = module
         self.group = group
@@ -127,7 +137,7 @@ class DistributedEFTS(torch.nn.Module):
         self.engine = engine_of(module)
         self.engine.bound.add("DistributedEFTS")
         self.reducer: Optional[BucketReducer] = None
-        if self.world > 1:
+        if self.world > 1 or (force_reducer and dist.is_initialized()):
             self.reducer = BucketReducer(self.engine.flat, self.engine.bucket_ends, group, algo=algo, timing=timing)
             self.engine.bucket_hook = self.reducer.reduce
             self.engine.join_reduce = self.reducer.finish

@@ -226,6 +226,7 @@ class EfficientTTSCNN(torch.nn.Module):
         self._folded_gen = -1               # the repack that last wrote the training engine's folded fp32 copies
         self._ws: Dict[Tuple, _Workspace] = {}
         self._ws_infer: Dict[Tuple, _Workspace] = {}
+        self._ws_train: Dict[Tuple, _Workspace] = {}
 
     # ------------------------------------------------------------------ weight norm (efficient_tts.py:400-418)
     def remove_weight_norm(self):
@@ -339,17 +340,28 @@ class EfficientTTSCNN(torch.nn.Module):
         V, C, K = table.shape[0], self.n_channels, self.k_size
         dev = table.device
         rsv = Rows(1, V)
-        plane = Plane.for_rows(rsv, C, self.split, dev)
+        # ONE table (and one staging plane) per (device, geometry), rebuilt IN PLACE like the packed planes: captured graphs bake the
+        # table's address into their efts_embed_conv launch, so a fresh allocation per repack would leave them reading a freed or
+        # stale table after any weight update; the stream orders the rebuild in front of the next replay
+        geo = (dev, K, V, C, self.split)
+        if getattr(self, "_te0_geo", None) != geo:
+            object.__setattr__(self, "_te0_geo", geo)
+            object.__setattr__(self, "_te0_tab", torch.empty(K, V, C, dtype=torch.float32, device=dev))
+            object.__setattr__(self, "_te0_plane", Plane.for_rows(rsv, C, self.split, dev))
+            object.__setattr__(self, "_te0_ids", torch.arange(V, device=dev)[None])
+        tab, plane = self._te0_tab, self._te0_plane
         with O.stream_scope():
-            O.embed(torch.arange(V, device=dev)[None], table, None, plane, rsv)
-            tab = torch.empty(K, V, C, dtype=torch.float32, device=dev)
+            O.embed(self._te0_ids, table, None, plane, rsv)
             w = pk["text_encoder.0"]
             for k in range(K):
                 O.gemm(a=plane, b_ptr=w.ptr + k * w.tap_stride, ldb=w.ld, m=V, n=C, out_f32_ptr=tab[k].data_ptr(), ldo=C, tiling=L.TILING_GENERIC)
-        object.__setattr__(self, "_te0_tab", tab)
         object.__setattr__(self, "_te0_gen", self._packed_gen)
-        object.__setattr__(self, "_te0_plane", plane)               # (kept alive: the launches above may still be in flight)
         return tab
+
+    def _te0_ptr(self) -> int:
+        """address of the tap table (part of every graph tag: a new table means a new capture)"""
+        tab = getattr(self, "_te0_tab", None)
+        return 0 if (tab is None or not self.embed_conv) else tab.data_ptr()
 
     def _embed_te0(self, ws, pk, text, rs1: Rows, lens_i32: Optional[torch.Tensor], tab: torch.Tensor):
         """embedding + text-encoder layer 0 in one gather launch -> (fp32 stream, operand plane) of layer 0's output"""
@@ -372,7 +384,15 @@ class EfficientTTSCNN(torch.nn.Module):
         """The buffers of one shape.  Bounded LRU pools (each entry holds full activations): 4 teacher-forced / training
         shapes, 64 free-running ones (one or a few utterances, a few MB each).  `pin`: workspaces of the call in progress,
         never evicted -- their buffers are about to be read (the value projection of phase 1) or captured."""
-        pool, cap = (self._ws_infer, 64) if key[0] in ("infb", "infb2", "inf", "inf2") else (self._ws, 4)
+        if key[0] in ("infb", "infb2", "inf", "inf2"):
+            pool, cap = self._ws_infer, 64
+        elif key[0] == "train":
+            # training shapes have a pool of their own: an evaluation pass over more than four shapes must not evict the workspace a
+            # captured training step (step_graph.GraphedStep) points into -- that forces a recapture and keeps two multi-GB
+            # workspaces alive at once (ADVICE r3)
+            pool, cap = self._ws_train, 4
+        else:
+            pool, cap = self._ws, 4
         ws = pool.pop(key, None)
         if ws is None:
             for old in list(pool):
@@ -606,7 +626,7 @@ class EfficientTTSCNN(torch.nn.Module):
         key = ("fwd", tuple(text.shape), tuple(speech.shape), text.dtype, speech.dtype, text_lengths.dtype, speech_lengths.dtype)
         ws = self._workspace(("fwd", text.shape[0], text.shape[1], speech.shape[1]), dev)
         # the graph is valid while the buffers its launches point at live: this workspace, the packed planes, the parameters
-        tag = (ws.serial, self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.side_stream, self.RESCONV_MIN_ROWS, self.fuse_soft_index, self.fuse_prenet, self.fuse_align, self.fuse_expand, self.merge_text, self.share_cus, self.ride_duration, self.embed_conv)
+        tag = (ws.serial, self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.side_stream, self.RESCONV_MIN_ROWS, self.fuse_soft_index, self.fuse_prenet, self.fuse_align, self.fuse_expand, self.merge_text, self.share_cus, self.ride_duration, self.embed_conv, self._te0_ptr())
 
         def body(t, tl, sp, sl):
             (_, stats, imv, ralpha, mel_pred, _), _ = self._forward_impl(t, tl, sp, sl)
@@ -642,10 +662,10 @@ class EfficientTTSCNN(torch.nn.Module):
         # The text side (masks, embed, 5 convs, K/V) and the duration predictor do not depend on the mel side (prenet, 3 convs).
         main = torch.cuda.current_stream(dev)
         side = self._side_stream(dev)
+        if not masks_done:
+            O.row_masks(ml, rs2, gap2, len2)                                      # :139 (in FRONT of the fork: the prenet on the side stream reads gap2)
         side.wait_stream(main)
         vt = None if self._fused_expand(T1) else ws.raw_plane("vt", B * C, T1, 2)
-        if not masks_done:
-            O.row_masks(ml, rs2, gap2, len2)                                      # :139
         dec_rider = dec_after = None
         nt, nm = len(self.text_encoder.layers), len(self.mel_encoder.layers)
         merged = self.merge_text and self._on_resconv(rs2) and nt >= 1 and nm >= 1
@@ -779,7 +799,7 @@ class EfficientTTSCNN(torch.nn.Module):
                    out_batch_stride=T2 * T1)
             O.attn_soft_index(scores, T1, tl, ml, sidx, alpha, B, T1, T2)         # :391-398, :168, :312
         e, lde = ws.tensor("e", (B, T1)), ws.tensor("lde", (B, T1))
-        if self.fuse_align and (2 * roundup(T2, 4) + T1) * 4 <= 160 * 1024:
+        if self.fuse_align and O.imv_align_fits(T1, T2):
             O.imv_align(sidx, tl, ml, float(self.sigma_e), float(self.duration_offset), self.delta_e_method_1, imv, e, lde, B, T1, T2)   # :314-345, :203-216
         else:
             O.imv_scan(sidx, tl, ml, imv, B, T2)                                  # :314-323
@@ -949,7 +969,7 @@ class EfficientTTSCNN(torch.nn.Module):
             T1b = roundup(T1, self.T1_BUCKET) if graphs else T1
             pk = self._weights()
             self._te0_table(pk)                               # (built outside the graphs, like the packed planes)
-            wsig = (self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.RESCONV_MIN_ROWS, self.fuse_expand, self.small_m, self.SMALL_M_ROWS, self.embed_conv)
+            wsig = (self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.RESCONV_MIN_ROWS, self.fuse_expand, self.small_m, self.SMALL_M_ROWS, self.embed_conv, self._te0_ptr())
             ws = self._workspace(("infb", B, T1b), dev)
             if graphs:
                 def phase1(t, l):
@@ -975,7 +995,9 @@ class EfficientTTSCNN(torch.nn.Module):
                 mel, ralpha = self._infer_cache.run(("mel", B, T1b, T2b), (ws.serial, ws2.serial, wsig), (), phase2, keepalive=(ws, ws2),
                                                     refs=(e, tl, ml), clone=not trim)
                 if trim:                                       # (the trimmed copies are the fresh tensors the caller gets)
-                    mel, ralpha = mel[:, :t2].contiguous(), ralpha[:, :T1, :t2].contiguous()
+                    # .clone(), not .contiguous(): at B == 1 (or t2 == T2b) the slice of the graph's static output is already
+                    # contiguous and .contiguous() would hand the caller a VIEW the next call of this bucket overwrites
+                    mel, ralpha = mel[:, :t2].clone(), ralpha[:, :T1, :t2].clone()
                 if want_lengths:
                     ml = ml.to(torch.int64)                    # (a new tensor: `ml` is the text graph's static output)
             else:

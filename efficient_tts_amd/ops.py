@@ -357,6 +357,12 @@ def reconst_alpha(e, tl, ml, sigma, alpha_out, plane: Optional[Plane], B, T1, T2
                                         B, T1, T2, T2p, _stream()), "efts_reconst_alpha")
 
 
+def imv_align_fits(T1: int, T2: int) -> bool:
+    """efts_imv_align keeps 2 * roundup(T2, 4) + kper + 1 floats in LDS (kper <= T1 keys per workgroup): a sufficient condition for its
+    160 KiB limit, so that the callers take the three-kernel chain instead of an EFTS_ESHAPE at the boundary"""
+    return (2 * roundup(T2, 4) + T1 + 1) * 4 <= 160 * 1024
+
+
 def imv_align(soft_idx, tl, ml, sigma_e, offset, method1: bool, imv, e, lde, B, T1, T2) -> None:
     """imv_scan + aligned_positions + duration_target in one launch (efts_imv_align)"""
     L.check(L.load().efts_imv_align(soft_idx.data_ptr(), tl.data_ptr(), ml.data_ptr(), sigma_e, offset, int(method1), imv.data_ptr(),

@@ -8,8 +8,14 @@ front of every replay (efts_store_words): the learning rate and Adam's two bias 
 word of the duration predictor's Dropout seeds (`drop_seed_add` of efts_layernorm_rows / _dot / _bwd).  Parameters, optimizer
 state and every result are bit-identical to the eager loop's (tests/test_gpu_train.py).
 
-Not captured (the step then runs eagerly, same results): data-parallel wrappers (the bucketed RCCL all-reduce is launched from
-hooks), conv / prenet Dropout (dropout_rate > 0: their seeds are by-value launch arguments), optimizers other than EftsAdam."""
+Data parallel (round 4): `GraphedStep(DistributedEFTS(model), ...)` captures the three bucket collectives too.  The reducer issues
+them as stream-ordered synchronous ops on its communication stream (dist.py), which is a plain fork of the capturing stream joined
+back in front of the optimizer launch -- the only dependency shape ROCm 7.2's capture handles (tools/gpu_probe_capture4.py) -- so
+a replay contains forward, backward, the RCCL exchanges overlapped with the backward, clip and Adam, and an 8-process host issues
+one launch per step instead of ~190.
+
+Not captured (the step then runs eagerly, same results): conv / prenet Dropout (dropout_rate > 0: their seeds are by-value launch
+arguments), optimizers other than EftsAdam."""
 from __future__ import annotations
 
 import logging
@@ -26,7 +32,12 @@ from .optim import EftsAdam
 class GraphedStep:
     """step = GraphedStep(model, optimizer, scheduler); loss, stats = step(text, text_lengths, speech, speech_lengths)"""
 
-    def __init__(self, model, optimizer, scheduler=None, grad_scale: float = 1.0, capacity: int = 4):
+    def __init__(self, model, optimizer, scheduler=None, grad_scale: float = None, capacity: int = 4):
+        self.ddp = model if (hasattr(model, "module") and hasattr(model, "reducer")) else None      # dist.DistributedEFTS
+        if self.ddp is not None:
+            model = self.ddp.module
+        if grad_scale is None:
+            grad_scale = self.ddp.grad_scale if self.ddp is not None else 1.0
         self.model, self.opt, self.sch, self.grad_scale, self.capacity = model, optimizer, scheduler, float(grad_scale), capacity
         self.entries: "OrderedDict[tuple, dict]" = OrderedDict()
         self.words = None
@@ -49,8 +60,9 @@ class GraphedStep:
     def _tag(self, ws, eng):
         """what a captured step is valid for: the buffers its launches point at and every argument they carry by value"""
         m, g = self.model, self.opt.param_groups[0]
+        red = self.ddp.reducer if self.ddp is not None else None
         return (ws.serial, id(eng), getattr(m, "_ptr_sig", None), float(self.opt.grad_norm), self.grad_scale, tuple(g["betas"]), float(g["eps"]),
-                float(g["weight_decay"]), bool(m.training))
+                float(g["weight_decay"]), bool(m.training), id(red), None if red is None else red.algo, eng.bucket_hook is not None)
 
     def _refresh(self, eng) -> None:
         """the words of the step about to run: Adam's scalars for step t + 1 and the Dropout step word of call dropout_calls + 1"""
@@ -71,11 +83,12 @@ class GraphedStep:
         self.entries.move_to_end(key)
         ent["calls"] += 1
         eng = engine_of(m)
-        ws = m._workspace(("train", text.shape[0], text.shape[1], speech.shape[1]), dev)
+        pinned = tuple(e["keep"][0] for e in self.entries.values() if e.get("keep"))
+        ws = m._workspace(("train", text.shape[0], text.shape[1], speech.shape[1]), dev, pin=pinned)
         tag = self._tag(ws, eng)
         if ent["graph"] is not None and ent["tag"] != tag:          # the buffers the launches point at were re-allocated, or a by-value
                                                                      # hyper-parameter of the captured launches changed
-            ent.update(graph=None, calls=2)
+            ent.update(graph=None, calls=2, keep=None)               # (the old workspace is released BEFORE a new capture allocates)
         if ent["calls"] == 1 or ent.get("eager_only"):
             return self._eager(text, text_lengths, speech, speech_lengths)
         with O.stream_scope():
@@ -92,6 +105,8 @@ class GraphedStep:
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         with O.stream_scope():
                             out3, _ = eng.forward_backward(*ent["static"])
+                            if eng.join_reduce is not None:           # data parallel: the optimizer waits for the last bucket
+                                eng.join_reduce()
                             self.opt.launch(self.grad_scale, hyper_ptr=self.words.data_ptr())
                 except Exception as exc:                              # noqa: BLE001
                     logging.warning("hipGraph capture of the training step failed (%s): this shape stays on eager launches", exc)

@@ -422,7 +422,7 @@ class TrainEngine:
         sidx, imv = ws.tensor("Tsidx", (B, T2)), ws.tensor("Timv", (B, T2))
         O.attn_soft_index(scores, T1, tl, ml, sidx, None, B, T1, T2)
         e, lde = ws.tensor("Te", (B, T1)), ws.tensor("Tlde", (B, T1))
-        if m.fuse_align and (2 * O.roundup(T2, 4)) * 4 <= 150 * 1024:
+        if m.fuse_align and O.imv_align_fits(T1, T2):
             O.imv_align(sidx, tl, ml, float(m.sigma_e), float(m.duration_offset), m.delta_e_method_1, imv, e, lde, B, T1, T2)
         else:
             O.imv_scan(sidx, tl, ml, imv, B, T2)

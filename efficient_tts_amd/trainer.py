@@ -148,13 +148,15 @@ class EfficientTTSTrainer:
 
     # ------------------------------------------------------------------------------------------ one optimisation step
     def _graphed_step(self):
-        """the GraphedStep of this run, or None: off unless the YAML asks for it, and only for the fused optimizer on one process"""
-        if not self.config.get("graph_steps", False) or hasattr(self.model, "finish_reduce") or not hasattr(self.optimizer, "launch"):
+        """the GraphedStep of this run, or None: off unless the YAML asks for it, and only for the fused optimizer.  Under data
+        parallelism the wrapper itself is handed over: the bucket collectives are captured with the step (step_graph.py)"""
+        if not self.config.get("graph_steps", False) or not hasattr(self.optimizer, "launch"):
             return None
         if getattr(self, "_graph", None) is None:
             from .step_graph import GraphedStep
-            self._graph = GraphedStep(self._net, self.optimizer, self.scheduler, grad_scale=getattr(self.model, "grad_scale", 1.0),
-                                      capacity=int(self.config.get("graph_shapes", 4)))
+            dp = hasattr(self.model, "finish_reduce")
+            self._graph = GraphedStep(self.model if dp else self._net, self.optimizer, self.scheduler,
+                                      grad_scale=getattr(self.model, "grad_scale", 1.0), capacity=int(self.config.get("graph_shapes", 4)))
         return self._graph
 
     def _train_step(self, batch) -> None:

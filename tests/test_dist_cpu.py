@@ -134,3 +134,24 @@ def test_dp_selfcheck_fingerprint_and_rccl_log_parsing(tmp_path, monkeypatch):
     assert lines and any("Algo 1 proto 2" in ln for ln in lines) and not any("unrelated" in ln for ln in lines)
     monkeypatch.delenv("NCCL_DEBUG_FILE")
     assert _rccl_log_lines() is None
+
+
+def test_bench_launches_its_own_ranks_and_refuses_fewer():
+    """`python bench.py --gpus N` without a launcher must start N ranks itself (it used to run ONE rank silently and
+    print n_gpus 1).  The `rendezvous` workload is the launch path only: every rank joins the group (gloo here, nccl on a GPU
+    box), one all-reduce counts them.  A launcher that started a different number of ranks than --gpus asks for is refused."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "rendezvous"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["self_launched"] is True
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "rendezvous"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)

@@ -1,0 +1,143 @@
+"""GPU (-m gpu): the data-parallel path on the RCCL backend itself.
+
+No multi-GPU box is in reach of the test run, so the `nccl` process group is opened with ONE rank on the one GPU: every
+`dist.all_reduce` / `reduce_scatter_tensor` / `all_gather_into_tensor` of efficient_tts_amd/dist.py then goes through RCCL (a
+one-rank sum is the identity), on the reducer's communication stream, from the training engine's bucket hooks -- the code that
+runs under `torch.distributed.run` on an 8-GPU node (reference: nntts/bin/train.py:53-68, :210-216), including the step captured
+as one hipGraph with the collectives inside (step_graph.GraphedStep).  The 2-rank arithmetic (mean of means, lock-step replicas)
+is covered over gloo in tests/test_gpu_train.py and tests/test_dist_cpu.py."""
+import json
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, port, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from efficient_tts_amd import EfficientTTSCNN
+    from efficient_tts_amd.dist import BucketReducer, DistributedEFTS
+    from efficient_tts_amd.optim import EftsAdam
+    from efficient_tts_amd.step_graph import GraphedStep
+    rec = dict(backend=dist.get_backend(), world=dist.get_world_size())
+
+    # ---- the reducer alone: a one-rank exchange is the identity, bit for bit, for both algorithms; its events make a record
+    torch.manual_seed(0)
+    for algo in ("allreduce", "rs_ag"):
+        flat = torch.randn(1000003, device=dev)
+        want = flat.clone()
+        red = BucketReducer(flat, [300001, 700000, 1000003], algo=algo, timing=True)
+        red.mark("backward_start")
+        for i in range(3):
+            flat[red.starts[i]:red.ends[i]].mul_(1.0)            # (compute-stream work in front of the hand-over)
+            red.reduce(i)
+        red.finish()
+        torch.cuda.synchronize()
+        assert torch.equal(flat, want), algo
+        st = red.stats()
+        assert st["algo"] == algo and st["world"] == 1 and len(st["bucket_ms"]) == 3 and all(v >= 0 for v in st["bucket_ms"]), st
+        assert st["exposed_ms"] >= 0 and st["backward_ms"] >= 0 and st["first_bucket_after_ms"] >= 0, st
+        rec[f"reducer_{algo}"] = st
+
+    # ---- the training step through DistributedEFTS with the reducer forced on, against the wrapper-free step from the same state
+    B, T1, T2 = 3, 40, 130
+    gen = torch.Generator().manual_seed(7)
+    batch = (torch.randint(0, 76, (B, T1), generator=gen).to(dev), torch.tensor([40, 33, 21]).to(dev),
+             torch.randn(B, T2, 80, generator=gen).to(dev), torch.tensor([130, 90, 64]).to(dev))
+    for algo in ("allreduce", "rs_ag"):
+        torch.manual_seed(1)
+        m = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, sigma=0.01, precision="bf16").to(dev).train()
+        opt = EftsAdam(m, lr=1e-4, betas=(0.9, 0.99), eps=1e-9, weight_decay=1e-5, amsgrad=True, grad_norm=1.0)
+        ddp = DistributedEFTS(m, algo=algo, timing=True, force_reducer=True)
+        assert ddp.reducer is not None and ddp.grad_scale == 1.0
+        eng = ddp.engine
+        hooks = (eng.bucket_hook, eng.join_reduce, eng.mark)
+        assert all(h is not None for h in hooks)
+
+        def one_step(net):
+            loss, stats, *_ = net(text=batch[0], text_lengths=batch[1], speech=batch[2], speech_lengths=batch[3])
+            opt.zero_grad()
+            loss.backward()
+            if net is ddp:
+                ddp.finish_reduce()
+            opt.step(grad_scale=1.0)
+            return float(loss)
+
+        one_step(ddp)                                             # warm-up (workspaces, plans)
+        state = (opt.flat_p.clone(), opt.m.clone(), opt.v.clone(), opt.vmax.clone(), opt.t, m.dropout_calls)
+
+        def restore():
+            opt.flat_p.copy_(state[0]); opt.m.copy_(state[1]); opt.v.copy_(state[2]); opt.vmax.copy_(state[3])
+            opt.t, m.dropout_calls, m._packed_sig = state[4], state[5], None
+
+        l_dp = one_step(ddp)
+        torch.cuda.synchronize()
+        st = ddp.reducer.stats()
+        assert len(st["bucket_ms"]) == 3 and abs(sum(st["bucket_mb"]) - 82.35) < 0.01 and st["world"] == 1, st
+        g_dp, p_dp = eng.flat.clone(), opt.flat_p.clone()
+        restore()
+        eng.bucket_hook, eng.join_reduce, eng.mark = None, None, None       # the wrapper-free step
+        l_pl = one_step(m)
+        g_pl, p_pl = eng.flat.clone(), opt.flat_p.clone()
+        eng.bucket_hook, eng.join_reduce, eng.mark = hooks
+        # (two runs of the SAME eager step differ by ~2e-8 in the gradients: float atomics in the backward; see
+        #  test_graphed_training_step_equals_the_eager_loop)
+        assert l_dp == l_pl, (l_dp, l_pl)
+        assert float((g_dp - g_pl).double().norm()) <= 1e-6 * float(g_pl.double().norm())
+        d = (p_dp - p_pl).abs()
+        assert float(d.max()) <= 2.05e-4 and float((d <= 1e-7).float().mean()) >= 0.999
+        rec[f"step_{algo}"] = dict(loss=l_dp, stats=st)
+
+        # ---- the same step as ONE hipGraph replay, collectives captured with it
+        step = GraphedStep(ddp, opt, None)
+        assert step.grad_scale == 1.0 and step.model is m
+        restore()
+        step(*batch)                                              # first call of the shape: eager
+        step(*batch)                                              # capture + first replay
+        ent = next(iter(step.entries.values()))
+        assert ent["graph"] is not None and not ent.get("eager_only"), "the data-parallel step was not captured"
+        assert step.replays == 1
+        for _ in range(2):
+            st0 = (opt.flat_p.clone(), opt.m.clone(), opt.v.clone(), opt.vmax.clone(), opt.t, m.dropout_calls)
+
+            def back():
+                opt.flat_p.copy_(st0[0]); opt.m.copy_(st0[1]); opt.v.copy_(st0[2]); opt.vmax.copy_(st0[3])
+                opt.t, m.dropout_calls, m._packed_sig = st0[4], st0[5], None
+            le, _ = step._eager(*batch)
+            ge, pe = eng.flat.clone(), opt.flat_p.clone()
+            back()
+            n0 = step.replays
+            lg, _ = step(*batch)
+            assert step.replays == n0 + 1
+            gg, pg = eng.flat.clone(), opt.flat_p.clone()
+            assert float(le) == float(lg)
+            assert float((ge - gg).double().norm()) <= 1e-6 * float(ge.double().norm())
+            d = (pe - pg).abs()
+            assert float(d.max()) <= 2.05e-4 and float((d <= 1e-7).float().mean()) >= 0.999
+        rec[f"graph_{algo}"] = dict(replays=step.replays)
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+    with open(out, "w") as f:
+        json.dump(rec, f)
+
+
+def test_rccl_one_rank_group_runs_the_bucketed_exchange_eager_and_captured(tmp_path):
+    """BucketReducer on the `nccl` (= RCCL) backend, both algorithms: identity exchange bit for bit, stats() record, the training
+    step through the forced reducer == the wrapper-free step, and GraphedStep over the wrapper == the eager loop."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "rccl1.json")
+    mp.spawn(_worker, args=(port, out), nprocs=1, join=True)
+    rec = json.load(open(out))
+    assert rec["backend"] == "nccl" and rec["world"] == 1
+    for algo in ("allreduce", "rs_ag"):
+        assert rec[f"graph_{algo}"]["replays"] >= 3 and len(rec[f"step_{algo}"]["stats"]["bucket_ms"]) == 3

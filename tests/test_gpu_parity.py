@@ -571,3 +571,81 @@ def test_small_m_tiling_vs_fp64_and_the_ring_kernels(split, taps, cin, cout, B, 
     with pytest.raises(ValueError):
         P.gemm(a=a, b_ptr=pw.ptr, ldb=pw.ld, b_tap_stride=pw.tap_stride, taps=taps, m=rs.rows, n=cout - 8, out_f32_ptr=out.ptr, ldo=cout,
                tiling=L.TILING_SMALLM)
+
+
+def test_graphs_follow_weight_updates():
+    """a captured forward / inference graph bakes the address of text-encoder layer 0's tap table
+    (efts_embed_conv) into its launches.  After a weight change on a WARM model -- an optimizer step, load_state_dict -- the next
+    plain call must give what a graph-free model gives with the new weights (the table is rebuilt in place, and its address is
+    part of the graph tags), for the teacher-forced forward and for inference()."""
+    from efficient_tts_amd import EfficientTTSCNN
+    dev = _dev()
+    torch.manual_seed(11)
+    m = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, sigma=0.01).to(dev).eval()
+    assert m.embed_conv
+    m.graph_policy = "always"
+    with torch.no_grad():
+        m.duration_predictor.linear.bias.fill_(1.5)
+    B, T1, T2 = 2, 40, 130
+    gen = torch.Generator().manual_seed(5)
+    text = torch.randint(0, 76, (B, T1), generator=gen).to(dev)
+    mel = torch.randn(B, T2, 80, generator=gen).to(dev)
+    tl, sl = torch.tensor([40, 33]).to(dev), torch.tensor([130, 77]).to(dev)
+    one = text[:1, :37].contiguous()
+    with torch.no_grad():
+        for _ in range(3):                                     # eager, capture, replay
+            m(text, tl, mel, sl)
+            m.inference(one)
+        assert next(iter(m._graph_cache.entries.values())).graph is not None
+        tab0 = m._te0_ptr()
+        for rnd in range(2):                                   # two rounds of updates: the table must be rebuilt, not re-allocated
+            for p in (m.text_embedding_table.weight, m.text_encoder.layers[0].conv[0].weight_v, m.decoder.layers[2].conv[0].bias):
+                p.add_(0.05 * torch.randn_like(p))
+            got = m(text, tl, mel, sl)
+            got_inf = m.inference(one)
+            assert m._te0_ptr() == tab0
+            m.graphs = False
+            ref = m(text, tl, mel, sl)
+            ref_inf = m.inference(one)
+            m.graphs = True
+            assert float(got[0]) == float(ref[0]), rnd
+            assert torch.equal(got[4], ref[4]) and torch.equal(got[2], ref[2]), rnd
+            assert got_inf[0].shape == ref_inf[0].shape and float((got_inf[0] - ref_inf[0]).abs().max()) <= 2e-4, rnd
+
+
+def test_inference_results_survive_later_calls_of_the_same_bucket(golden_dir, model):
+    """at B = 1 the trimmed slice of phase 2's static output is already contiguous, so `.contiguous()` handed
+    the caller a VIEW that the next utterance of the same (T1, T2) bucket overwrote.  Two DIFFERENT utterances that land in one
+    bucket: the tensors of the first must still hold its own result after the second has run."""
+    g = _golden(golden_dir, "inference_lj")
+    dev = _dev()
+    base = torch.from_numpy(g["text0"]).to(dev)
+    T1 = base.shape[1]
+    model.graphs = False
+    try:
+        exact0 = model.inference(base)
+        t2b = -(-exact0[0].shape[1] // model.T2_BUCKET)
+        other, exact1 = None, None
+        for k in range(1, T1 - 1):                               # a second utterance of the same length whose mel lands in the same bucket
+            cand = base.clone()
+            cand[0, k], cand[0, k + 1] = base[0, k + 1], base[0, k]
+            if torch.equal(cand, base):
+                continue
+            e1 = model.inference(cand)
+            if -(-e1[0].shape[1] // model.T2_BUCKET) == t2b and (e1[0].shape != exact0[0].shape or not torch.equal(e1[0], exact0[0])):
+                other, exact1 = cand, e1
+                break
+    finally:
+        model.graphs = True
+    assert other is not None, "no second utterance of the same bucket found"
+    for x in (base, other) * 2:                                  # eager, then captured
+        model.inference(x)
+    a = model.inference(base)
+    a_mel, a_al = a[0].clone(), a[1].clone()
+    b = model.inference(other)
+    c = model.inference(base)
+    for t in (a[0], a[1]):
+        assert all(t.data_ptr() != u.data_ptr() for u in (b[0], b[1], c[0], c[1]))
+    assert torch.equal(a[0], a_mel) and torch.equal(a[1], a_al), "the first call's tensors were overwritten by a later call"
+    assert float((a[0] - exact0[0]).abs().max()) <= 2e-4 and float((b[0] - exact1[0]).abs().max()) <= 2e-4
+    assert torch.equal(a[0], c[0])
