@@ -218,6 +218,7 @@ class EfficientTTSCNN(torch.nn.Module):
         self.side_stream = True             # text-length work on a second HIP stream beside the mel-length kernels
         self.resconv = True                 # long row spaces: residual stacks on efts_resconv5 (False: efts_gemm + fp32 stream, A/B and tests)
         self.dropout_seed = 0x5EED          # base seed of the train-mode dropout masks (mixed with the data-parallel rank and the step counter)
+        self._drop_now = None               # set while a train()-mode gradient-free forward enqueues its launches: (conv p, k -> seed, duration p, (seed0, seed1))
         self.dropout_calls = 0              # training steps taken so far: the position in the mask sequence (the trainer restores it from the step count on --resume)
         self._packed: Dict[str, PackedWeight] = {}
         self._packed_sig = None
@@ -332,8 +333,8 @@ class EfficientTTSCNN(torch.nn.Module):
         """tap_table [k_size][num_symbols][C] of text-encoder layer 0: tap k's weights applied to every symbol's embedding, in the
         operand format the model runs in (k_size one-tap efts_gemm launches over the embedding rows); rebuilt when the weights were
         re-packed.  None when the look-up form does not apply."""
-        if not self.embed_conv or len(self.text_encoder.layers) == 0 or self.n_channels % 32:
-            return None
+        if not self.embed_conv or len(self.text_encoder.layers) == 0 or self.n_channels % 32 or self._drop(0)[0] > 0.0:
+            return None                      # (a Dropout mask sits between layer 0's activation and its residual add: no look-up form)
         if getattr(self, "_te0_gen", None) == self._packed_gen and getattr(self, "_te0_tab", None) is not None:
             return self._te0_tab
         table = self.text_embedding_table.weight.detach()
@@ -370,6 +371,34 @@ class EfficientTTSCNN(torch.nn.Module):
         O.embed_conv(text, lens_i32, self.text_embedding_table.weight.detach(), tab, self.text_encoder.layers[0].conv[0].bias, self.slope,
                      x_f, x_p, rs1)
         return x_f, x_p
+
+    # ------------------------------------------------------------------ train-mode Dropout (counter-based masks)
+    def _dropout_base(self) -> int:
+        """the base seed of this process's mask family: the model's seed mixed with the data-parallel rank (the reference's ranks have
+        their own torch RNG streams)"""
+        rank = 0
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                rank = dist.get_rank()
+        except Exception:                                  # noqa: BLE001
+            rank = 0
+        return (int(self.dropout_seed) + 0x9E3779B1 * rank) & 0xFFFFFFFF
+
+    def _dropout_seeds(self, calls: int):
+        """(conv(k) -> seed of the Dropout behind conv / prenet launch k, seed of duration-predictor layer 0, of layer 1) for the
+        `calls`-th train-mode pass of this process: ONE definition for the fused training pass (train.TrainEngine) and the
+        gradient-free train()-mode forward, which therefore draw the same masks at the same counter"""
+        base = self._dropout_base()
+
+        def conv(k: int) -> int:
+            return (base * 2654435761 + calls * 1000003 + k * 7919 + 12345) & 0xFFFFFFFF
+        return conv, (base + 2 * calls) & 0xFFFFFFFF, (base + 2 * calls + 1) & 0xFFFFFFFF
+
+    def _drop(self, k: int):
+        """(p, seed) of the Dropout behind conv / prenet launch k in the pass in progress ((0, 0): none)"""
+        st = getattr(self, "_drop_now", None)
+        return (0.0, 0) if st is None or st[0] <= 0.0 else (st[0], st[1](k))
 
     def _side_stream(self, device) -> "torch.cuda.Stream":
         if not self.side_stream:
@@ -419,6 +448,8 @@ class EfficientTTSCNN(torch.nn.Module):
         return None
 
     def _on_resconv(self, rs: Rows) -> bool:
+        if self._drop(0)[0] > 0.0:           # conv Dropout in the pass in progress: efts_gemm's epilogue carries the masks
+            return False
         return self.resconv and rs.rows >= self.RESCONV_MIN_ROWS and self.n_channels % 256 == 0 and self.k_size in (3, 5)
 
     def _stream_in(self, ws, tag, rs: Rows):
@@ -468,16 +499,19 @@ class EfficientTTSCNN(torch.nn.Module):
                 x_pl, x_lo = y, y_lo
             return o_f32, x_pl
         assert rider is None and after is None
+        kbase = dict(te=10, me=20, dec=30).get(tag, 50)      # launch index of the Dropout masks (same numbering as the fused training pass)
         for i in range(start, n):
             last = i == n - 1
             w = pk[f"{blk}.{i}"]
             o_split = last_split if last else self.split
             o_f32 = ws.f32(f"{tag}_f{i & 1}", rs, C) if (not last or last_f32) else None
             o_pl = ws.plane(f"{tag}_p{i & 1}", rs, C, o_split)
+            dp_, dseed = self._drop(kbase + i)               # efts_modules.py:38-47: Dropout behind the activation, in front of the residual add
             O.gemm(a=x_pl, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=self.k_size, m=rs.rows, n=C,
                    act=L.ACT_LEAKY, slope=self.slope, bias=getattr(self, blk).layers[i].conv[0].bias,
                    resid_ptr=x_f32.ptr, ldr=C, rowmask_ptr=gap_ptr,
-                   out_f32_ptr=None if o_f32 is None else o_f32.ptr, ldo=C, out_plane=o_pl, tiling=self._til(rs.rows))
+                   out_f32_ptr=None if o_f32 is None else o_f32.ptr, ldo=C, out_plane=o_pl, tiling=self._til(rs.rows),
+                   drop_p=dp_, drop_seed=dseed)
             x_f32, x_pl = o_f32, o_pl
         return x_f32, x_pl
 
@@ -529,7 +563,8 @@ class EfficientTTSCNN(torch.nn.Module):
         return val_f, val_p
 
     def _duration(self, ws, pk, rs1: Rows, val_p: Plane, gap1, out_mask_ptr, mode: int) -> torch.Tensor:
-        """DurationPredictor._forward (duration_predictor.py:66-88); eval-mode (Dropout = identity)."""
+        """DurationPredictor._forward (duration_predictor.py:66-88); its Dropout(0.1) behind each LayerNorm (:61) is applied when the
+        pass in progress is a train()-mode one (`_drop_now`), else identity."""
         C = self.n_channels
         dp = self.duration_predictor
         h_f = ws.f32("dur_f", rs1, C)
@@ -555,12 +590,14 @@ class EfficientTTSCNN(torch.nn.Module):
         dp = self.duration_predictor
         ln = dp.conv[i][2]
         h_f = ws.f32("dur_f", rs1, C)
+        st = getattr(self, "_drop_now", None)
+        dur_p, dur_seed = (0.0, 0) if st is None else (st[2], st[3][min(i, 1)] if i < 2 else (st[3][1] + i) & 0xFFFFFFFF)
         if i + 1 < len(dp.conv):
             x_p = ws.plane(f"dur_p{i}", rs1, C, self.split)
-            O.layernorm_rows(h_f.ptr, ln.weight.detach(), ln.bias.detach(), ln.eps, gap1.data_ptr(), None, x_p, rs1.rows, C)
+            O.layernorm_rows(h_f.ptr, ln.weight.detach(), ln.bias.detach(), ln.eps, gap1.data_ptr(), None, x_p, rs1.rows, C, dur_p, dur_seed)
             return x_p
         O.layernorm_dot(h_f.ptr, ln.weight.detach(), ln.bias.detach(), ln.eps, dp.linear.weight.detach(), dp.linear.bias.detach(),
-                        out_mask_ptr, mode, float(dp.offset), ws.tensor("dur_out", (rs1.rows,)), rs1.rows, C)
+                        out_mask_ptr, mode, float(dp.offset), ws.tensor("dur_out", (rs1.rows,)), rs1.rows, C, dur_p, dur_seed)
         return None
 
     def _fused_expand(self, T1: int) -> bool:
@@ -608,15 +645,16 @@ class EfficientTTSCNN(torch.nn.Module):
         """Teacher-forced forward.  Returns (loss, stats, imv[B,T2], reconst_alpha[B,T1,T2],
         mel_pred[B,T2,odim], speech) exactly like the reference (:228)."""
         training_path = torch.is_grad_enabled() and (self.text_embedding_table.weight.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if not training_path and self.training and self.dropout_rate >= 1e-5:
-            # the reference would apply ResConv1d's / the prenet's Dropout here (efts_modules.py:38-47, efficient_tts.py:76-80); the
-            # masks live in the fused training pass only: refuse instead of returning a dropout-free result in train() mode
-            raise NotImplementedError(f"dropout_rate={self.dropout_rate} in train() mode without gradients: the conv / prenet Dropout is "
-                                      "applied by the fused training pass only; call eval() for a dropout-free forward")
         self._require(text)
         if training_path:
             from .autograd import training_forward
             return training_forward(self, text, text_lengths, speech, speech_lengths)
+        if self.training:
+            # train() mode without gradients (a validation pass that forgot eval(), a probe): the reference applies its Dropouts here --
+            # the duration predictor's 0.1 always (duration_predictor.py:61), ResConv1d's and the prenet's when dropout_rate > 0
+            # (efts_modules.py:38-47, efficient_tts.py:76-80).  Same counter-based masks as the fused training pass (one draw per
+            # train-mode pass: `dropout_calls` advances); the seeds are by-value launch arguments, so no graph
+            return self._forward_impl(text, text_lengths, speech, speech_lengths)[0]
         if not self.graphs or torch.cuda.is_current_stream_capturing():
             return self._forward_impl(text, text_lengths, speech, speech_lengths)[0]
         # per-shape hipGraph: the launches of this shape are replayed as one graph (efficient_tts_amd/graphs.py)
@@ -637,8 +675,19 @@ class EfficientTTSCNN(torch.nn.Module):
         return out3[0], LazyStats(out3), imv, ralpha, mel_pred, speech
 
     def _forward_impl(self, text, text_lengths, speech, speech_lengths, keep: bool = False):
-        with O.stream_scope():
-            return self._forward_body(text, text_lengths, speech, speech_lengths, keep)
+        prev = getattr(self, "_drop_now", None)
+        if self.training:
+            self.dropout_calls = int(self.dropout_calls) + 1
+            conv, s0, s1 = self._dropout_seeds(self.dropout_calls)
+            conv_p = float(self.dropout_rate) if self.dropout_rate >= 1e-5 else 0.0
+            object.__setattr__(self, "_drop_now", (conv_p, conv, float(self.duration_predictor.conv[0][3].p), (s0, s1)))
+        else:
+            object.__setattr__(self, "_drop_now", None)
+        try:
+            with O.stream_scope():
+                return self._forward_body(text, text_lengths, speech, speech_lengths, keep)
+        finally:
+            object.__setattr__(self, "_drop_now", prev)
 
     def _forward_body(self, text, text_lengths, speech, speech_lengths, keep: bool = False):
         dev = text.device
@@ -674,7 +723,8 @@ class EfficientTTSCNN(torch.nn.Module):
         def prenet(max_wgs=0):                                                    # :161
             pre_f, pre_p, pre_l = self._stream_in(ws, "pre", rs2)
             wp = pk["prenet"]
-            if self.fuse_prenet and self.odim % 8 == 0 and self.odim <= 128 and C % 128 == 0:
+            pre_dp, pre_seed = self._drop(40)                                      # mel_prenet's Dropout (:76-80)
+            if pre_dp == 0.0 and self.fuse_prenet and self.odim % 8 == 0 and self.odim <= 128 and C % 128 == 0:
                 # straight from the caller's fp32 frames: no operand plane of the mel input, one launch (bit-identical on every frame)
                 O.frame_linear(x=speech, w=wp, bias=self.mel_prenet[0].bias, act=L.ACT_LEAKY, slope=self.slope, rs=rs2,
                                y=pre_p, y_lo=pre_l, y_f32=pre_f, max_workgroups=max_wgs)
@@ -683,7 +733,7 @@ class EfficientTTSCNN(torch.nn.Module):
                 O.pack_rows(speech, None, mel_in, rs2)
                 O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, act=L.ACT_LEAKY, slope=self.slope,
                        bias=self.mel_prenet[0].bias, rowmask_ptr=gap2.data_ptr(), out_f32_ptr=None if pre_f is None else pre_f.ptr,
-                       ldo=C, out_plane=pre_p, out_plane_lo=pre_l)
+                       ldo=C, out_plane=pre_p, out_plane_lo=pre_l, drop_p=pre_dp, drop_seed=pre_seed)
             return pre_f, pre_p, pre_l
 
         def mel_stack(pre_f, pre_p, pre_l, rider=None):                            # :162-164

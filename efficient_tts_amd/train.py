@@ -164,18 +164,11 @@ class TrainEngine:
         m = self.m
         if not m.training or m.dropout_rate < 1e-5:
             return 0.0, 0
-        return float(m.dropout_rate), (getattr(self, "seed_base", int(m.dropout_seed)) * 2654435761 + self.drop_calls * 1000003 + k * 7919 + 12345) & 0xFFFFFFFF
+        return float(m.dropout_rate), m._dropout_seeds(self.drop_calls)[0](k)
 
     def _seed_base(self) -> int:
         """the model's base seed mixed with the data-parallel rank"""
-        rank = 0
-        try:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized():
-                rank = dist.get_rank()
-        except Exception:                                  # noqa: BLE001
-            rank = 0
-        return (int(self.m.dropout_seed) + 0x9E3779B1 * rank) & 0xFFFFFFFF
+        return self.m._dropout_base()
 
     def _wgrad_any(self, ws, dz_f_ptr, dz_p: Optional[Plane], x_f_ptr, x_p: Optional[Plane], cout, cin, taps, rows, out_dw):
         """un-normed weights: the direct kernel when both operand planes exist in one format and the shape fits its tiles"""

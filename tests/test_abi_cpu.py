@@ -85,21 +85,26 @@ def test_model_fails_loudly_without_gpu():
         m.inference(torch.zeros(1, 8, dtype=torch.long))
 
 
-def test_dropout_free_forward_in_train_mode_is_refused_not_ignored():
+def test_train_mode_forward_without_gradients_reaches_the_device_path():
     """The reference applies Dropout inside ResConv1d and the prenet for dropout_rate > 0 (ctor default 0.1,
-    nntts/layers/efts_modules.py:38-47, efficient_tts.py:76-80).  The fused training pass does (tests/test_gpu_train.py); a
-    forward in train() mode WITHOUT gradients would silently be dropout-free, so it raises (eval() and dropout_rate=0.0 are fine)."""
+    nntts/layers/efts_modules.py:38-47, efficient_tts.py:76-80) in EVERY train()-mode forward.  Since round 4 the gradient-free
+    train()-mode forward applies the same counter-based masks as the fused training pass (tests/test_gpu_train.py compares the two on
+    the GPU) instead of refusing; on a CPU-only box it must fail on the missing device like any other call -- no silent CPU path --
+    and the mask seeds are one definition shared with the training engine."""
     import torch
     from efficient_tts_amd import EfficientTTSCNN
     m = EfficientTTSCNN(num_symbols=76, use_masking=True)                # dropout_rate = 0.1, train() mode
     t = torch.zeros(1, 8, dtype=torch.long)
-    with torch.no_grad(), pytest.raises(NotImplementedError, match="dropout_rate"):
-        m(t, torch.tensor([8]), torch.zeros(1, 16, 80), torch.tensor([16]))
-    m.eval()
     if not torch.cuda.is_available():
-        with torch.no_grad(), pytest.raises(Exception) as ei:             # past the guard: fails on the missing device instead
-            m(t, torch.tensor([8]), torch.zeros(1, 16, 80), torch.tensor([16]))
-        assert "dropout_rate" not in str(ei.value)
+        for mode in (m.train, m.eval):
+            mode()
+            with torch.no_grad(), pytest.raises(Exception) as ei:
+                m(t, torch.tensor([8]), torch.zeros(1, 16, 80), torch.tensor([16]))
+            assert not isinstance(ei.value, NotImplementedError)
+    conv, s0, s1 = m._dropout_seeds(7)
+    conv2, t0, t1 = m._dropout_seeds(8)
+    assert conv(30) != conv(31) and conv(30) != conv2(30) and (s0, s1) != (t0, t1) and s1 == (s0 + 1) & 0xFFFFFFFF
+    assert m._drop(30) == (0.0, 0)                                       # no pass in progress: no masks
 
 
 def test_lazy_stats_behaves_like_a_dict():
