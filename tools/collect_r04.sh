@@ -1,0 +1,43 @@
+#!/bin/bash
+# Round-4 evidence in one gpurun call: lab libraries rebuilt from HEAD, workgroup stamps / phase counters / tile marks / ablations of the
+# dominant kernel, rocprofv3 summaries (trace + PMC passes, with timelines for BOTH precisions), the bench lines of every workload.
+# Everything lands in gpurun_out/collect/; copy what is to be judged into profiles/.  A failing probe fails the script.
+set -eo pipefail
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/collect
+mkdir -p $O
+cd $R
+TAGR=${TAGR:-r04}
+EXPS="1 8 9 4" bash tools/lab_build.sh > $O/lab_build.log 2>&1
+probe() {   # name, lab library, script, env...
+  local out=$O/$1; local lib=$2; local script=$3; shift 3
+  env "$@" EFTS_LIB=$R/lab/$lib timeout 300 python $script > $out 2>&1 || { echo "PROBE FAILED: $out"; tail -5 $out; exit 1; }
+  if grep -q "Traceback" $out; then echo "PROBE FAILED (traceback): $out"; exit 1; fi
+}
+( for sp in 1 2; do PSPLIT=$sp EFTS_LIB=$R/lab/rc_stamp.so timeout 300 python tools/gpu_probe_rc_stamp.py; done ) > $O/rc_stamps_$TAGR.txt 2>&1 || { echo "PROBE FAILED: stamps"; exit 1; }
+if grep -q Traceback $O/rc_stamps_$TAGR.txt; then echo "PROBE FAILED (traceback): stamps"; exit 1; fi
+probe rc_phases_$TAGR.txt rc_phase.so tools/gpu_probe_rc_phases.py
+probe rc_marks_$TAGR.txt rc_marks.so tools/gpu_probe_rc_marks.py
+# ablations of the ping-pong kernel (us per B = 64 launch): all / no LDS-DMA / no epilogue traffic / neither / no MFMA + fragment reads
+GRAFT_REPO_ROOT=$R bash tools/rc_ab.sh 64x800 cur exp1 exp8 exp9 exp4 > $O/rc_ablate_$TAGR.txt 2>&1 || { echo "PROBE FAILED: ablations"; exit 1; }
+if [ -z "$SKIP_PROF" ]; then
+PREC=bf16 TIMELINE=60 bash tools/prof_conv.sh ${TAGR}_bf16 > /dev/null 2>&1
+PREC=bf16x3 TIMELINE=60 bash tools/prof_conv.sh ${TAGR}_bf16x3 > /dev/null 2>&1
+WL=train32 STEPS=3 TIMELINE=240 BARGS="--train-graph 0" bash tools/prof_conv.sh ${TAGR}_train_bf16 > /dev/null 2>&1
+for t in ${TAGR}_bf16 ${TAGR}_bf16x3 ${TAGR}_train_bf16; do
+  test -s gpurun_out/prof_$t/summary_$t.txt || { echo "PROFILE FAILED: $t"; exit 1; }
+  cp gpurun_out/prof_$t/summary_$t.txt $O/rocprofv3_${t}_summary.txt
+  cp gpurun_out/prof_$t/bench_line_$t.json $O/bench_line_under_rocprof_$t.json
+done
+fi
+cd $R
+if [ -z "$SKIP_BENCH" ]; then
+python bench.py > $O/bench_fwd64_$TAGR.json 2> $O/bench_fwd64.err
+python bench.py --workload fwd16_long > $O/bench_fwd16_long_$TAGR.json 2> $O/bench_fwd16_long.err
+python bench.py --workload train32 > $O/bench_train32_bf16_$TAGR.json 2> $O/bench_train32.err
+python bench.py --workload train32 --precision bf16x3 --no-cpu-baseline > $O/bench_train32_bf16x3_$TAGR.json 2>> $O/bench_train32.err
+python bench.py --workload infer64 --no-cpu-baseline > $O/bench_infer64_bf16_$TAGR.json 2> $O/bench_infer.err
+python bench.py --workload infer_lj > $O/bench_infer_lj_bf16_$TAGR.json 2>> $O/bench_infer.err
+for f in $O/bench_*_$TAGR.json; do test -s $f || { echo "BENCH FAILED: $f"; exit 1; }; done
+fi
+ls -la $O
