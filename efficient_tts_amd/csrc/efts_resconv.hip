@@ -468,12 +468,9 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, const RcProb& pq, const
     }
 }
 
-#ifndef RC_W4
-#define RC_W4 0
-#endif
-#if RC_W4
-#include "efts_resconv_w4.h"   // lab variant: one wave per SIMD (slower; see the header)
-#endif
+}  // namespace efts
+#include "efts_resconv4.h"     // the one-wave-per-SIMD kernel (bf16 planes, 5 taps): hand-scheduled main loop
+namespace efts {
 
 template <int SPLIT>
 __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
@@ -713,6 +710,15 @@ static int rc_check(const efts_resconv5_args* a, const char* who) {
     return 0;
 }
 
+// which kernel efts_resconv5 launches: 0 = by shape (default), 1 = always the 8-wave ping-pong kernel, 2 = the one-wave-per-SIMD kernel
+// (error where it does not apply).  Process-wide; for A/B measurements and the bit-equality tests between the two.
+static int g_rc_kernel = 0;
+extern "C" int efts_resconv5_kernel(int32_t which) {
+    const int prev = g_rc_kernel;
+    if (which >= 0 && which <= 2) g_rc_kernel = which;
+    return prev;
+}
+
 extern "C" int efts_resconv5_multi(const efts_resconv5_args* a, int32_t count, void* stream) {
     if (!a) return efts_fail(EFTS_EINVAL, "efts_resconv5: null args");
     if (count < 1 || count > RC_MAXPROB) return efts_fail(EFTS_EINVAL, "efts_resconv5_multi: 1..%d layers per launch", RC_MAXPROB);
@@ -757,19 +763,17 @@ extern "C" int efts_resconv5_multi(const efts_resconv5_args* a, int32_t count, v
         if (base) { k.stamp = base + (size_t)(launch % 64) * 1024; ++launch; }
     }
 #endif
-#if RC_W4
-    {
+    // bf16 planes with 5 taps (the mel-length stacks of every shipped configuration): the one-wave-per-SIMD kernel with the generated
+    // main loop (efts_resconv4.h); everything else -- split-2 planes, k3 layers, a single K chunk -- stays on the 8-wave kernel
+    bool w4 = g_rc_kernel != 1 && a->split == 1 && k.nchunk >= 2;
+    for (int i = 0; i < count; ++i) w4 = w4 && k.pr[i].taps == 5;
+    if (g_rc_kernel == 2 && !w4) return efts_fail(EFTS_EINVAL, "efts_resconv5: the one-wave-per-SIMD kernel was forced (efts_resconv5_kernel(2)) but takes bf16 planes (split 1), 5 taps and at least 2 K chunks only");
+    if (w4) {
         static bool attr4 = false;
-        if (!attr4) {
-            (void)hipFuncSetAttribute((const void*)resconv5w4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
-            (void)hipFuncSetAttribute((const void*)resconv5w4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS);
-            attr4 = true;
-        }
-        if (a->split == 1) hipLaunchKernelGGL(resconv5w4_kernel<1>, grid, dim3(256), RC_LDS, (hipStream_t)stream, k);
-        else hipLaunchKernelGGL(resconv5w4_kernel<2>, grid, dim3(256), RC_LDS, (hipStream_t)stream, k);
+        if (!attr4) { (void)hipFuncSetAttribute((const void*)resconv5w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS); attr4 = true; }
+        hipLaunchKernelGGL(resconv5w4_kernel, grid, dim3(256), RC_LDS, (hipStream_t)stream, k);
         return efts_check_launch("efts_resconv5");
     }
-#endif
     if (a->split == 1) hipLaunchKernelGGL(resconv5_kernel<1>, grid, dim3(512), RC_LDS, (hipStream_t)stream, k);
     else hipLaunchKernelGGL(resconv5_kernel<2>, grid, dim3(512), RC_LDS, (hipStream_t)stream, k);
     return efts_check_launch("efts_resconv5");

@@ -76,6 +76,7 @@ _SIGS = {
     "efts_resconv5": (i32, [C.POINTER(ResConv5Args), vp]),
     "efts_resconv5_multi": (i32, [C.POINTER(ResConv5Args), i32, vp]),
     "efts_resconv5_plan": (i32, [i32, i32, i32, C.POINTER(i32), i32]),
+    "efts_resconv5_kernel": (i32, [i32]),
     "efts_pack_weight": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "efts_row_masks": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "efts_row_masks_pair": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -239,6 +239,12 @@ int efts_frame_linear(const efts_frame_linear_args* a, void* stream);
 #define EFTS_RC_PLAN_INTS 42
 int efts_resconv5_plan(int32_t m, int32_t n, int32_t cus, int32_t* plan, int32_t cap);
 
+/* efts_resconv5 has two kernels with the same tiles, plans and results: the 8-wave ping-pong kernel (any plane format, 3 or 5 taps) and, for
+ * bf16 planes (split 1) with 5 taps and >= 2 K chunks, the one-wave-per-SIMD kernel with the hand-scheduled main loop (round 4).
+ * which = 0: chosen by shape (default); 1: always the 8-wave kernel; 2: the one-wave-per-SIMD kernel (EFTS_EINVAL where it does not apply);
+ * any other value only queries.  Process-wide; returns the previous setting.  For A/B measurements and the equality tests between the two. */
+int efts_resconv5_kernel(int32_t which);
+
 /* ------------------------------------------------------------------------------------
  * Parameter preparation.
  * efts_pack_weight: w[cout][cin][taps] fp32 (torch Conv1d / Linear layout) -> B operand plane
