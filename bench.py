@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--call-modes", type=int, default=1, help="forward workloads, N=1: 10 extra steps per call mode (plain call / bench graph / eager) -> `call_modes`")
     ap.add_argument("--train-record", type=int, default=1, help="fwd64, N=1: also time BASELINE config 3 (training step B=32, 10 steps) under the same invocation -> `train32` in the JSON line")
     ap.add_argument("--measure-traffic", type=int, default=1, help="forward workloads, N=1: roofline.traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) over a 2-step child run, when rocprofv3 is on the box; 0: the committed profiles/traffic.json")
+    ap.add_argument("--rc-kernel", type=int, default=0, help="A/B: efts_resconv5_kernel(which): 0 / 1 the 8-wave ping-pong kernel (default), 2 the one-wave-per-SIMD kernel where it applies")
     ap.add_argument("--merge-text", type=int, default=1, help="A/B: 0 = text-encoder layers as launches of their own on the second stream")
     return ap.parse_args()
 
@@ -187,7 +188,7 @@ def measure_traffic(a, precision, workload=None):
             out = os.path.join(tmp, ctr)
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", out, "-o", "b", "--", sys.executable, os.path.abspath(__file__),
                    "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--parity-mode", "0", "--call-modes", "0", "--train-record", "0",
-                   "--measure-traffic", "0", "--train-graph", "0", "--precision", precision, "--workload", workload or a.workload]
+                   "--measure-traffic", "0", "--train-graph", "0", "--rc-kernel", str(a.rc_kernel), "--precision", precision, "--workload", workload or a.workload]
             subprocess.run(cmd, cwd="/tmp", env=env, timeout=150, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
             if not dbs:
@@ -531,6 +532,9 @@ def main():
         return run_rendezvous(a, world, rank)
 
     from efficient_tts_amd import EfficientTTSCNN, ops as P
+    if a.rc_kernel:
+        from efficient_tts_amd import lib as _L
+        _L.load().efts_resconv5_kernel(a.rc_kernel)
     if a.workload == "infer_lj":
         return run_infer_lj(a, world, rank, dev)
     if a.workload == "infer64":

@@ -137,7 +137,11 @@ __device__ __forceinline__ int rc_pieces(int h, int wave) { return (4 * h - wave
 // the weight requests two steps ahead simply wrap into the next tile's steps 0 and 1, and the next tile's first window
 // (rows m1, height h1; 0 = no next tile) is requested at the first tap of this tile's last chunk.  On entry the window of
 // chunk 0 and the weights of steps 0 and 1 are therefore in flight or landed.
-template <int SPLIT, int NI, int TAPS>
+// FAST: a layer in the middle of a stack on planes -- residual from the planes (split 1: hi + lo planes; split 2: the [hi | lo] chunks),
+// row mask, planes out in the same format, nothing else -- with every per-layer switch of the epilogue a compile-time constant.  Read from
+// the argument segment inside the sweep those switches cost a unit (32 rows x 64 columns) ~850 instructions incl. 24 scalar loads and ~50
+// uniform branches; as constants ~380 (round 4; the sweep is bound by instruction issue, not by its bytes).
+template <int SPLIT, int NI, int TAPS, bool FAST>
 __device__ __forceinline__ void rc_tile(const RcArgs& p, const RcProb& pq, const RcProb& pn, RcCtx& c, int m0, int h, int rows_out, int m1, int h1) {
     // TAPS 5 or 3: a k3 layer keeps the k5 geometry (window from row m0 - 2, 32 h - 4 output rows per tile) and simply reads window
     // rows r + k + 1 for its three taps; fewer steps per chunk, everything else -- streams, barriers, epilogue -- is the same code
@@ -352,8 +356,16 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, const RcProb& pq, const
     const __amdgpu_buffer_rsrc_t r_ob = make_rsrc(pq.ob ? pq.ob + (long)m0 * pq.ldob : nullptr, pq.ob ? (long)rows_out * pq.ldob : 0);
     const __amdgpu_buffer_rsrc_t r_ol = make_rsrc(pq.ob_lo ? pq.ob_lo + (long)m0 * pq.ldob : nullptr, pq.ob_lo ? (long)rows_out * pq.ldob : 0);
     const __amdgpu_buffer_rsrc_t r_sg = make_rsrc(pq.sign ? pq.sign + (long)m0 * pq.ldsg : nullptr, pq.sign ? (long)rows_out * pq.ldsg : 0);
-    const bool res_f32 = pq.resid != nullptr;
-    const bool has_mask = pq.rowmask != nullptr && !(RC_EXP & 8);
+    const bool res_f32 = FAST ? false : pq.resid != nullptr;
+    const bool has_mask = FAST ? !(RC_EXP & 8) : (pq.rowmask != nullptr && !(RC_EXP & 8));
+    const bool f_noresid = FAST ? false : pq.no_resid != 0;
+    const bool f_sign = FAST ? false : pq.sign != nullptr;
+    const bool f_of32 = FAST ? false : pq.out_f32 != nullptr;
+    const bool f_ob = FAST ? true : pq.ob != nullptr;
+    const bool f_os2 = FAST ? SPLIT == 2 : pq.out_split == 2;
+    const bool f_oblo = FAST ? SPLIT == 1 : pq.ob_lo != nullptr;
+    const float slope = pq.slope;
+    const unsigned ldsg = (unsigned)pq.ldsg;
     const int srow = lane >> 3;                       // row of the 8-row pass this lane handles
     const int c8 = lane & 7;                          // its 8 columns inside the 64-column pair of blocks
     const char* const stl = (c8 < 4 ? st0 : st1);     // the block those columns were staged in
@@ -367,9 +379,9 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, const RcProb& pq, const
     const unsigned sx_row = res_f32 ? (unsigned)pq.ldr * 4 : (unsigned)pq.lda;       // bytes per row
     const unsigned vm = lrow0 * 4;
     const unsigned vof = lrow0 * (unsigned)pq.ldo * 4 + col0 * 4, sof_row = (unsigned)pq.ldo * 4;
-    const unsigned vob = lrow0 * (unsigned)pq.ldob + (pq.out_split == 1 ? col0 * 2 : (col0 >> 5) * 128 + (col0 & 31) * 2);
+    const unsigned vob = lrow0 * (unsigned)pq.ldob + (!f_os2 ? col0 * 2 : (col0 >> 5) * 128 + (col0 & 31) * 2);
     const unsigned sob_row = (unsigned)pq.ldob;
-    const unsigned vsg = lrow0 * (unsigned)pq.ldsg + (col0 >> 3);
+    const unsigned vsg = lrow0 * ldsg + (col0 >> 3);
 
     // (split-2 planes keep 64-byte hi / lo halves per instruction.  Measured and dropped: lanes 0-3 of a row on the hi slots and
     // lanes 4-7 on the lo slots of the same 32 columns, words swapped through ds_bpermute, both lanes computing the same outputs --
@@ -384,7 +396,7 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, const RcProb& pq, const
         for (int pp = 0; pp < 2; ++pp) {
             const unsigned rofs = (u >> 1) * 32 + ((u & 1) * 2 + pp) * 8;
             const unsigned so = rofs * sx_row;
-            if ((RC_EXP & 8) || pq.no_resid) { xa[bsel][pp] = u32x4{0, 0, 0, 0}; xb[bsel][pp] = xa[bsel][pp]; }
+            if ((RC_EXP & 8) || f_noresid) { xa[bsel][pp] = u32x4{0, 0, 0, 0}; xb[bsel][pp] = xa[bsel][pp]; }
             else if (res_f32) {
                 xa[bsel][pp] = __builtin_amdgcn_raw_buffer_load_b128(r_x, vx, so, 0);
                 xb[bsel][pp] = __builtin_amdgcn_raw_buffer_load_b128(r_x, vx, so + 16, 0);
@@ -410,7 +422,7 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, const RcProb& pq, const
             for (int r = 0; r < 16; ++r) {
                 const int rl = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
                 float v = acc[i][j][r] + c.bv[j];
-                v = v > 0.f ? v : v * pq.slope;
+                v = v > 0.f ? v : v * slope;
                 *(float*)(stj + rl * 128 + ((((lrow >> 2) ^ ((rl >> 1) & 1))) << 4) + (lrow & 3) * 4) = v;
             }
         }
@@ -439,20 +451,20 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, const RcProb& pq, const
             float y[8] = {(x[0] + d0.x) * rm, (x[1] + d0.y) * rm, (x[2] + d0.z) * rm, (x[3] + d0.w) * rm,
                           (x[4] + d1.x) * rm, (x[5] + d1.y) * rm, (x[6] + d1.z) * rm, (x[7] + d1.w) * rm};
             const unsigned brow = i * 32 + ps * 8;
-            if ((int)(lrow0 + brow) >= rows_out) continue;      // rows of the next tile / past the matrix (the descriptors clip them too)
+            // (rows of the next tile / past the matrix: every output descriptor ends at this tile's last row, so their stores are dropped)
             if (RC_EXP & 8) { asm volatile("" ::"v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7])); continue; }
-            if (pq.sign) {                                      // training: one byte of sign bits per lane (its 8 columns)
+            if (f_sign) {                                       // training: one byte of sign bits per lane (its 8 columns)
                 const unsigned sb = (d0.x > 0.f ? 1u : 0u) | (d0.y > 0.f ? 2u : 0u) | (d0.z > 0.f ? 4u : 0u) | (d0.w > 0.f ? 8u : 0u) |
                                     (d1.x > 0.f ? 16u : 0u) | (d1.y > 0.f ? 32u : 0u) | (d1.z > 0.f ? 64u : 0u) | (d1.w > 0.f ? 128u : 0u);
-                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)sb, r_sg, vsg, brow * (unsigned)pq.ldsg, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)sb, r_sg, vsg, brow * ldsg, 0);
             }
-            if (pq.out_f32) {
+            if (f_of32) {
                 const u32x4 o0 = {__float_as_uint(y[0]), __float_as_uint(y[1]), __float_as_uint(y[2]), __float_as_uint(y[3])};
                 const u32x4 o1 = {__float_as_uint(y[4]), __float_as_uint(y[5]), __float_as_uint(y[6]), __float_as_uint(y[7])};
                 store_b128(o0, r_of, vof, brow * sof_row);               // constant displacements go into the scalar
                 store_b128(o1, r_of, vof, brow * sof_row + 16);          // offset: no VALU address math between stores
             }
-            if (pq.ob) {
+            if (f_ob) {
                 float rr[8];
                 const u32x4 hi = {pack_bf16x2(y[0], y[1], &rr[0], &rr[1]), pack_bf16x2(y[2], y[3], &rr[2], &rr[3]),
                                   pack_bf16x2(y[4], y[5], &rr[4], &rr[5]), pack_bf16x2(y[6], y[7], &rr[6], &rr[7])};
@@ -461,8 +473,8 @@ __device__ __forceinline__ void rc_tile(const RcArgs& p, const RcProb& pq, const
                                   pack_bf16x2(rr[4], rr[5], &d0_, &d1_), pack_bf16x2(rr[6], rr[7], &d0_, &d1_)};
                 const unsigned so = brow * sob_row;
                 store_b128(hi, r_ob, vob, so);
-                if (pq.out_split == 2) store_b128(lo, r_ob, vob, so + 64);
-                else if (pq.ob_lo) store_b128(lo, r_ol, vob, so);
+                if (f_os2) store_b128(lo, r_ob, vob, so + 64);
+                else if (f_oblo) store_b128(lo, r_ol, vob, so);
             }
         }
     }
@@ -564,19 +576,28 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
         c.w_next = pn.w + (long)c.n0 * pn.ldw;
         c.wts_next = pn.w_tap_stride;
         const int nblk = c.wm ? h >> 1 : (h + 1) >> 1;      // 32-row blocks of this wave's row (wave-uniform)
+        const bool fast = !pq.resid && pq.rowmask && pq.ob && !pq.out_f32 && !pq.sign && !pq.no_resid &&
+                          (SPLIT == 1 ? (pq.a_lo && pq.ob_lo && pq.out_split == 1) : pq.out_split == 2);
         if (pq.taps == 3) {
             switch (nblk) {
-                case 1: rc_tile<SPLIT, 1, 3>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
-                case 2: rc_tile<SPLIT, 2, 3>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
-                case 3: rc_tile<SPLIT, 3, 3>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
-                default: rc_tile<SPLIT, 4, 3>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+                case 1: rc_tile<SPLIT, 1, 3, false>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+                case 2: rc_tile<SPLIT, 2, 3, false>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+                case 3: rc_tile<SPLIT, 3, 3, false>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+                default: rc_tile<SPLIT, 4, 3, false>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+            }
+        } else if (fast) {
+            switch (nblk) {
+                case 1: rc_tile<SPLIT, 1, 5, true>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+                case 2: rc_tile<SPLIT, 2, 5, true>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+                case 3: rc_tile<SPLIT, 3, 5, true>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+                default: rc_tile<SPLIT, 4, 5, true>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
             }
         } else {
             switch (nblk) {
-                case 1: rc_tile<SPLIT, 1, 5>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
-                case 2: rc_tile<SPLIT, 2, 5>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
-                case 3: rc_tile<SPLIT, 3, 5>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
-                default: rc_tile<SPLIT, 4, 5>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+                case 1: rc_tile<SPLIT, 1, 5, false>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+                case 2: rc_tile<SPLIT, 2, 5, false>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+                case 3: rc_tile<SPLIT, 3, 5, false>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+                default: rc_tile<SPLIT, 4, 5, false>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
             }
         }
         RC_MARK(p, c);
@@ -710,8 +731,8 @@ static int rc_check(const efts_resconv5_args* a, const char* who) {
     return 0;
 }
 
-// which kernel efts_resconv5 launches: 0 = by shape (default), 1 = always the 8-wave ping-pong kernel, 2 = the one-wave-per-SIMD kernel
-// (error where it does not apply).  Process-wide; for A/B measurements and the bit-equality tests between the two.
+// which kernel efts_resconv5 launches: 0 = default (the 8-wave ping-pong kernel), 1 = the same, explicitly, 2 = the one-wave-per-SIMD
+// kernel wherever it applies (bf16 planes, 5 taps, >= 2 K chunks; the 8-wave kernel elsewhere).  Process-wide; for A/B measurements and the bit-equality tests between the two.
 static int g_rc_kernel = 0;
 extern "C" int efts_resconv5_kernel(int32_t which) {
     const int prev = g_rc_kernel;
@@ -763,11 +784,12 @@ extern "C" int efts_resconv5_multi(const efts_resconv5_args* a, int32_t count, v
         if (base) { k.stamp = base + (size_t)(launch % 64) * 1024; ++launch; }
     }
 #endif
-    // bf16 planes with 5 taps (the mel-length stacks of every shipped configuration): the one-wave-per-SIMD kernel with the generated
-    // main loop (efts_resconv4.h); everything else -- split-2 planes, k3 layers, a single K chunk -- stays on the 8-wave kernel
-    bool w4 = g_rc_kernel != 1 && a->split == 1 && k.nchunk >= 2;
+    // The one-wave-per-SIMD kernel with the generated main loop (efts_resconv4.h; bf16 planes, 5 taps) is launched on request only
+    // (efts_resconv5_kernel(2)): its main loop needs 8 % fewer cycles than the ping-pong kernel's (2 210 vs ~2 400 per full step), but on
+    // MI355X both run at the clock the power budget leaves (1.4-1.5 GHz with every CU issuing MFMAs on random operands) and take the same
+    // time -- measured in one process: forward 1.596 vs 1.561 ms, training step 3.80 vs 3.70 ms, the 8-wave kernel ahead (DESIGN.md 4a').
+    bool w4 = g_rc_kernel == 2 && a->split == 1 && k.nchunk >= 2;
     for (int i = 0; i < count; ++i) w4 = w4 && k.pr[i].taps == 5;
-    if (g_rc_kernel == 2 && !w4) return efts_fail(EFTS_EINVAL, "efts_resconv5: the one-wave-per-SIMD kernel was forced (efts_resconv5_kernel(2)) but takes bf16 planes (split 1), 5 taps and at least 2 K chunks only");
     if (w4) {
         static bool attr4 = false;
         if (!attr4) { (void)hipFuncSetAttribute((const void*)resconv5w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS); attr4 = true; }

@@ -241,7 +241,8 @@ int efts_resconv5_plan(int32_t m, int32_t n, int32_t cus, int32_t* plan, int32_t
 
 /* efts_resconv5 has two kernels with the same tiles, plans and results: the 8-wave ping-pong kernel (any plane format, 3 or 5 taps) and, for
  * bf16 planes (split 1) with 5 taps and >= 2 K chunks, the one-wave-per-SIMD kernel with the hand-scheduled main loop (round 4).
- * which = 0: chosen by shape (default); 1: always the 8-wave kernel; 2: the one-wave-per-SIMD kernel (EFTS_EINVAL where it does not apply);
+ * which = 0: the default (the 8-wave kernel: measured equal or ahead in situ, DESIGN.md 4a'); 1: the 8-wave kernel, explicitly; 2: the
+ * one-wave-per-SIMD kernel wherever it applies (the 8-wave kernel elsewhere);
  * any other value only queries.  Process-wide; returns the previous setting.  For A/B measurements and the equality tests between the two. */
 int efts_resconv5_kernel(int32_t which);
 

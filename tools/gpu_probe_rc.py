@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from efficient_tts_amd import lib as L, ops as P
 dev = torch.device("cuda:0"); L.load(); L.require_device()
-L.load().efts_resconv5_kernel(int(os.environ.get("RCK", "0")))     # RCK: 0 by shape, 1 the 8-wave kernel, 2 the one-wave-per-SIMD kernel
+L.load().efts_resconv5_kernel(int(os.environ.get("RCK", "0")))     # RCK: 0 / 1 the 8-wave kernel (default), 2 the one-wave-per-SIMD kernel where it applies
 C = 512
 def bf16_split(x):
     hi = x.to(torch.bfloat16); lo = (x - hi.float()).to(torch.bfloat16)
