@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--workload", default="fwd64", choices=["fwd64", "fwd16_long", "train32", "infer_lj", "infer64", "logmel64", "vocoder", "vocoder8", "rendezvous"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-set", action="append", default=[], metavar="NAME=INT",
-                    help="train32 A/B runs: set a switch of efficient_tts_amd.train (_SIGN_MIN_ROWS=0, _BIAS_PARTS=0, ...)")
+                    help="train32 A/B runs: set a hook of efficient_tts_amd.train (_RESCONV_DGRAD=3, _SIGN_MIN_ROWS=0, ...)")
     ap.add_argument("--dp-algo", default="allreduce", choices=["allreduce", "rs_ag"], help="train32, N > 1: per-bucket all_reduce, or reduce_scatter + all_gather (point-to-point xGMI)")
     ap.add_argument("--side-stream", type=int, default=1, help="0: text-length work on the main stream (A/B)")
     ap.add_argument("--resconv", type=int, default=1, help="0: residual stacks on efts_gemm + fp32 stream (A/B)")
@@ -67,7 +67,6 @@ def parse():
     ap.add_argument("--train-record", type=int, default=1, help="fwd64, N=1: also time BASELINE config 3 (training step B=32, 10 steps) under the same invocation -> `train32` in the JSON line")
     ap.add_argument("--measure-traffic", type=int, default=1, help="forward workloads, N=1: roofline.traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) over a 2-step child run, when rocprofv3 is on the box; 0: the committed profiles/traffic.json")
     ap.add_argument("--rc-kernel", type=int, default=0, help="A/B: efts_resconv5_kernel(which): 0 / 1 the 8-wave ping-pong kernel (default), 2 the one-wave-per-SIMD kernel where it applies")
-    ap.add_argument("--merge-text", type=int, default=1, help="A/B: 0 = text-encoder layers as launches of their own on the second stream")
     return ap.parse_args()
 
 
@@ -609,7 +608,6 @@ def run_forward(a, world, rank, dev, wl):
         m.side_stream, m.resconv = bool(a.side_stream), bool(a.resconv)
         m.fuse_soft_index = bool(a.fuse_soft_index)
         m.fuse_prenet = bool(a.fuse_prenet)
-        m.merge_text = bool(a.merge_text)
         if a.resconv_min_rows >= 0:
             m.RESCONV_MIN_ROWS = a.resconv_min_rows
         return m

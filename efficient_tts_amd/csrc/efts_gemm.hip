@@ -621,7 +621,7 @@ template <int T, int S>
 static void set_lds_attr() {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<T, S, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
 }
-extern "C" void efts_gemm_init(void) {
+__attribute__((visibility("hidden"))) void efts_gemm_init(void) {
     static bool once = false;
     if (!once) {
         conv5_set_lds_attr();

@@ -9,7 +9,8 @@
 int efts_fail(int code, const char* fmt, ...);
 // hipGetLastError() after a launch -> EFTS_ELAUNCH with the HIP error string.
 int efts_check_launch(const char* what);
-extern "C" void efts_gemm_init(void);
+// (internal: not an ABI symbol, hidden from the shared object's export table)
+__attribute__((visibility("hidden"))) void efts_gemm_init(void);
 // number of compute units of the current device (cached)
 int efts_num_cus(void);
 

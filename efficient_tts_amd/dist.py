@@ -62,7 +62,7 @@ class BucketReducer:
         issued as stream-ordered SYNCHRONOUS ops (async_op=False): the NCCL backend then enqueues them on the stream they are called
         on, so the communication stream stays a plain fork of the compute stream -- the only dependency shape ROCm 7.2 captures safely
         (a forked stream waiting for an event of ANOTHER forked stream -- what the backend's internal stream of an async op is --
-        crashes hipStreamEndCapture: tools/gpu_probe_capture4.py) -- and the whole step, collectives included, can be one hipGraph.
+        crashes hipStreamEndCapture: tools/attic/gpu_probe_capture4.py) -- and the whole step, collectives included, can be one hipGraph.
         Neither the host nor the compute stream waits: only the communication stream is ordered behind the collective."""
         view = self.flat[self.starts[i]:self.ends[i]]
         on_gpu = self.comm_stream is not None

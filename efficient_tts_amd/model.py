@@ -10,6 +10,7 @@ fallback: without the library or a gfx950 device the model raises.
 """
 from __future__ import annotations
 
+import dataclasses
 import logging
 from typing import Dict, Optional, Tuple
 
@@ -142,6 +143,28 @@ class _Workspace:
 PRECISIONS = {"bf16": 1, "bf16x3": 2}
 
 
+@dataclasses.dataclass
+class LaunchOptions:
+    """Everything that changes WHICH launches a pass consists of (not their results): the A/B and test hooks of the model.  One object,
+    so that the tags of the captured graphs are derived from it (`tag()`) instead of being enumerated by hand at every capture site
+    -- an option that is missing from a tag replays a graph captured under the other setting.  Every field is also readable / writable
+    as an attribute of the model (`model.resconv = False`); the finished A/Bs of earlier rounds (text layers as riders of the
+    mel-encoder launches, CU halves for the prenet, duration-predictor riders) are no longer options: their winners are the code."""
+    resconv: bool = True            # long row spaces: residual stacks on efts_resconv5 (False: efts_gemm + fp32 stream)
+    resconv_min_rows: int = 16384   # ... from this many rows on (shorter ones keep the fp32 stream + efts_gemm, whose 124-row tiles fill the chip better)
+    side_stream: bool = True        # text-length work on a second HIP stream beside the mel-length kernels
+    fuse_prenet: bool = True        # the prenet straight from the fp32 frames (efts_frame_linear); False: efts_pack_rows + efts_gemm
+    fuse_soft_index: bool = True    # T1 <= 128: q.k^T, softmax and soft index in one launch (False: scores stored, efts_attn_soft_index)
+    fuse_align: bool = True         # imv scan + aligned positions + duration target in one launch (efts_imv_align)
+    fuse_expand: bool = True        # T1 <= 256: alpha' generated in registers inside the expand contraction (efts_expand)
+    embed_conv: bool = True         # eval paths: embedding + text-encoder layer 0 as table look-ups (efts_embed_conv)
+    small_m: bool = True            # free-running inference on short row spaces: the K-split small-M tiling of efts_gemm
+    small_m_rows: int = 1024        # ... up to this many rows
+
+    def tag(self) -> tuple:
+        return dataclasses.astuple(self)
+
+
 class EfficientTTSCNN(torch.nn.Module):
     """EFTS-CNN acoustic model (drop-in for nntts.models.EfficientTTSCNN).
 
@@ -198,25 +221,14 @@ class EfficientTTSCNN(torch.nn.Module):
         self.decoder = _ResConvBlock(n_decoder_layer, n_channels, k_size, a, ap, dropout_rate, use_weight_norm)
         self.mel_output_layer = torch.nn.Linear(n_channels, odim)
         self.duration_predictor = _DurationPredictor(n_channels, n_duration_layer, n_channels, offset=duration_offset)
-        self.fuse_prenet = True             # the prenet straight from the fp32 frames (efts_frame_linear); False: efts_pack_rows + efts_gemm
-        self.fuse_soft_index = True         # T1 <= 128: q.k^T, softmax and soft index in one launch (False: scores stored, efts_attn_soft_index)
-        self.small_m = True                 # free-running inference on short row spaces (<= SMALL_M_ROWS rows): the K-split small-M tiling of efts_gemm
+        self.opt = LaunchOptions()          # launch-affecting options (A/B and test hooks): also plain attributes of the model, see below
         self._free_running = False          # set while inference() / inference_batch() enqueue their launches
-        self.embed_conv = True              # eval paths: embedding + text-encoder layer 0 as table look-ups (efts_embed_conv) instead of a 21-GFLOP launch
-        self.ride_duration = False          # merged mode: the duration predictor's k3 convolutions ride in decoder launches 0, 2, LayerNorms on the second stream
-                                            # (measured 1.665 vs 1.633 ms: a rider costs a whole tile step of the 13, off by default)
-        self.share_cus = True               # merged mode: the prenet and the first text layers run side by side on disjoint halves of the CUs
-        self.merge_text = True              # text-encoder layers ride in the persistent launches of the mel-encoder layers (efts_resconv5_multi)
-        self.fuse_align = True              # imv scan + aligned positions + duration target in one launch (efts_imv_align)
-        self.fuse_expand = True             # T1 <= 256: alpha' generated in registers inside the expand contraction (efts_expand); False: reconst_alpha + pack_vt + efts_gemm
         self.graphs = True                  # plain eval calls replay a per-shape hipGraph (False: every kernel launched eagerly)
         self._graph_cache = GraphCache()
         self.graph_policy = "auto"          # teacher-forced forward: "auto" = a shape replays a graph only where launch latency is not
                                             # hidden by the device time anyway (graphs.GraphCache.run, adaptive); "always" = every shape
         self._len1 = {}
         self._infer_cache = GraphCache(capacity=64)      # free-running inference: two phases per (bucketed) shape
-        self.side_stream = True             # text-length work on a second HIP stream beside the mel-length kernels
-        self.resconv = True                 # long row spaces: residual stacks on efts_resconv5 (False: efts_gemm + fp32 stream, A/B and tests)
         self.dropout_seed = 0x5EED          # base seed of the train-mode dropout masks (mixed with the data-parallel rank and the step counter)
         self._drop_now = None               # set while a train()-mode gradient-free forward enqueues its launches: (conv p, k -> seed, duration p, (seed0, seed1))
         self.dropout_calls = 0              # training steps taken so far: the position in the mask sequence (the trainer restores it from the step count on --resume)
@@ -434,11 +446,6 @@ class EfficientTTSCNN(torch.nn.Module):
         return ws
 
     # ------------------------------------------------------------------ building blocks
-    # row spaces of at least this many rows run their residual stacks on efts_resconv5 (hi/lo planes, one persistent
-    # 8-wave workgroup per CU); shorter ones keep the fp32 stream + efts_gemm, whose 124-row tiles fill the chip better
-    RESCONV_MIN_ROWS = 16384
-
-    SMALL_M_ROWS = 1024
 
     def _til(self, rows: int):
         """efts_gemm tiling for a 512-column launch over `rows` rows: the small-M kernel (64 x 32 tiles, K split across the waves:
@@ -576,13 +583,6 @@ class EfficientTTSCNN(torch.nn.Module):
             x_p = self._duration_norm(ws, rs1, i, gap1, out_mask_ptr, mode)
         return ws.tensor("dur_out", (rs1.rows,))
 
-    def _duration_conv_kw(self, ws, pk, rs1: Rows, i: int, x_p: Plane) -> dict:
-        """Conv1d(k3) + ReLU of duration-predictor layer i (duration_predictor.py:57) as an efts_resconv5 layer without a residual
-        term (slope 0 = ReLU), fp32 output for the LayerNorm: what rides in a decoder launch"""
-        C = self.n_channels
-        return dict(x=x_p, w=pk[f"dur.{i}"], m=rs1.rows, n=C, bias=self.duration_predictor.conv[i][0].bias, slope=0.0,
-                    y_f32_ptr=ws.f32("dur_f", rs1, C).ptr, ldo=C, taps=3, no_residual=True)
-
     def _duration_norm(self, ws, rs1: Rows, i: int, gap1, out_mask_ptr, mode: int) -> Optional[Plane]:
         """LayerNorm behind conv i (duration_predictor.py:58-61): -> the next conv's operand plane, or (last layer) + Linear(C, 1) ->
         the predicted log-durations in ws "dur_out" """
@@ -664,7 +664,7 @@ class EfficientTTSCNN(torch.nn.Module):
         key = ("fwd", tuple(text.shape), tuple(speech.shape), text.dtype, speech.dtype, text_lengths.dtype, speech_lengths.dtype)
         ws = self._workspace(("fwd", text.shape[0], text.shape[1], speech.shape[1]), dev)
         # the graph is valid while the buffers its launches point at live: this workspace, the packed planes, the parameters
-        tag = (ws.serial, self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.side_stream, self.RESCONV_MIN_ROWS, self.fuse_soft_index, self.fuse_prenet, self.fuse_align, self.fuse_expand, self.merge_text, self.share_cus, self.ride_duration, self.embed_conv, self._te0_ptr())
+        tag = (ws.serial, self._ptr_sig, tuple(w.ptr for w in pk.values()), self.opt.tag(), self._te0_ptr())
 
         def body(t, tl, sp, sl):
             (_, stats, imv, ralpha, mel_pred, _), _ = self._forward_impl(t, tl, sp, sl)
@@ -715,9 +715,8 @@ class EfficientTTSCNN(torch.nn.Module):
             O.row_masks(ml, rs2, gap2, len2)                                      # :139 (in FRONT of the fork: the prenet on the side stream reads gap2)
         side.wait_stream(main)
         vt = None if self._fused_expand(T1) else ws.raw_plane("vt", B * C, T1, 2)
-        dec_rider = dec_after = None
         nt, nm = len(self.text_encoder.layers), len(self.mel_encoder.layers)
-        merged = self.merge_text and self._on_resconv(rs2) and nt >= 1 and nm >= 1
+        merged = self._on_resconv(rs2) and nt >= 1 and nm >= 1
         v_ready = torch.cuda.Event()
 
         def prenet(max_wgs=0):                                                    # :161
@@ -759,7 +758,7 @@ class EfficientTTSCNN(torch.nn.Module):
             # prenet is bound by HBM -- which half the CUs saturate -- and a text-length layer by streaming its weights, so the
             # prenet's grid is capped at half the CUs and the text layers are scheduled onto the other half.
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
-            share = self.share_cus and ns > (1 if self._te0_table(pk) is not None else 0) and cus >= 64
+            share = ns > (1 if self._te0_table(pk) is not None else 0) and cus >= 64
             with O.on_stream(side):
                 pre = prenet(cus // 2 if share else 0)
                 pre_ready.record(side)
@@ -790,38 +789,10 @@ class EfficientTTSCNN(torch.nn.Module):
             te_done.record(main)
             key_p = self._key_proj(ws, pk, rs1, tstate["x_p"], gap1, len1)          # :149, :155-156 (q.k^T is next on this stream)
             side.wait_event(te_done)
-            ndur, ndec = len(self.duration_predictor.conv), len(self.decoder.layers)
-            ride_dur = self.ride_duration and 2 * ndur - 1 <= ndec
-            with O.on_stream(side):                                               # the value projection beside the key projection
-                val_f, val_p = self._value_proj(ws, pk, rs1, tstate["x_p"], gap1, len1, vt)   # :150-157
-                v_ready.record(side)
-                if not ride_dur:
-                    dur = self._duration(ws, pk, rs1, val_p, gap1, len1.data_ptr(), 0)    # :219
-            if ride_dur:
-                # The duration predictor (:219) is needed by the loss only.  Its k3 convolutions ride in decoder launches 0, 2, ...
-                # (efts_resconv5 layers without a residual term: +13 us each) and its LayerNorms run on the second stream beside
-                # launches 1, 3, ...: nothing of it competes with q.k^T / the alignment block / the expand launch any more, and
-                # nothing of it is still on the CUs when the decoder's first persistent launch wants them.
-                dstate = dict(x_p=val_p, ev=None)
-
-                def dec_rider(i):
-                    if i % 2 or i // 2 >= ndur:
-                        return None
-                    if dstate["ev"] is not None:
-                        main.wait_event(dstate["ev"])                             # the LayerNorm in front of this convolution
-                    return self._duration_conv_kw(ws, pk, rs1, i // 2, dstate["x_p"])
-
-                def dec_after(i):
-                    if i % 2 or i // 2 >= ndur:
-                        return
-                    done = torch.cuda.Event()
-                    done.record(main)
-                    side.wait_event(done)
-                    with O.on_stream(side):
-                        dstate["x_p"] = self._duration_norm(ws, rs1, i // 2, gap1, len1.data_ptr(), 0)
-                        dstate["ev"] = torch.cuda.Event()
-                        dstate["ev"].record(side)
-                dur = ws.tensor("dur_out", (rs1.rows,))
+            with O.on_stream(side):                                               # the value projection beside the key projection, then the
+                val_f, val_p = self._value_proj(ws, pk, rs1, tstate["x_p"], gap1, len1, vt)   # :150-157   duration predictor (:219;
+                v_ready.record(side)                                              # needed by the loss only).  (Its k3 convolutions as riders of
+                dur = self._duration(ws, pk, rs1, val_p, gap1, len1.data_ptr(), 0)    # decoder launches: measured slower, 1.665 vs 1.633 ms, r3.)
         else:
             # second HIP stream: the text-side launches fill the tail rounds of the mel-length kernels
             k_ready = torch.cuda.Event()
@@ -861,7 +832,7 @@ class EfficientTTSCNN(torch.nn.Module):
 
         main.wait_event(v_ready)
         mel = self._expand_decode(ws, pk, B, T1, rs1, rs2, val_f, e, tl, ml, ralpha, len2.data_ptr(), gap2, vt=vt,
-                                  rider=dec_rider, after=dec_after)                                          # :184-200
+                                  )                                                                          # :184-200
         main.wait_stream(side)                                                     # duration predictor done
 
         out3 = torch.empty(3, dtype=torch.float32, device=dev)                     # :220-227
@@ -1019,7 +990,7 @@ class EfficientTTSCNN(torch.nn.Module):
             T1b = roundup(T1, self.T1_BUCKET) if graphs else T1
             pk = self._weights()
             self._te0_table(pk)                               # (built outside the graphs, like the packed planes)
-            wsig = (self._ptr_sig, tuple(w.ptr for w in pk.values()), self.resconv, self.RESCONV_MIN_ROWS, self.fuse_expand, self.small_m, self.SMALL_M_ROWS, self.embed_conv, self._te0_ptr())
+            wsig = (self._ptr_sig, tuple(w.ptr for w in pk.values()), self.opt.tag(), self._te0_ptr())
             ws = self._workspace(("infb", B, T1b), dev)
             if graphs:
                 def phase1(t, l):
@@ -1054,3 +1025,13 @@ class EfficientTTSCNN(torch.nn.Module):
                 mel, ralpha = self._infer_mel(ws, ws2, e, tl, ml, T2b)
                 ml = ml.to(torch.int64) if want_lengths else ml
             return mel, ml, ralpha
+
+
+def _opt_property(name: str):
+    return property(lambda self: getattr(self.opt, name), lambda self, v: setattr(self.opt, name, type(getattr(LaunchOptions(), name))(v)))
+
+
+for _f in dataclasses.fields(LaunchOptions):
+    setattr(EfficientTTSCNN, _f.name, _opt_property(_f.name))
+EfficientTTSCNN.RESCONV_MIN_ROWS = _opt_property("resconv_min_rows")      # (the names tests and tools of earlier rounds use)
+EfficientTTSCNN.SMALL_M_ROWS = _opt_property("small_m_rows")

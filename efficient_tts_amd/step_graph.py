@@ -10,7 +10,7 @@ state and every result are bit-identical to the eager loop's (tests/test_gpu_tra
 
 Data parallel (round 4): `GraphedStep(DistributedEFTS(model), ...)` captures the three bucket collectives too.  The reducer issues
 them as stream-ordered synchronous ops on its communication stream (dist.py), which is a plain fork of the capturing stream joined
-back in front of the optimizer launch -- the only dependency shape ROCm 7.2's capture handles (tools/gpu_probe_capture4.py) -- so
+back in front of the optimizer launch -- the only dependency shape ROCm 7.2's capture handles (tools/attic/gpu_probe_capture4.py) -- so
 a replay contains forward, backward, the RCCL exchanges overlapped with the backward, clip and Adam, and an 8-process host issues
 one launch per step instead of ~190.
 
@@ -24,6 +24,7 @@ from collections import OrderedDict
 import torch
 
 from . import ops as O
+from . import train as T
 from .autograd import engine_of
 from .model import LazyStats
 from .optim import EftsAdam
@@ -62,7 +63,8 @@ class GraphedStep:
         m, g = self.model, self.opt.param_groups[0]
         red = self.ddp.reducer if self.ddp is not None else None
         return (ws.serial, id(eng), getattr(m, "_ptr_sig", None), float(self.opt.grad_norm), self.grad_scale, tuple(g["betas"]), float(g["eps"]),
-                float(g["weight_decay"]), bool(m.training), id(red), None if red is None else red.algo, eng.bucket_hook is not None)
+                float(g["weight_decay"]), bool(m.training), id(red), None if red is None else red.algo, eng.bucket_hook is not None,
+                m.opt.tag(), T.switch_tag())
 
     def _refresh(self, eng) -> None:
         """the words of the step about to run: Adam's scalars for step t + 1 and the Dropout step word of call dropout_calls + 1"""

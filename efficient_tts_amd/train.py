@@ -23,19 +23,25 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-_WGRAD_TN_SPLITS = 8         # K-splits of the direct (row-major) k5 wgrad; 0 disables it (A/B: bench.py --train-set _WGRAD_TN_SPLITS=...)
+# Test / A-B hooks of the training pass (module-level: bench.py --train-set NAME=INT, tests).  `switch_tag()` is what a captured step
+# (step_graph.GraphedStep) is valid for.  Finished A/Bs of earlier rounds are no longer switches: the direct wgrad for taps 1 / 3
+# (was _WGRAD_TN_SMALL) and the prenet through efts_frame_linear (was _FRAME_PRENET) are simply the code.
+_WGRAD_TN_SPLITS = 8         # K-splits of the direct (row-major) wgrad; 0 = everything through the transposed planes + split-K efts_gemm (the path the
+                             # 80-channel layers always take: tests compare the two)
 _SIGN_MIN_ROWS = 16384       # row spaces from here on: the forward convolutions of the stacks write the activation's sign words
                              # (efts_gemm `sign_mask`) and efts_act_bwd reads those instead of y and x in fp32 (14 -> 6 B per element);
                              # shorter ones (the text side) keep the narrow tiling, which does not write them.  0 = never
-_WGRAD_TN_SMALL = 1          # key / value / query Linears and the duration predictor's k3 convolutions: weight gradient straight from
-                             # the row-major planes too (taps 1 / 3) instead of two transposed copies + a split-K efts_gemm (0: the latter)
-_BIAS_PARTS = 1              # direct-wgrad layers: bias gradient as per-row-block sums finished by the wgrad reduction (0: atomics in act_bwd)
+_BIAS_PARTS = 1              # direct-wgrad layers: bias gradient as per-row-block sums finished by the wgrad reduction (0: atomics in act_bwd; tests compare)
 _RESCONV_FWD = 3             # residual stacks whose FORWARD runs on efts_resconv5 when their row space is long enough: bit 0 decoder,
                              # bit 1 mel encoder (A/B: bench.py --train-set _RESCONV_FWD=...)
 _RESCONV_DGRAD = -1          # ... and whose DGRAD does (same bits as efts_gemm's); -1: decoder (bf16) / decoder + mel encoder (bf16x3), measured best:
                              # 3.72 -> 3.58-3.61 ms per B = 32 step with both switches (bf16), 6.96 -> 6.62-6.64 (bf16x3), tools/train_ab.sh
-_FRAME_PRENET = 1            # prenet without Dropout straight from the caller's frames (efts_frame_linear); 0: efts_gemm over the packed mel plane
 _WGRAD_WGS = 480             # split-K target: 480 workgroups per wgrad launch measured best (6.30 vs 6.60 ms/step at 640)
+
+
+def switch_tag() -> tuple:
+    """every hook above, by value: part of the tag of a captured training step"""
+    return (_WGRAD_TN_SPLITS, _SIGN_MIN_ROWS, _BIAS_PARTS, _RESCONV_FWD, _RESCONV_DGRAD, _WGRAD_WGS)
 
 
 class _TPlane(Plane):
@@ -172,7 +178,7 @@ class TrainEngine:
 
     def _wgrad_any(self, ws, dz_f_ptr, dz_p: Optional[Plane], x_f_ptr, x_p: Optional[Plane], cout, cin, taps, rows, out_dw):
         """un-normed weights: the direct kernel when both operand planes exist in one format and the shape fits its tiles"""
-        if (_WGRAD_TN_SMALL and _WGRAD_TN_SPLITS > 0 and dz_p is not None and x_p is not None and dz_p.split == x_p.split
+        if (_WGRAD_TN_SPLITS > 0 and dz_p is not None and x_p is not None and dz_p.split == x_p.split
                 and cout % 128 == 0 and cin % 64 == 0 and taps in (1, 3, 5)):
             self._wgrad_tn(ws, dz_p, x_p, cout, cin, rows, None, None, out_dw, None, taps=taps)
         else:
@@ -389,7 +395,7 @@ class TrainEngine:
         pre_f, pre_p = ws.f32("Tpre_f", rs2, C), ws.plane("Tpre_p", rs2, C, split)
         wp = pk["prenet"]
         pre_dp, pre_seed = self._conv_drop(40)                       # mel_prenet's Dropout (efficient_tts.py:76-80)
-        if _FRAME_PRENET and pre_dp == 0.0 and m.fuse_prenet and odim % 8 == 0 and odim <= 128 and C % 128 == 0:
+        if pre_dp == 0.0 and m.fuse_prenet and odim % 8 == 0 and odim <= 128 and C % 128 == 0:
             # no Dropout on the prenet (the shipped recipe): straight from the caller's frames, whole-line stores (efts_frame_linear;
             # bit-identical to the launch below)
             O.frame_linear(x=speech, w=wp, bias=m.mel_prenet[0].bias, act=L.ACT_LEAKY, slope=m.slope, rs=rs2, y=pre_p, y_f32=pre_f)

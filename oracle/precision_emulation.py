@@ -5,7 +5,7 @@ oracle (oracle/efts_oracle.py) computes with
   "bf16"   : operands rounded to bf16, fp32 accumulate
   "bf16x3" : a = a_hi + a_lo (two bf16), product = hi*hi + hi*lo + lo*hi, fp32 accumulate
   "fp32"   : unchanged
-Used by tools/precision_study.py (design study) and by the gradient parity tests: the HIP backward
+Used by tools/attic/precision_study.py (design study) and by the gradient parity tests: the HIP backward
 must agree tightly with autograd of the oracle run in the SAME operand mode, while the distance to
 the fp32 oracle is the (documented) sensitivity of the alignment block to that mode.
 """

@@ -1,6 +1,6 @@
 """k5 conv at B=64 / 32: gemm_kernel vs conv5_kernel vs conv8_kernel (8 waves, 256 x 256 tile): equality and time"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from efficient_tts_amd import lib as L, ops as P
 dev = torch.device("cuda:0"); L.load(); L.require_device()

@@ -1,7 +1,7 @@
 """conv8 (one 8-wave workgroup per CU, 256 x 256 tile) at growing grids: per-tile time with 52 ... 408 workgroups.
 Question: is the time outside the main loop (epilogue, prologue) the HBM burst of all CUs at once?"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from efficient_tts_amd import lib as L, ops as P
 dev = torch.device("cuda:0"); L.load(); L.require_device()

@@ -1,6 +1,6 @@
 """k5 conv at B=64, 124-row kernel, debug instantiation: EFTS_GEMM_DBG ablation bits from the command line"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from efficient_tts_amd import lib as L, ops as P
 dev = torch.device("cuda:0"); L.load(); L.require_device()

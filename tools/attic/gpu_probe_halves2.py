@@ -1,6 +1,6 @@
 """Throughput of P independent B=64/P forward pipelines, each driven eagerly by its own host thread on its own stream"""
 import os, sys, threading, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from efficient_tts_amd import EfficientTTSCNN
 dev = torch.device("cuda:0")

@@ -2,7 +2,7 @@
 (63 groups x 2 column tiles = 126 workgroups of two tiles), started half a layer apart: do the epilogue bursts of one chain hide
 under the main loops of the other?"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from efficient_tts_amd import lib as L, ops as P
 dev = torch.device("cuda:0")

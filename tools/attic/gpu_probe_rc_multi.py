@@ -1,6 +1,6 @@
 """efts_resconv5_multi: time of a grouped launch (mel-length layer + text-length layer) against single launches (us)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 from test_resconv_gpu import Case, C, _dev

@@ -1,7 +1,7 @@
 """Isolated launch times of the short-K / few-step efts_gemm launches on the mel chain of the B=64 forward (prenet, q.k^T,
 alpha'.V, mel head), by tiling and by output streams (timing only, random operands).  PB / PT1 / PT2: shape."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from efficient_tts_amd import lib as L, ops as P
 dev = torch.device("cuda:0"); L.load(); L.require_device()

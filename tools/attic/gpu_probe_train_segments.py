@@ -1,7 +1,7 @@
 """Training step B=32: device time of the segments of the fused forward + backward on the main stream (events at the engine's
 marks), un-profiled, median of 20 steps."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from efficient_tts_amd import EfficientTTSCNN
 from efficient_tts_amd.autograd import engine_of

@@ -1,6 +1,6 @@
 """TN wgrad kernel vs a float64 reference and vs the transposed-plane path; timing"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from efficient_tts_amd import lib as L, ops as P
 dev = torch.device("cuda:0"); lib = L.load(); L.require_device()

@@ -5,7 +5,7 @@
 Prints max-abs error of each output vs the fp32 oracle on the golden inputs."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import efts_oracle as O
 
 from oracle.precision_emulation import Mode  # noqa: E402
