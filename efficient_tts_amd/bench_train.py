@@ -117,11 +117,12 @@ def measure_train(a, world, rank, dev, wl, steps, warmup, precision=None):
 
     rows = P.Rows(B, T2).rows
     want_graph = bool(getattr(a, "train_graph", 1))
-    selfcheck, dp_stats, eager_dt, graph_dt, graph_note = None, None, None, None, None
+    selfcheck, dp_stats, eager_dt, graph_dt, graph_note, poisoned = None, None, None, None, None, False
     if world > 1:
         # ---- (1) self-validation before anything is timed
         backend = dist.get_backend()
-        assert backend == "nccl", f"data-parallel runs use the RCCL backend ('nccl'), got {backend!r}"
+        # (tests/test_dist_gpu.py drives this very code with two ranks sharing the test GPU, which only gloo allows)
+        assert backend == "nccl" or getattr(a, "allow_gloo", False), f"data-parallel runs use the RCCL backend ('nccl'), got {backend!r}"
         for _ in range(2):
             step()
         torch.cuda.synchronize()
@@ -137,28 +138,42 @@ def measure_train(a, world, rank, dev, wl, steps, warmup, precision=None):
         durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in P.PROFILE if tag == (5, rows, 512)]
         P.PROFILE, P.PROFILE_TAG = None, None
         dp_stats = ddp.reducer.stats()
-        # ---- (3) the step as one hipGraph replay per rank, collectives inside
-        if want_graph:
-            graphed = GraphedStep(ddp, opt, sch)
-            ok = 1
+        lv_eager = float(loss)
+        # ---- (3) the step as one hipGraph replay per rank, collectives inside.  LAST device work of the measurement, and fenced: a
+        # capture that fails half-way can leave its forked streams in capture mode (ROCm 7.2), after which any use of the default stream
+        # raises -- the eager numbers above must survive that, so everything from here on is inside one try, and the record is put
+        # together from host values only.  gloo cannot be captured at all (its collectives synchronise the host): not attempted.
+        poisoned = False
+        if want_graph and backend != "nccl":
+            graph_note = f"{backend} collectives cannot be captured; eager loop timed"
+        elif want_graph:
             try:
-                for _ in range(max(warmup, 3)):               # eager, capture, replays
-                    loss = graphed(text, tl, mel, sl)[0]
-                torch.cuda.synchronize()
-                ok = int(graphed.replays >= 1)
-            except Exception as exc:                           # noqa: BLE001 -- reported, the eager measurement stands
-                ok, graph_note = 0, f"capture failed on rank {rank}: {exc}"[:300]
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # every rank replays, or none does
-            if int(flag.item()) == 1:
-                r0 = graphed.replays
-                graph_dt, loss = timed(lambda: graphed(text, tl, mel, sl)[0], steps)
-                assert graphed.replays - r0 == steps, "the timed steps were not graph replays"
-                same2, every2 = fingerprints()
-                assert same2, "data-parallel replicas diverged under graph replays: " + str([e.tolist() for e in every2])
-                selfcheck["replicas_bit_identical_after_graph_replays"] = same2
-            elif graph_note is None:
-                graph_note = "capture failed on another rank; eager loop timed"
+                graphed = GraphedStep(ddp, opt, sch)
+                ok = 1
+                try:
+                    for _ in range(max(warmup, 3)):           # eager, capture, replays
+                        loss = graphed(text, tl, mel, sl)[0]
+                    torch.cuda.synchronize()
+                    ok = int(graphed.replays >= 1)
+                except Exception as exc:                       # noqa: BLE001 -- reported, the eager measurement stands
+                    ok, graph_note = 0, f"capture failed on rank {rank}: {exc}"[:300]
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # every rank replays, or none does
+                if int(flag.item()) == 1:
+                    r0 = graphed.replays
+                    gdt, loss = timed(lambda: graphed(text, tl, mel, sl)[0], steps)
+                    assert graphed.replays - r0 == steps, "the timed steps were not graph replays"
+                    same2, every2 = fingerprints()
+                    assert same2, "data-parallel replicas diverged under graph replays: " + str([e.tolist() for e in every2])
+                    selfcheck["replicas_bit_identical_after_graph_replays"] = same2
+                    lv_eager = float(loss)
+                    graph_dt = gdt
+                elif graph_note is None:
+                    graph_note = "capture failed on another rank; eager loop timed"
+            except Exception as exc:                           # noqa: BLE001
+                poisoned = True
+                graph_dt = None
+                graph_note = ((graph_note + "; ") if graph_note else "") + f"graph attempt abandoned on rank {rank}: {exc}"[:300]
         dt = graph_dt if graph_dt is not None else eager_dt
         issue = "one hipGraph replay per step and rank, bucket collectives captured (step_graph.GraphedStep)" if graph_dt is not None else "eager launches"
     else:
@@ -182,7 +197,7 @@ def measure_train(a, world, rank, dev, wl, steps, warmup, precision=None):
         durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in P.PROFILE if tag == (5, rows, 512)]
         P.PROFILE, P.PROFILE_TAG = None, None
         issue = "one hipGraph replay per step (step_graph.GraphedStep)" if graphed is not None else "eager launches"
-    lv = float(loss)
+    lv = lv_eager if world > 1 else float(loss)
     assert lv == lv, "NaN loss"
     avg = sum(durs) / max(len(durs), 1)
     conv_flop = 2.0 * B * T2 * 512 * 512 * 5
@@ -216,6 +231,8 @@ def measure_train(a, world, rank, dev, wl, steps, warmup, precision=None):
                              avg_launch_us=avg * 1e6, launches_measured=len(durs)))
     if graph_note:
         res["config"]["graph_note"] = graph_note
+    if world > 1 and poisoned:
+        res["config"]["device_state"] = "a failed capture left streams in capture mode: no further device work in this process"
     if ddp is not None:
         # the last eager step's communication: one record that explains the scaling number (backend, ranks, algorithm,
         # bytes and time per bucket, how much of it the backward did NOT hide)

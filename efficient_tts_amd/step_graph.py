@@ -113,6 +113,15 @@ class GraphedStep:
                 except Exception as exc:                              # noqa: BLE001
                     logging.warning("hipGraph capture of the training step failed (%s): this shape stays on eager launches", exc)
                     ent["eager_only"] = True
+                    # streams that were forked into the failed capture may be left in capture mode: never use them again
+                    object.__setattr__(m, "_side", None)
+                    if self.ddp is not None and self.ddp.reducer is not None and self.ddp.reducer.comm_stream is not None:
+                        self.ddp.reducer.comm_stream = torch.cuda.Stream(device=dev)
+                        self.ddp.reducer.pending, self.ddp.reducer.events = False, {}
+                    try:
+                        torch.cuda.graph.default_capture_stream = None
+                    except Exception:                             # noqa: BLE001
+                        pass
                     eng.step_words = None
                     m.dropout_calls = calls0
                     torch.cuda.synchronize()

@@ -141,3 +141,47 @@ def test_rccl_one_rank_group_runs_the_bucketed_exchange_eager_and_captured(tmp_p
     assert rec["backend"] == "nccl" and rec["world"] == 1
     for algo in ("allreduce", "rs_ag"):
         assert rec[f"graph_{algo}"]["replays"] >= 3 and len(rec[f"step_{algo}"]["stats"]["bucket_ms"]) == 3
+
+
+def _bench_worker(rank, port, out):
+    import sys
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    from efficient_tts_amd.bench_train import measure_train
+    a = types.SimpleNamespace(precision="bf16", train_set=[], dp_algo="allreduce", train_graph=1, allow_gloo=True)
+    wl = dict(B=3, T1=40, T2=130, desc="test shape")
+    rec = measure_train(a, 2, rank, dev, wl, steps=3, warmup=2)
+    if rank == 0:
+        with open(out, "w") as f:
+            json.dump(rec, f)
+    else:
+        assert rec is None
+    dist.destroy_process_group()
+
+
+def test_bench_dp_record_two_ranks():
+    """bench.py's data-parallel measurement (efficient_tts_amd/bench_train.measure_train at world > 1: what the driver's N > 1 runs
+    execute on every rank) driven end to end by two ranks that share the test GPU -- gloo, the only backend that allows that: the
+    pre-timing self-check (bit-exact replica fingerprints), the eager loop with per-bucket events, the attempt to capture the step with
+    its collectives (gloo cannot be captured: both ranks must agree on that through the all-reduce and fall back to the eager number,
+    without hanging), and the record with its `dp` block."""
+    import tempfile
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "rec.json")
+        mp.spawn(_bench_worker, args=(port, out), nprocs=2, join=True)
+        rec = json.load(open(out))
+    assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["steps"] == 3
+    dp = rec["dp"]
+    assert dp["ranks"] == 2 and dp["selfcheck"]["replicas_bit_identical"] and len(dp["bucket_ms"]) == 3 and abs(sum(dp["bucket_mb"]) - 82.35) < 0.01
+    assert rec["eager_ms_per_step"] > 0 and rec["value"] > 0
+    if rec["graph_ms_per_step"] is None:                      # (gloo: the capture fails on every rank alike)
+        assert "eager" in rec["config"]["step_issue"]
+    else:
+        assert dp["selfcheck"]["replicas_bit_identical_after_graph_replays"]

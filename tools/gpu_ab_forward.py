@@ -1,5 +1,5 @@
 """A/B of model switches inside one process, arms interleaved: python tools/gpu_ab_forward.py name=attr:val[,attr:val] ...
-e.g.  python tools/gpu_ab_forward.py base= merged=merge_text:1 unmerged=merge_text:0     (precisions bf16 and bf16x3, B=64)"""
+e.g.  python tools/gpu_ab_forward.py base= nosoft=fuse_soft_index:0 noexp=fuse_expand:0     (precisions bf16 and bf16x3, B=64; attributes = the fields of model.opt)"""
 import os
 import sys
 

@@ -16,11 +16,12 @@ build_one() {   # name, define
   $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $2 -c efficient_tts_amd/csrc/efts_resconv.hip -o /tmp/rc_$1.o
   $HIPCC --offload-arch=gfx950 -shared -fPIC -o lab/rc_$1.so $OBJS /tmp/rc_$1.o
 }
-build_one stamp -DRC_STAMP=1 &
-build_one phase -DRC_STAMP=2 &
-build_one marks -DRC_STAMP=3 &
-for e in ${EXPS:-}; do build_one exp$e -DRC_EXP=$e & done
-wait
+pids=""
+build_one stamp -DRC_STAMP=1 & pids="$pids $!"
+build_one phase -DRC_STAMP=2 & pids="$pids $!"
+build_one marks -DRC_STAMP=3 & pids="$pids $!"
+for e in ${EXPS:-}; do build_one exp$e -DRC_EXP=$e & pids="$pids $!"; done
+for p in $pids; do wait $p || { echo "LAB BUILD FAILED (pid $p)"; exit 1; }; done
 # every lab library must export what the ctypes binding asks for
 python - <<'PY'
 import ctypes, glob, sys
