@@ -46,8 +46,10 @@ FWD_FLOP_PER_ITEM = 21.43e9           # SURVEY.md 8d, (T1, T2) = (128, 800)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: long enough for the clock governor to settle (the chip runs this workload at its 1 400 W cap and ramps for tens of
+    # milliseconds: 5 + 20 steps measure 1-2 % slower than the sustained rate, profiles/bench_ramp_r04.txt); ~0.3 s of timed work
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
     ap.add_argument("--workload", default="fwd64", choices=["fwd64", "fwd16_long", "train32", "infer_lj", "infer64", "logmel64", "vocoder", "vocoder8", "rendezvous"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -64,7 +66,7 @@ def parse():
     ap.add_argument("--parity-mode", type=int, default=1, help="forward workloads in bf16: also time the bf16x3 parity-grade mode (same K / W) -> `parity_mode` in the JSON line")
     ap.add_argument("--train-graph", type=int, default=1, help="train32, one process: the step as one hipGraph replay (0: eager launches)")
     ap.add_argument("--call-modes", type=int, default=1, help="forward workloads, N=1: 10 extra steps per call mode (plain call / bench graph / eager) -> `call_modes`")
-    ap.add_argument("--train-record", type=int, default=1, help="fwd64, N=1: also time BASELINE config 3 (training step B=32, 10 steps) under the same invocation -> `train32` in the JSON line")
+    ap.add_argument("--train-record", type=int, default=1, help="fwd64, N=1: also time BASELINE config 3 (training step B=32, 40 steps) under the same invocation -> `train32` in the JSON line")
     ap.add_argument("--measure-traffic", type=int, default=1, help="forward workloads, N=1: roofline.traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) over a 2-step child run, when rocprofv3 is on the box; 0: the committed profiles/traffic.json")
     ap.add_argument("--rc-kernel", type=int, default=0, help="A/B: efts_resconv5_kernel(which): 0 / 1 the 8-wave ping-pong kernel (default), 2 the one-wave-per-SIMD kernel where it applies")
     return ap.parse_args()
@@ -718,15 +720,15 @@ def run_forward(a, world, rank, dev, wl):
             res["hip_vs_oracle_mel_max_abs"] = float((checks[a.precision] - ref).abs().max())
     if a.workload == "fwd64" and a.train_record and not os.environ.get("EFTS_BENCH_CHILD"):
         # ---- BASELINE configs 3 / 4 under the same invocation, on EVERY rank: the training step at B=32 per GPU (fwd + bwd + clip +
-        # Adam-amsgrad; N > 1: the bucketed RCCL gradient all-reduce overlapped with the backward -> its `dp` record), 10 steps; and
+        # Adam-amsgrad; N > 1: the bucketed RCCL gradient all-reduce overlapped with the backward -> its `dp` record), 40 steps; and
         # its parity-grade mode (bf16x3) under the same clock
         from efficient_tts_amd.bench_train import measure_train
         torch.cuda.empty_cache()
-        tr = measure_train(a, world, rank, dev, WORKLOADS["train32"], steps=10, warmup=3)
+        tr = measure_train(a, world, rank, dev, WORKLOADS["train32"], steps=40, warmup=10)
         trp = None
         if a.precision == "bf16" and a.parity_mode and not (rank == 0 and tr and tr["config"].get("device_state")):
             try:
-                trp = measure_train(a, world, rank, dev, WORKLOADS["train32"], steps=10, warmup=3, precision="bf16x3")
+                trp = measure_train(a, world, rank, dev, WORKLOADS["train32"], steps=40, warmup=10, precision="bf16x3")
             except Exception as exc:                                   # noqa: BLE001 -- the line must still be printed
                 trp = None
                 if rank == 0:

@@ -116,3 +116,40 @@ def test_make_plan_round_trip():
         assert buf[1] == len(classes)
         covered = (buf[0] // len(classes)) * sum(rows) + sum(rows[:buf[0] % len(classes)])
         assert covered >= m and covered - m < max(rows) + min(rows)
+
+
+def test_generated_main_loop_is_what_the_generator_writes(tmp_path):
+    """csrc/efts_rc4_loop.inc (the hand-scheduled main loop of efts_resconv5's one-wave-per-SIMD kernel) is generated: the committed
+    file must be exactly what tools/gen_rc4_asm.py produces, and the stream must have the shape the kernel's C++ side assumes --
+    per tile height h: three chunk bodies of 5 steps of 8 h MFMAs, every MFMA on its own accumulator block per k-slice, one barrier per
+    step plus the prologue's, staging loads / stores paired, all registers inside the declared clobber ranges."""
+    import importlib.util
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_rc4_asm", os.path.join(root, "tools", "gen_rc4_asm.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    committed = open(g.OUT).read()
+    g.OUT = str(tmp_path / "loop.inc")
+    g.main()
+    assert open(g.OUT).read() == committed, "efts_rc4_loop.inc is stale: run python tools/gen_rc4_asm.py"
+    for h in range(2, 9):
+        lines = g.Gen(h).build()
+        mf = [ln for ln in lines if ln.startswith("v_mfma")]
+        assert len(mf) == 3 * 5 * 8 * h
+        assert sum(1 for ln in lines if ln == "s_barrier") == 3 * 5 - 1 + 1          # one per step but the tile's last; + the prologue's
+        # per k-slice of 2 h MFMAs every accumulator block appears exactly once
+        for q in range(0, len(mf), 2 * h):
+            accs = [re.match(r"v_mfma_f32_32x32x16_bf16 a\[(\d+):", ln).group(1) for ln in mf[q:q + 2 * h]]
+            assert sorted(map(int, accs)) == [16 * b for b in range(2 * h)]
+        assert sum(1 for ln in mf if ln.endswith(", 0")) == 2 * h                      # the tile's first k-slice starts from zero
+        # staging: as many ds_write_b128 of weight pieces as buffer_loads of them (+ the prologue's 8 loads, - the final step's missing re-loads)
+        wl = sum(1 for ln in lines if ln.startswith("buffer_load_dwordx4") and f"v{g.VOW}" <= ln.split(", ")[1] <= f"v{g.VOW + 7}")
+        ww = sum(1 for ln in lines if ln.startswith("ds_write_b128") and f"v{g.WRW}," in ln)
+        assert ww == 3 * 5 * 8 and wl == ww
+        for ln in lines:                                                               # registers stay inside what the statement clobbers
+            for r in re.findall(r"\bv\[?(\d+)", ln):
+                assert g.V0 <= int(r) < g.VEND, ln
+            for r in re.findall(r"\bs\[?(\d+)", ln):
+                assert g.S0 <= int(r) < g.SEND, ln

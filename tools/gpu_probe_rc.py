@@ -18,7 +18,7 @@ def where(a, b, name):
         cols = (d[r0] > 0).nonzero().flatten()
         print(f"    {name}: {bad.numel()} bad rows of {a.shape[0]} (buffer rows, 8 guard rows first): first {bad[:6].tolist()} last {bad[-3:].tolist()};"
               f" row {r0}: {cols.numel()} bad cols, first {cols[:4].tolist()}, got {a[r0, cols[0]].item():.5f} want {b[r0, cols[0]].item():.5f}", flush=True)
-def timeit(fn, iters=50):
+def timeit(fn, iters=int(os.environ.get("PLOOP", "50"))):        # PLOOP: launches per timing sample (long loops for tools/gpu_power_trace.sh)
     for _ in range(5): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
