@@ -470,7 +470,7 @@ def _self_launch(a) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves -- this same command line under
     torch.distributed.run on 127.0.0.1 -- and pass rank 0's JSON line through.  Fails (non-zero) unless N ranks come up."""
     import socket
-    if a.workload != "rendezvous":
+    if a.workload != "rendezvous" and os.environ.get("EFTS_BENCH_BACKEND", "nccl") == "nccl":
         have = torch.cuda.device_count()
         if have < a.gpus:
             raise SystemExit(f"--gpus {a.gpus}: only {have} GPU(s) visible on this node; refusing to measure fewer ranks than asked for")
@@ -513,8 +513,12 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher must start exactly --gpus ranks")
     on_gpu = torch.cuda.is_available()
+    # EFTS_BENCH_BACKEND=gloo (tests only): the ranks share the visible GPUs, so the whole N > 1 code path of this script can be driven
+    # on a one-GPU box (RCCL needs a GPU per rank); the data-parallel record then says backend gloo and skips the captured step
+    backend = os.environ.get("EFTS_BENCH_BACKEND", "nccl")
+    a.allow_gloo = backend != "nccl"
     if a.workload != "rendezvous" or on_gpu:
-        dev = torch.device("cuda", local)
+        dev = torch.device("cuda", local if backend == "nccl" else local % max(torch.cuda.device_count(), 1))
         torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
@@ -525,7 +529,7 @@ def main():
             os.environ.setdefault("NCCL_DEBUG", "INFO")
             os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING")
             os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/efts_rccl_{os.getpid()}_%h_%p.log")
-        if on_gpu:
+        if on_gpu and backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")

@@ -185,3 +185,25 @@ def test_bench_dp_record_two_ranks():
         assert "eager" in rec["config"]["step_issue"]
     else:
         assert dp["selfcheck"]["replicas_bit_identical_after_graph_replays"]
+
+
+def test_bench_two_ranks_end_to_end():
+    """`python bench.py --gpus 2` as the driver's multi-GPU runs execute it -- self-launched ranks, replica forward in both precisions,
+    then the data-parallel training record on every rank -- on the ONE GPU of the test box: EFTS_BENCH_BACKEND=gloo lets the two ranks share
+    it (RCCL needs a GPU per rank).  One JSON line, n_gpus 2, the `train32` record with its `dp` block and both precisions."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["EFTS_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["config"]["parallelism"] == "replicas x2" and rec["scaling"] == "weak"
+    assert rec["parity_mode"]["ms_per_step"] > rec["ms_per_step"] > 0
+    tr = rec["train32"]
+    assert tr["n_gpus"] == 2 and tr["config"]["parallelism"] == "dp2" and tr["dp"]["ranks"] == 2 and tr["dp"]["selfcheck"]["replicas_bit_identical"]
+    assert len(tr["dp"]["bucket_ms"]) == 3 and tr["parity_mode"]["ms_per_step"] > 0
