@@ -44,6 +44,9 @@
 #ifndef RC_STAMP
 #define RC_STAMP 0
 #endif
+#ifndef RC_LAB_MIN
+#define RC_LAB_MIN 0
+#endif
 
 namespace efts {
 
@@ -578,6 +581,19 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
         const int nblk = c.wm ? h >> 1 : (h + 1) >> 1;      // 32-row blocks of this wave's row (wave-uniform)
         const bool fast = !pq.resid && pq.rowmask && pq.ob && !pq.out_f32 && !pq.sign && !pq.no_resid &&
                           (SPLIT == 1 ? (pq.a_lo && pq.ob_lo && pq.out_split == 1) : pq.out_split == 2);
+#if RC_LAB_MIN
+        // lab builds (tools/lab_build.sh): only the variant the probes launch -- 5 taps, planes in and out -- is instantiated.  With all 24
+        // tile variants AND the stamping code inlined into one kernel the register allocator runs out, the wave-uniform operands of the
+        // LDS-DMA statements come back from spill slots in VGPRs and the build fails ("s" constraint) or, forced through readfirstlane,
+        // spills 60-100 VGPRs into the main loop; the product build (no stamps) has 223 VGPRs and no scratch.
+        (void)fast;
+        switch (nblk) {
+            case 1: rc_tile<SPLIT, 1, 5, true>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+            case 2: rc_tile<SPLIT, 2, 5, true>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+            case 3: rc_tile<SPLIT, 3, 5, true>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+            default: rc_tile<SPLIT, 4, 5, true>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
+        }
+#else
         if (pq.taps == 3) {
             switch (nblk) {
                 case 1: rc_tile<SPLIT, 1, 3, false>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
@@ -600,6 +616,7 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
                 default: rc_tile<SPLIT, 4, 5, false>(p, pq, pn, c, m0, h, rows_out, m1, h1); break;
             }
         }
+#endif
         RC_MARK(p, c);
         if (h1 > 0 && pi1 != pi) bias_of(pn);
         c.w_base = c.w_next; c.wts = c.wts_next;

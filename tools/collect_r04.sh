@@ -8,7 +8,7 @@ O=$R/gpurun_out/collect
 mkdir -p $O
 cd $R
 TAGR=${TAGR:-r04}
-EXPS="1 8 9" bash tools/lab_build.sh > $O/lab_build.log 2>&1
+EXPS="1 8 9 4" bash tools/lab_build.sh > $O/lab_build.log 2>&1
 probe() {   # name, lab library, script, env...
   local out=$O/$1; local lib=$2; local script=$3; shift 3
   env "$@" EFTS_LIB=$R/lab/$lib timeout 300 python $script > $out 2>&1 || { echo "PROBE FAILED: $out"; tail -5 $out; exit 1; }
@@ -18,8 +18,8 @@ probe() {   # name, lab library, script, env...
 if grep -q Traceback $O/rc_stamps_$TAGR.txt; then echo "PROBE FAILED (traceback): stamps"; exit 1; fi
 probe rc_phases_$TAGR.txt rc_phase.so tools/gpu_probe_rc_phases.py
 probe rc_marks_$TAGR.txt rc_marks.so tools/gpu_probe_rc_marks.py
-# ablations of the ping-pong kernel (us per B = 64 launch): all / no LDS-DMA / no epilogue traffic / neither  (the "no MFMA" build, -DRC_EXP=4, no longer compiles next to the FAST epilogue variants: its LDS-DMA operands lose their uniformity)
-GRAFT_REPO_ROOT=$R bash tools/rc_ab.sh 64x800 cur exp1 exp8 exp9 > $O/rc_ablate_$TAGR.txt 2>&1 || { echo "PROBE FAILED: ablations"; exit 1; }
+# ablations of the ping-pong kernel (us per B = 64 launch): all / no LDS-DMA / no epilogue traffic / neither / no MFMA + fragment reads
+GRAFT_REPO_ROOT=$R bash tools/rc_ab.sh 64x800 cur exp1 exp8 exp9 exp4 > $O/rc_ablate_$TAGR.txt 2>&1 || { echo "PROBE FAILED: ablations"; exit 1; }
 if [ -z "$SKIP_PROF" ]; then
 PREC=bf16 TIMELINE=60 bash tools/prof_conv.sh ${TAGR}_bf16 > /dev/null 2>&1
 PREC=bf16x3 TIMELINE=60 bash tools/prof_conv.sh ${TAGR}_bf16x3 > /dev/null 2>&1

@@ -4,6 +4,7 @@
 #   lab/rc_phase.so  -DRC_STAMP=2  per-wave cycle counters of the ping-pong phases (read / its barrier / MFMA / its barrier)
 #   lab/rc_marks.so  -DRC_STAMP=3  tile-phase marks (tile 0 main loop / epilogue / rest)
 #   lab/rc_exp<N>.so -DRC_EXP=N    ablations (1 no LDS-DMA, 4 no MFMA + fragment reads, 8 no epilogue traffic, 16 no epilogue), with EXPS="1 4 ..."
+# Lab builds instantiate only the tile variant the probes launch (5 taps, planes in and out: -DRC_LAB_MIN=1, see efts_resconv.hip).
 # The product library is (re)built first, so every lab library exports exactly the product's symbols: a stale lab build is what
 # left four traceback-only files under profiles/ in rounds 2 and 3.
 set -e
@@ -13,7 +14,7 @@ mkdir -p lab
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OBJS=$(ls efficient_tts_amd/build/*.o | grep -v efts_resconv.o)
 build_one() {   # name, define
-  $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $2 -c efficient_tts_amd/csrc/efts_resconv.hip -o /tmp/rc_$1.o
+  $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DRC_LAB_MIN=1 $2 -c efficient_tts_amd/csrc/efts_resconv.hip -o /tmp/rc_$1.o
   $HIPCC --offload-arch=gfx950 -shared -fPIC -o lab/rc_$1.so $OBJS /tmp/rc_$1.o
 }
 pids=""
