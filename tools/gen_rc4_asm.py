@@ -371,7 +371,9 @@ def main():
         out.append('    : : "v"(W0), "v"(W1), "v"(W2), "v"(W3), "v"(W4), "v"(W5), "v"(W6), "v"(W7) : "memory")')
         out.append("")
     # ablation variants of the full-height loop for the micro benchmark (tools/micro/rc4_loop_test.hip)
-    for name, ab in (("NOLOADS", ("loads", "writes")), ("NOSTAGE", ("loads",)), ("NOMFMA", ("writes",)), ("NOREADS", ("bunch",))):
+    # NOSTAGING: no operand loads / LDS writes; WRITES_ONLY / LOADS_ONLY: one half of the staging; BUNCHED: the first schedule (all eight
+    # ds_writes in k-slice 0, all eight loads in k-slice 1), kept to show what spreading them bought
+    for name, ab in (("NOSTAGING", ("loads", "writes")), ("WRITES_ONLY", ("loads",)), ("LOADS_ONLY", ("writes",)), ("BUNCHED", ("bunch",))):
         lines, body, clob = render(8, ab)
         out.append(f"#define RC4_LOOP_H8_{name}(ARS, A1RS, WRS, W1RS, LDA, RMAX, LDA1, RMAX1, LDW, WTS, WTS1, NCH, WAVE, STATE, LDS0) \\")
         out.append("  asm volatile( \\")

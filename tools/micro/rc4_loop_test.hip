@@ -67,10 +67,10 @@ __global__ __launch_bounds__(256, 1) void k(Args p) {
             if constexpr (H == 7) RC4_LOOP_H7(ars, ars, wrs, wrs, lda, rmax, lda, rmax, ldw, wts, wts, nch, wave, state, lds0);
             if constexpr (H == 8) RC4_LOOP_H8(ars, ars, wrs, wrs, lda, rmax, lda, rmax, ldw, wts, wts, nch, wave, state, lds0);
         }
-        if constexpr (VAR == 1) RC4_LOOP_H8_NOLOADS(ars, ars, wrs, wrs, lda, rmax, lda, rmax, ldw, wts, wts, nch, wave, state, lds0);
-        if constexpr (VAR == 2) RC4_LOOP_H8_NOSTAGE(ars, ars, wrs, wrs, lda, rmax, lda, rmax, ldw, wts, wts, nch, wave, state, lds0);
-        if constexpr (VAR == 3) RC4_LOOP_H8_NOMFMA(ars, ars, wrs, wrs, lda, rmax, lda, rmax, ldw, wts, wts, nch, wave, state, lds0);
-        if constexpr (VAR == 4) RC4_LOOP_H8_NOREADS(ars, ars, wrs, wrs, lda, rmax, lda, rmax, ldw, wts, wts, nch, wave, state, lds0);
+        if constexpr (VAR == 1) RC4_LOOP_H8_NOSTAGING(ars, ars, wrs, wrs, lda, rmax, lda, rmax, ldw, wts, wts, nch, wave, state, lds0);
+        if constexpr (VAR == 2) RC4_LOOP_H8_WRITES_ONLY(ars, ars, wrs, wrs, lda, rmax, lda, rmax, ldw, wts, wts, nch, wave, state, lds0);
+        if constexpr (VAR == 3) RC4_LOOP_H8_LOADS_ONLY(ars, ars, wrs, wrs, lda, rmax, lda, rmax, ldw, wts, wts, nch, wave, state, lds0);
+        if constexpr (VAR == 4) RC4_LOOP_H8_BUNCHED(ars, ars, wrs, wrs, lda, rmax, lda, rmax, ldw, wts, wts, nch, wave, state, lds0);
         state ^= ((5 * nch) & 1) | ((nch & 1) << 1);
         state = __builtin_amdgcn_readfirstlane(state);
     }
@@ -173,10 +173,10 @@ int main(int argc, char** argv) {
     const int cus = pr.multiProcessorCount;
     for (int rep = 0; rep < 2; ++rep) {
         bench<8, 0>("full", 8, cus, 4);
-        bench<8, 1>("noloads", 8, cus, 4);
-        bench<8, 2>("w-only", 8, cus, 4);
-        bench<8, 3>("l-only", 8, cus, 4);
-        bench<8, 4>("bunch", 8, cus, 4);
+        bench<8, 1>("no-staging", 8, cus, 4);
+        bench<8, 2>("writes-only", 8, cus, 4);
+        bench<8, 3>("loads-only", 8, cus, 4);
+        bench<8, 4>("bunched", 8, cus, 4);
         bench<7, 0>("full", 8, cus, 4);
         bench<6, 0>("full", 8, cus, 4);
         bench<4, 0>("full", 8, cus, 4);
