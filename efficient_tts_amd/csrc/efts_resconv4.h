@@ -29,7 +29,6 @@ struct Rc4Ctx {
     int lane, wave;
     int n0;
     int state;              // bit 0: weight slot of the next step, bit 1: window buffer of the next tile's chunk 0
-    float bv[8];            // bias of this lane's 8 sweep columns
     int nst;
 };
 
@@ -44,20 +43,22 @@ __device__ __forceinline__ void rc4_prime(char* dst, const char* src, long ld, i
     }
 }
 
-// the epilogue of one tile of H row blocks: accumulators (a[0:255], transposed) -> staging -> row-major sweep
-// FAST: the layer in the middle of a stack on bf16 planes -- residual from the hi + lo planes, row mask, hi + lo planes out -- with every
-// per-layer switch a compile-time constant (a wave alone on its SIMD has nobody to hide scalar loads and uniform branches behind: with the
-// switches read from the argument segment inside the sweep, a unit cost 886 instructions incl. 24 scalar loads and 48 branches)
-template <int H, bool FAST>
+// the epilogue of one tile of H row blocks, general form: accumulators (a[0:255], transposed) -> staging -> row-major sweep, every
+// per-layer switch read at run time (first / last layers of a stack, fp32 residual, sign bytes for training, [32 hi|32 lo] planes out).
+// The layer in the middle of a stack on bf16 planes takes the generated sweep instead (RC4_EPI_H*, rc4_tile below).
+template <int H>
 __device__ __forceinline__ void rc4_epilogue(const RcArgs& p, const RcProb& pq, Rc4Ctx& c, int m0, int rows_out) {
     const int lane = c.lane, wave = c.wave;
-    const bool f_noresid = FAST ? false : pq.no_resid != 0;
-    const bool f_sign = FAST ? false : pq.sign != nullptr;
-    const bool f_of32 = FAST ? false : pq.out_f32 != nullptr;
-    const bool f_ob = FAST ? true : pq.ob != nullptr;
-    const bool f_os2 = FAST ? false : pq.out_split == 2;
-    const bool f_oblo = FAST ? true : pq.ob_lo != nullptr;
+    const bool f_noresid = pq.no_resid != 0;
+    const bool f_sign = pq.sign != nullptr;
+    const bool f_of32 = pq.out_f32 != nullptr;
+    const bool f_ob = pq.ob != nullptr;
+    const bool f_os2 = pq.out_split == 2;
+    const bool f_oblo = pq.ob_lo != nullptr;
     const float slope = pq.slope;
+    float bv[8];                                                   // bias of this lane's 8 sweep columns
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = pq.bias ? pq.bias[c.n0 + wave * 64 + (lane & 7) * 8 + e] : 0.f;
     const unsigned ldsg = (unsigned)pq.ldsg;
     char* const st = c.smem + RC4_STAGE + wave * 8192;             // [32 rows][64 channels] fp32, 16-byte slots XORed with (row & 7) << 1
     // staging write addresses: lane = time row (lane & 31); register quad (j, g) = channels 32 j + 8 g + 4 (lane >> 5) + 0..3 = slot j 8 + g 2 + (lane >> 5)
@@ -76,8 +77,8 @@ __device__ __forceinline__ void rc4_epilogue(const RcArgs& p, const RcProb& pq, 
     const __amdgpu_buffer_rsrc_t r_ob = make_rsrc(pq.ob ? pq.ob + (long)m0 * pq.ldob : nullptr, pq.ob ? (long)rows_out * pq.ldob : 0);
     const __amdgpu_buffer_rsrc_t r_ol = make_rsrc(pq.ob_lo ? pq.ob_lo + (long)m0 * pq.ldob : nullptr, pq.ob_lo ? (long)rows_out * pq.ldob : 0);
     const __amdgpu_buffer_rsrc_t r_sg = make_rsrc(pq.sign ? pq.sign + (long)m0 * pq.ldsg : nullptr, pq.sign ? (long)rows_out * pq.ldsg : 0);
-    const bool res_f32 = FAST ? false : pq.resid != nullptr;
-    const bool has_mask = FAST ? true : pq.rowmask != nullptr;
+    const bool res_f32 = pq.resid != nullptr;
+    const bool has_mask = pq.rowmask != nullptr;
     const int srow = lane >> 3;                       // row of the 8-row pass this lane handles
     const int c8 = lane & 7;                          // its 8 columns inside the wave's 64
     const char* const rd = st + srow * 256 + ((c8 ^ srow) << 5);       // this lane's 32 bytes of pass 0 (passes are 8 rows = 2 KiB apart)
@@ -144,7 +145,7 @@ __device__ __forceinline__ void rc4_epilogue(const RcArgs& p, const RcProb& pq, 
             float d[8] = {q0[ps].x, q0[ps].y, q0[ps].z, q0[ps].w, q1[ps].x, q1[ps].y, q1[ps].z, q1[ps].w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {                          // bias + activation, as rc_tile applies them in front of its staging
-                float v = d[e] + c.bv[e];
+                float v = d[e] + bv[e];
                 d[e] = v > 0.f ? v : v * slope;
             }
             float x[8];
@@ -219,9 +220,26 @@ __device__ __forceinline__ void rc4_tile(const RcArgs& p, const RcProb& pq, cons
     // 5 nchunk steps later: the weight slot and the window buffer the NEXT tile starts on
     c.state = __builtin_amdgcn_readfirstlane(state ^ (((5 * nch) & 1) | ((nch & 1) << 1)));
     RC_MARK(p, c);
-    const bool fast = pq.a_lo && !pq.resid && pq.rowmask && pq.ob && pq.ob_lo && pq.out_split == 1 && !pq.out_f32 && !pq.sign && !pq.no_resid;
-    if (fast) rc4_epilogue<H, true>(p, pq, c, m0, rows_out);
-    else rc4_epilogue<H, false>(p, pq, c, m0, rows_out);
+    // the layer in the middle of a stack on bf16 planes (residual from the hi + lo planes, row mask, hi + lo planes out, 0 <= slope <= 1 so
+    // that LeakyReLU is max(v, v slope)): the generated, stage-major sweep
+    const bool fast = pq.a_lo && !pq.resid && pq.rowmask && pq.ob && pq.ob_lo && pq.out_split == 1 && !pq.out_f32 && !pq.sign && !pq.no_resid &&
+                      pq.slope >= 0.f && pq.slope <= 1.f;
+    if (!fast) { rc4_epilogue<H>(p, pq, c, m0, rows_out); return; }
+    const __amdgpu_buffer_rsrc_t r_a = make_rsrc(pq.a + (long)m0 * pq.lda, (long)rows_out * pq.lda);
+    const __amdgpu_buffer_rsrc_t r_al = make_rsrc(pq.a_lo + (long)m0 * pq.lda, (long)rows_out * pq.lda);
+    const __amdgpu_buffer_rsrc_t r_m = make_rsrc(pq.rowmask + m0, (long)rows_out * 4);
+    const __amdgpu_buffer_rsrc_t r_ob = make_rsrc(pq.ob + (long)m0 * pq.ldob, (long)rows_out * pq.ldob);
+    const __amdgpu_buffer_rsrc_t r_ol = make_rsrc(pq.ob_lo + (long)m0 * pq.ldob, (long)rows_out * pq.ldob);
+    const __amdgpu_buffer_rsrc_t r_b = make_rsrc(pq.bias, pq.bias ? (long)p.ntn * RC_BN * 4 : 0);      // no bias: the loads return zeros
+    const int ldob = __builtin_amdgcn_readfirstlane((int)pq.ldob), n0 = __builtin_amdgcn_readfirstlane(c.n0);
+    const unsigned long slope2 = (unsigned long)__builtin_amdgcn_readfirstlane((int)__float_as_uint(pq.slope));
+    if constexpr (H == 2) RC4_EPI_H2(r_a, r_al, r_m, r_ob, r_ol, r_b, lda, ldob, slope2, n0, wave, lds0);
+    if constexpr (H == 3) RC4_EPI_H3(r_a, r_al, r_m, r_ob, r_ol, r_b, lda, ldob, slope2, n0, wave, lds0);
+    if constexpr (H == 4) RC4_EPI_H4(r_a, r_al, r_m, r_ob, r_ol, r_b, lda, ldob, slope2, n0, wave, lds0);
+    if constexpr (H == 5) RC4_EPI_H5(r_a, r_al, r_m, r_ob, r_ol, r_b, lda, ldob, slope2, n0, wave, lds0);
+    if constexpr (H == 6) RC4_EPI_H6(r_a, r_al, r_m, r_ob, r_ol, r_b, lda, ldob, slope2, n0, wave, lds0);
+    if constexpr (H == 7) RC4_EPI_H7(r_a, r_al, r_m, r_ob, r_ol, r_b, lda, ldob, slope2, n0, wave, lds0);
+    if constexpr (H == 8) RC4_EPI_H8(r_a, r_al, r_m, r_ob, r_ol, r_b, lda, ldob, slope2, n0, wave, lds0);
 }
 
 __global__ __launch_bounds__(256, 1) void resconv5w4_kernel(RcArgs p) {
@@ -266,14 +284,9 @@ __global__ __launch_bounds__(256, 1) void resconv5w4_kernel(RcArgs p) {
     int pi, m0, h, rows_out;
     locate(0, vrow, pi, m0, h, rows_out);
     if (h == 0) return;
-    auto bias_of = [&](const RcProb& q) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) c.bv[e] = q.bias ? q.bias[c.n0 + c.wave * 64 + (c.lane & 7) * 8 + e] : 0.f;
-    };
     {
         // kernel prologue: the first tile's window chunk 0 into buffer 0 and its weight tile (tap 0, chunk 0) into slot 0
         const RcProb& q0 = p.pr[pi];
-        bias_of(q0);
         c.state = 0;
         rc4_prime(smem, q0.a + (long)(m0 - 2) * q0.lda, q0.lda, h, q0.m + 143 - (m0 - 2), c.wave, c.lane);
         rc4_prime(smem + 2 * 32768, q0.w + (long)c.n0 * q0.ldw, q0.ldw, 8, 0x7fffffff, c.wave, c.lane);
@@ -294,7 +307,6 @@ __global__ __launch_bounds__(256, 1) void resconv5w4_kernel(RcArgs p) {
             default: rc4_tile<8>(p, pq, pn, c, m0, rows_out, m1, h1); break;
         }
         RC_MARK(p, c);
-        if (h1 > 0 && pi1 != pi) bias_of(pn);
         vrow = vnext; pi = pi1; m0 = m1; h = h1; rows_out = rows1;
     }
     if (RC_STAMP == 1 && p.stamp && tid == 0) p.stamp[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();

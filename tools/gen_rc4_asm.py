@@ -336,6 +336,162 @@ class Gen:
         return [f"v{i}" for i in range(V0, VEND)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(S0, SEND)] + ["scc", "memory"]
 
 
+# ---------------------------------------------------------------------------------------------------------------- the FAST epilogue
+# One asm statement per tile height for the layer in the middle of a stack on bf16 planes (residual from the hi + lo planes, row mask,
+# hi + lo planes out).  Why asm here too: a wave alone on its SIMD has no partner to fill the gaps behind dependent VALU results, and hipcc
+# emits the sweep chain by chain (shift, and, add, add, mul, cvt, shift, and, fma: ~7.5 cycles per instruction, 12.8 us per tile against
+# 8.1 us for the 8-wave kernel's two interleaved waves).  Here the 16 value pairs of two 8-row passes go through every stage together, so
+# a result is needed 8 instructions after it was issued.  The operations and their order per value are exactly the compiler's (h + l, + d,
+# * m, cvt, fma(s, m, -g): the remainder keeps the contraction the C++ epilogues compile to), hence the same bits.
+E0 = 16                       # first VGPR of the epilogue statement (v0 .. v15 stay with the compiler)
+E_WV = E0                     # WV[8]     staging (dump) addresses
+E_RD = E_WV + 8               # read-back address of pass 0
+E_VX = E_RD + 1               # residual offset (both planes), E_VM mask offset, E_VOB output offset (both planes)
+E_VM = E_VX + 1
+E_VOB = E_VM + 1
+E_T = E_VOB + 1               # 4 temporaries
+E_BIAS = 32                   # BIAS[8] (pairs, even-aligned)
+E_Q = E_BIAS + 8              # Q[32]     read-back of the unit: pass ps element e at Q + 8 ps + e
+E_XA = E_Q + 32               # XA[3][16] hi words of three units in flight (pass ps: 4 registers)
+E_XB = E_XA + 48              # XB[3][16] lo words
+E_RM = E_XB + 48              # RM[3][8]  row masks (one even-aligned pair slot per pass)
+E_T1 = E_RM + 24              # T1[16], T2[16]  stage temporaries of one half unit (2 passes x 4 pairs)
+E_T2 = E_T1 + 16
+E_OUT = E_T2 + 16             # OUT[2][16] packed hi (8) + lo (8) words of a half unit, double-buffered (store data must stay put)
+E_END = E_OUT + 32
+assert E_END <= 256, E_END
+ES0 = 76                      # SGPRs: ES0 .. ES0 + 7 temporaries
+EOPS = ["ra", "ral", "rm", "rob", "rol", "rbias", "lda", "ldob", "slope2", "n0", "wave", "lds0"]
+EOP = {n: i for i, n in enumerate(EOPS)}
+
+
+def eop(name):
+    return f"%{EOP[name]}"
+
+
+def gen_epilogue(h):
+    out = []
+    e = out.append
+    vm_ops = []                                   # VMEM ops in issue order: (kind, unit)
+
+    def loads(u):                                 # residual hi / lo words and row masks of unit u -> set u % 3
+        st = u % 3
+        for ps in range(4):
+            rofs = u * 32 + ps * 8
+            e(f"s_mul_i32 {s(ES0)}, {eop('lda')}, {rofs}")
+            e(f"buffer_load_dwordx4 {v(E_XA + st * 16 + ps * 4, 4)}, {v(E_VX)}, {eop('ra')}, {s(ES0)} offen")
+            e(f"buffer_load_dwordx4 {v(E_XB + st * 16 + ps * 4, 4)}, {v(E_VX)}, {eop('ral')}, {s(ES0)} offen")
+            e(f"buffer_load_dword {v(E_RM + st * 8 + ps * 2)}, {v(E_VM)}, {eop('rm')}, 0 offen offset:{rofs * 4}")
+            vm_ops.extend([("ld", u)] * 3)
+
+    def dump(u):
+        for j in range(2):
+            for g in range(4):
+                base = (2 * u + j) * 16 + 4 * g
+                e(f"ds_write_b128 {v(E_WV + j * 4 + g)}, {a(base, 4)}")
+
+    # ---- per-lane constants
+    e("v_mbcnt_lo_u32_b32 " + v(E_T) + ", -1, 0")
+    e(f"v_mbcnt_hi_u32_b32 {v(E_T)}, -1, {v(E_T)}")                       # lane
+    e(f"v_and_b32 {v(E_T + 1)}, 31, {v(E_T)}")                            # lrow (time row of the accumulator layout)
+    e(f"v_lshrrev_b32 {v(E_T + 2)}, 5, {v(E_T)}")                         # lhalf
+    e(f"s_lshl_b32 {s(ES0)}, {eop('wave')}, 13")
+    e(f"s_add_u32 {s(ES0)}, {s(ES0)}, {eop('lds0')}")
+    e(f"s_add_u32 {s(ES0)}, {s(ES0)}, 0x20000")                           # staging block of this wave (RC4_STAGE = 128 KiB)
+    e(f"v_and_b32 {v(E_T + 3)}, 7, {v(E_T + 1)}")
+    e(f"v_lshlrev_b32 {v(E_T + 3)}, 1, {v(E_T + 3)}")                     # (lrow & 7) << 1
+    e(f"v_lshlrev_b32 {v(E_RD)}, 8, {v(E_T + 1)}")                        # lrow * 256
+    e(f"v_add_u32 {v(E_RD)}, {s(ES0)}, {v(E_RD)}")
+    for q in range(8):
+        e(f"v_or_b32 {v(E_WV + q)}, {2 * q}, {v(E_T + 2)}")               # slot = 2 q + lhalf
+        e(f"v_xor_b32 {v(E_WV + q)}, {v(E_WV + q)}, {v(E_T + 3)}")
+        e(f"v_lshl_add_u32 {v(E_WV + q)}, {v(E_WV + q)}, 4, {v(E_RD)}")
+    e(f"v_lshrrev_b32 {v(E_T + 1)}, 3, {v(E_T)}")                         # srow
+    e(f"v_and_b32 {v(E_T + 2)}, 7, {v(E_T)}")                             # c8
+    e(f"v_xor_b32 {v(E_T + 3)}, {v(E_T + 1)}, {v(E_T + 2)}")
+    e(f"v_lshlrev_b32 {v(E_T + 3)}, 5, {v(E_T + 3)}")                     # (c8 ^ srow) * 32
+    e(f"v_lshl_add_u32 {v(E_RD)}, {v(E_T + 1)}, 8, {v(E_T + 3)}")         # srow * 256 + ...
+    e(f"v_add_u32 {v(E_RD)}, {s(ES0)}, {v(E_RD)}")
+    e(f"s_lshl_b32 {s(ES0 + 1)}, {eop('wave')}, 6")
+    e(f"s_add_u32 {s(ES0 + 1)}, {s(ES0 + 1)}, {eop('n0')}")               # n0 + wave * 64
+    e(f"v_lshl_add_u32 {v(E_T + 3)}, {v(E_T + 2)}, 3, {s(ES0 + 1)}")      # col0 = n0 + wave 64 + c8 8
+    e(f"v_mul_lo_u32 {v(E_VX)}, {v(E_T + 1)}, {eop('lda')}")
+    e(f"v_lshl_add_u32 {v(E_VX)}, {v(E_T + 3)}, 1, {v(E_VX)}")            # srow * lda + col0 * 2
+    e(f"v_mul_lo_u32 {v(E_VOB)}, {v(E_T + 1)}, {eop('ldob')}")
+    e(f"v_lshl_add_u32 {v(E_VOB)}, {v(E_T + 3)}, 1, {v(E_VOB)}")
+    e(f"v_lshlrev_b32 {v(E_VM)}, 2, {v(E_T + 1)}")                        # srow * 4
+    e(f"v_lshlrev_b32 {v(E_T + 3)}, 2, {v(E_T + 3)}")                     # col0 * 4
+    e(f"buffer_load_dwordx4 {v(E_BIAS, 4)}, {v(E_T + 3)}, {eop('rbias')}, 0 offen")
+    e(f"buffer_load_dwordx4 {v(E_BIAS + 4, 4)}, {v(E_T + 3)}, {eop('rbias')}, 0 offen offset:16")
+    vm_ops.extend([("bias", -1)] * 2)
+    loads(0)
+    if h > 1:
+        loads(1)
+    dump(0)
+    for u in range(h):
+        st = u % 3
+        for ps in range(4):
+            e(f"ds_read_b128 {v(E_Q + ps * 8, 4)}, {v(E_RD)} offset:{ps * 2048}")
+            e(f"ds_read_b128 {v(E_Q + ps * 8 + 4, 4)}, {v(E_RD)} offset:{ps * 2048 + 16}")
+        nd = 0
+        if u + 1 < h:
+            dump(u + 1)
+            nd = 8
+        if u + 2 < h:
+            loads(u + 2)
+        last = max(i for i, (k, uu) in enumerate(vm_ops) if k == "ld" and uu == u)
+        e(f"s_waitcnt vmcnt({len(vm_ops) - 1 - last})")
+        e(f"s_waitcnt lgkmcnt({nd})")
+        for half in range(2):
+            ob = E_OUT + ((2 * u + half) % 2) * 16
+            P = [2 * half, 2 * half + 1]
+            chains = [(ps, k) for ps in P for k in range(4)]            # 8 pair chains: pass ps, pair k (elements 2 k, 2 k + 1)
+            def Q2(ps, k): return v(E_Q + ps * 8 + 2 * k, 2)
+            def T1(i): return E_T1 + 2 * i
+            def T2(i): return E_T2 + 2 * i
+            # 1. d += bias      2. t = d * slope      3. d = max(d, t)
+            for i, (ps, k) in enumerate(chains):
+                e(f"v_pk_add_f32 {Q2(ps, k)}, {Q2(ps, k)}, {v(E_BIAS + 2 * k, 2)}")
+            for i, (ps, k) in enumerate(chains):
+                e(f"v_pk_mul_f32 {v(T1(i), 2)}, {eop('slope2')}, {Q2(ps, k)} op_sel_hi:[0,1]")
+            for i, (ps, k) in enumerate(chains):
+                e(f"v_max_f32 {v(E_Q + ps * 8 + 2 * k)}, {v(E_Q + ps * 8 + 2 * k)}, {v(T1(i))}")
+                e(f"v_max_f32 {v(E_Q + ps * 8 + 2 * k + 1)}, {v(E_Q + ps * 8 + 2 * k + 1)}, {v(T1(i) + 1)}")
+            # 4. unpack hi -> T1, lo -> T2     5. x = h + l     6. s = x + d     7. y = s * m
+            for i, (ps, k) in enumerate(chains):
+                H, L = E_XA + st * 16 + ps * 4 + k, E_XB + st * 16 + ps * 4 + k
+                e(f"v_lshlrev_b32 {v(T1(i))}, 16, {v(H)}")
+                e(f"v_and_b32 {v(T1(i) + 1)}, 0xffff0000, {v(H)}")
+                e(f"v_lshlrev_b32 {v(T2(i))}, 16, {v(L)}")
+                e(f"v_and_b32 {v(T2(i) + 1)}, 0xffff0000, {v(L)}")
+            for i, (ps, k) in enumerate(chains):
+                e(f"v_pk_add_f32 {v(T1(i), 2)}, {v(T1(i), 2)}, {v(T2(i), 2)}")
+            for i, (ps, k) in enumerate(chains):
+                e(f"v_pk_add_f32 {v(T1(i), 2)}, {v(T1(i), 2)}, {Q2(ps, k)}")
+            for i, (ps, k) in enumerate(chains):
+                e(f"v_pk_mul_f32 {v(T2(i), 2)}, {v(T1(i), 2)}, {v(E_RM + st * 8 + ps * 2, 2)} op_sel_hi:[1,0]")
+            # 8. hi' = cvt(y)      9. g = unpack(hi')      10. rem = fma(s, m, -g)      11. lo' = cvt(rem)
+            for i, (ps, k) in enumerate(chains):
+                e(f"v_cvt_pk_bf16_f32 {v(ob + (ps - P[0]) * 4 + k)}, {v(T2(i))}, {v(T2(i) + 1)}")
+            for i, (ps, k) in enumerate(chains):
+                hp = ob + (ps - P[0]) * 4 + k
+                e(f"v_lshlrev_b32 {v(T2(i))}, 16, {v(hp)}")
+                e(f"v_and_b32 {v(T2(i) + 1)}, 0xffff0000, {v(hp)}")
+            for i, (ps, k) in enumerate(chains):
+                e(f"v_pk_fma_f32 {v(T1(i), 2)}, {v(T1(i), 2)}, {v(E_RM + st * 8 + ps * 2, 2)}, {v(T2(i), 2)} op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]")
+            for i, (ps, k) in enumerate(chains):
+                e(f"v_cvt_pk_bf16_f32 {v(ob + 8 + (ps - P[0]) * 4 + k)}, {v(T1(i))}, {v(T1(i) + 1)}")
+            for ps in P:
+                rofs = u * 32 + ps * 8
+                e(f"s_mul_i32 {s(ES0)}, {eop('ldob')}, {rofs}")
+                e(f"buffer_store_dwordx4 {v(ob + (ps - P[0]) * 4, 4)}, {v(E_VOB)}, {eop('rob')}, {s(ES0)} offen")
+                e(f"buffer_store_dwordx4 {v(ob + 8 + (ps - P[0]) * 4, 4)}, {v(E_VOB)}, {eop('rol')}, {s(ES0)} offen")
+                vm_ops.extend([("st", u)] * 2)
+    e("s_nop 1")
+    clob = [f"v{i}" for i in range(E0, E_END)] + [f"s{i}" for i in range(ES0, ES0 + 8)] + ["scc", "memory"]
+    return out, clob
+
+
 def render(h, ablate=()):
     g = Gen(h, ablate)
     lines = g.build()
@@ -369,6 +525,16 @@ def main():
         out.append("  asm volatile( \\")
         out.append(body + " \\")
         out.append('    : : "v"(W0), "v"(W1), "v"(W2), "v"(W3), "v"(W4), "v"(W5), "v"(W6), "v"(W7) : "memory")')
+        out.append("")
+    # the FAST epilogue, one statement per tile height.  Operands (all "s"): " + ", ".join(f"%{i} {n}" for i, n in enumerate(EOPS)) + "
+    for h in range(2, 9):
+        lines, clob = gen_epilogue(h)
+        body = " \\\n".join(f'    "{ln}\\n\\t"' for ln in lines)
+        out.append(f"#define RC4_EPI_H{h}(RA, RAL, RM, ROB, ROL, RBIAS, LDA, LDOB, SLOPE2, N0, WAVE, LDS0) \\")
+        out.append("  asm volatile( \\")
+        out.append(body + " \\")
+        out.append('    : : "s"(RA), "s"(RAL), "s"(RM), "s"(ROB), "s"(ROL), "s"(RBIAS), "s"(LDA), "s"(LDOB), "s"(SLOPE2), "s"(N0), "s"(WAVE), "s"(LDS0) \\')
+        out.append("    : " + ", ".join(f'"{c}"' for c in clob) + ")")
         out.append("")
     # ablation variants of the full-height loop for the micro benchmark (tools/micro/rc4_loop_test.hip)
     # NOSTAGING: no operand loads / LDS writes; WRITES_ONLY / LOADS_ONLY: one half of the staging; BUNCHED: the first schedule (all eight
