@@ -187,7 +187,9 @@ def measure_train(a, world, rank, dev, wl, steps, warmup, precision=None):
         if graphed is None:
             P.PROFILE, P.PROFILE_TAG = [], (5, rows, 512)
         dt, loss = timed(run, steps)
-        if graphed is not None:
+        if graphed is not None and os.environ.get("EFTS_BENCH_TRAIN_NO_EAGER") == "1":
+            graph_dt = dt                          # (profiling a replay's timeline: nothing issued behind the timed replays)
+        elif graphed is not None:
             # the same step issued eagerly (what the reference's loop does), with the conv launches bracketed by events for the roofline
             assert graphed.replays >= steps, "the timed steps were not graph replays"
             graph_dt = dt

@@ -27,7 +27,9 @@ if [ -z "$SKIP_PROF" ]; then
 PREC=bf16 TIMELINE=60 bash tools/prof_conv.sh ${TAGR}_bf16 > /dev/null 2>&1
 PREC=bf16x3 TIMELINE=60 bash tools/prof_conv.sh ${TAGR}_bf16x3 > /dev/null 2>&1
 WL=train32 STEPS=3 TIMELINE=240 BARGS="--train-graph 0" bash tools/prof_conv.sh ${TAGR}_train_bf16 > /dev/null 2>&1
-for t in ${TAGR}_bf16 ${TAGR}_bf16x3 ${TAGR}_train_bf16; do
+# the same training step as ONE hipGraph replay (what bench.py times): trace only, nothing issued behind the replays
+EFTS_BENCH_TRAIN_NO_EAGER=1 NOPMC=1 WL=train32 STEPS=6 TIMELINE=215 BARGS="--train-graph 1" bash tools/prof_conv.sh ${TAGR}_train_graph > /dev/null 2>&1
+for t in ${TAGR}_bf16 ${TAGR}_bf16x3 ${TAGR}_train_bf16 ${TAGR}_train_graph; do
   test -s gpurun_out/prof_$t/summary_$t.txt || { echo "PROFILE FAILED: $t"; exit 1; }
   cp gpurun_out/prof_$t/summary_$t.txt $O/rocprofv3_${t}_summary.txt
   cp gpurun_out/prof_$t/bench_line_$t.json $O/bench_line_under_rocprof_$t.json
@@ -41,6 +43,8 @@ python bench.py --workload train32 > $O/bench_train32_bf16_$TAGR.json 2> $O/benc
 python bench.py --workload train32 --precision bf16x3 --no-cpu-baseline > $O/bench_train32_bf16x3_$TAGR.json 2>> $O/bench_train32.err
 python bench.py --workload infer64 --no-cpu-baseline > $O/bench_infer64_bf16_$TAGR.json 2> $O/bench_infer.err
 python bench.py --workload infer_lj > $O/bench_infer_lj_bf16_$TAGR.json 2>> $O/bench_infer.err
+# the forward on the one-wave-per-SIMD kernel (where it is eligible), interleaved with the default for an in-situ comparison
+for k in 1 2 1 2; do python bench.py --rc-kernel $k --no-cpu-baseline --parity-mode 0 --call-modes 0 --measure-traffic 0 --train-record 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('rc-kernel $k', 'ms_per_step', round(d['ms_per_step'], 4), 'roofline', d['roofline']['achieved'], d['roofline']['frac'])"; done > $O/bench_rc_kernel_ab_$TAGR.txt 2>&1
 for f in $O/bench_*_$TAGR.json; do test -s $f || { echo "BENCH FAILED: $f"; exit 1; }; done
 fi
 ls -la $O
