@@ -8,6 +8,7 @@ O=$R/gpurun_out/collect
 mkdir -p $O
 cd $R
 TAGR=${TAGR:-r04}
+if [ -z "$SKIP_LAB" ]; then
 EXPS="1 8 9 4" bash tools/lab_build.sh > $O/lab_build.log 2>&1
 probe() {   # name, lab library, script, env...
   local out=$O/$1; local lib=$2; local script=$3; shift 3
@@ -23,12 +24,13 @@ probe rc_marks_w4_$TAGR.txt rc_marks.so tools/gpu_probe_rc_marks.py RCK=2
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I efficient_tts_amd/csrc tools/micro/rc4_loop_test.hip -o lab/rc4_loop_test > $O/rc4_micro_build.log 2>&1 && timeout 200 lab/rc4_loop_test > $O/rc4_loop_micro_$TAGR.txt 2>&1 || { echo "PROBE FAILED: rc4 micro benchmark"; exit 1; }
 # ablations of the ping-pong kernel (us per B = 64 launch): all / no LDS-DMA / no epilogue traffic / neither / no MFMA + fragment reads
 GRAFT_REPO_ROOT=$R bash tools/rc_ab.sh 64x800 cur exp1 exp8 exp9 exp4 > $O/rc_ablate_$TAGR.txt 2>&1 || { echo "PROBE FAILED: ablations"; exit 1; }
+fi
 if [ -z "$SKIP_PROF" ]; then
 PREC=bf16 TIMELINE=60 bash tools/prof_conv.sh ${TAGR}_bf16 > /dev/null 2>&1
 PREC=bf16x3 TIMELINE=60 bash tools/prof_conv.sh ${TAGR}_bf16x3 > /dev/null 2>&1
-WL=train32 STEPS=3 TIMELINE=240 BARGS="--train-graph 0" bash tools/prof_conv.sh ${TAGR}_train_bf16 > /dev/null 2>&1
+WL=train32 STEPS=3 TSTEPS=3 TWARM=2 TIMELINE=240 BARGS="--train-graph 0" bash tools/prof_conv.sh ${TAGR}_train_bf16 > /dev/null 2>&1
 # the same training step as ONE hipGraph replay (what bench.py times): trace only, nothing issued behind the replays
-EFTS_BENCH_TRAIN_NO_EAGER=1 NOPMC=1 WL=train32 STEPS=6 TIMELINE=215 BARGS="--train-graph 1" bash tools/prof_conv.sh ${TAGR}_train_graph > /dev/null 2>&1
+EFTS_BENCH_TRAIN_NO_EAGER=1 NOPMC=1 WL=train32 STEPS=6 TSTEPS=20 TWARM=5 TIMELINE=215 BARGS="--train-graph 1" bash tools/prof_conv.sh ${TAGR}_train_graph > /dev/null 2>&1
 for t in ${TAGR}_bf16 ${TAGR}_bf16x3 ${TAGR}_train_bf16 ${TAGR}_train_graph; do
   test -s gpurun_out/prof_$t/summary_$t.txt || { echo "PROFILE FAILED: $t"; exit 1; }
   cp gpurun_out/prof_$t/summary_$t.txt $O/rocprofv3_${t}_summary.txt
