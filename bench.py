@@ -16,7 +16,9 @@ launcher's and must number N; WITHOUT one this script launches the N ranks itsel
 N-GPU value is N replicas (weak scaling, frames of all ranks / max-over-ranks time).  The same line then carries `train32`:
 BASELINE configs 3 / 4, the data-parallel training step at batch 32 per GPU with the bucketed RCCL gradient all-reduce overlapped
 with the backward (efficient_tts_amd/bench_train.py), with its `dp` record (backend, ranks, bytes and time per bucket, exposed wait,
-RCCL's own topology lines, bit-exact replica check).  `--workload train32` times only that step.
+RCCL's own topology lines, bit-exact replica check).  `--workload train32` times only that step.  At N > 1 the forward result is
+protected from that record: an exception in it costs the record (`train32.error`), a hang is cut after EFTS_BENCH_DP_TIMEOUT
+(240) seconds by a watchdog that prints the line with what there is and ends every rank.
 
 Prints ONE JSON line on rank 0, with `roofline` for the dominant kernel (the k5 Conv1d contraction at mel length, measured with HIP
 events on the launch stream inside the timed region; `traffic` from two rocprofv3 PMC child passes) and `cpu_baseline` (the
@@ -597,6 +599,24 @@ def conv_roofline(P, model, step, B, T2, precision, workload, a=None):
                 mfma_issue_frac=(3 if model.split == 2 else 1) * flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS)
 
 
+def _watchdog(seconds, rank, res, key):
+    """a timer that, when it fires, prints rank 0's line (with `key` marked as abandoned) and ends the process; .cancel() disarms it"""
+    import threading
+
+    def fire():
+        if res is not None and rank == 0:
+            res.setdefault(key, dict(error=f"abandoned after {seconds} s without finishing (a rank hung); the rest of the line stands"))
+            try:
+                print(json.dumps(res), flush=True)
+            except Exception:                                          # noqa: BLE001
+                pass
+        os._exit(0)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def run_forward(a, world, rank, dev, wl):
     """BASELINE config 2 (fwd64) / config 5 (fwd16_long): the teacher-forced forward.  The timed step is a PLAIN
     `model(text, tl, mel, sl)` call -- what a drop-in caller of the reference class executes; the model replays a per-shape
@@ -728,16 +748,30 @@ def run_forward(a, world, rank, dev, wl):
         # its parity-grade mode (bf16x3) under the same clock
         from efficient_tts_amd.bench_train import measure_train
         torch.cuda.empty_cache()
-        tr = measure_train(a, world, rank, dev, WORKLOADS["train32"], steps=40, warmup=10)
+        # N > 1: the forward result above must survive whatever the data-parallel record runs into on hardware this code has not seen
+        # (a rank that fails alone leaves the others inside a collective).  An exception costs the record, not the line; a hang is
+        # cut by a watchdog that prints the line with what there is and ends the process on every rank.
+        dog = _watchdog(int(os.environ.get("EFTS_BENCH_DP_TIMEOUT", "240")), rank, res, "train32") if world > 1 else None
+        failed = False
+        try:
+            tr = measure_train(a, world, rank, dev, WORKLOADS["train32"], steps=40, warmup=10)      # (None on ranks other than 0)
+        except Exception as exc:                                       # noqa: BLE001 -- the line must still be printed
+            if world == 1:
+                raise
+            tr, failed = None, True
+            if res is not None:
+                res["train32"] = dict(error=f"rank {rank}: {type(exc).__name__}: {exc}"[:400])
         trp = None
-        if a.precision == "bf16" and a.parity_mode and not (rank == 0 and tr and tr["config"].get("device_state")):
+        if not failed and a.precision == "bf16" and a.parity_mode and not (rank == 0 and tr and tr["config"].get("device_state")):
             try:
                 trp = measure_train(a, world, rank, dev, WORKLOADS["train32"], steps=40, warmup=10, precision="bf16x3")
             except Exception as exc:                                   # noqa: BLE001 -- the line must still be printed
                 trp = None
                 if rank == 0:
                     tr["config"]["parity_mode_note"] = f"not measured: {exc}"[:200]
-        if rank == 0:
+        if dog is not None:
+            dog.cancel()
+        if rank == 0 and tr is not None:
             if trp is not None:
                 tr["parity_mode"] = {k: trp[k] for k in ("value", "ms_per_step", "eager_ms_per_step", "graph_ms_per_step", "dtype", "loss", "tflops", "roofline", "steps", "warmup")}
                 tr["parity_mode"]["note"] = ("bf16x3 operands: the mode the gradient-vs-oracle tests run in (tests/test_gpu_train.py); the bf16 mode's own "
@@ -753,10 +787,12 @@ def run_forward(a, world, rank, dev, wl):
         print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist
+        _watchdog(60, rank, None, None)                                # the line is out: a tear-down that hangs must not hold the launcher
         try:
             dist.destroy_process_group()
         except Exception:                                              # noqa: BLE001 -- the line is out; nothing left to lose
-            os._exit(0)
+            pass
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -155,3 +155,23 @@ def test_bench_launches_its_own_ranks_and_refuses_fewer():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "rendezvous"],
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
+
+
+def test_bench_watchdog_prints_the_line_and_ends_the_process():
+    """N > 1: a data-parallel record that hangs (a rank that failed alone leaves the others inside a collective) must not take the
+    forward result with it: bench.py's watchdog prints rank 0's line with the record marked as abandoned and ends the process."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; res = dict(metric='m', value=1.0)\n"
+            "bench._watchdog(1, 0, res, 'train32'); time.sleep(60); print('not reached')" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "not reached" not in out.stdout, out.stderr[-1000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["value"] == 1.0 and "abandoned after 1 s" in rec["train32"]["error"]
+    quiet = subprocess.run([sys.executable, "-c", code.replace("(1, 0, res", "(1, 1, res")], capture_output=True, text=True, timeout=300)
+    assert quiet.returncode == 0 and quiet.stdout.strip() == ""           # other ranks: no line, same exit
+    code2 = code.replace("time.sleep(60)", "t = bench._watchdog(1, 0, res, 'x'); t.cancel(); [w.cancel() for w in __import__('threading').enumerate() if hasattr(w, 'cancel')]; time.sleep(2)")
+    kept = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=300)
+    assert "not reached" in kept.stdout                                   # a cancelled watchdog does nothing
