@@ -467,7 +467,7 @@ static void launch_debug(dim3 grid, hipStream_t st, GemmKernelArgs k, int prof) 
 extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     if (!a) return efts_fail(EFTS_EINVAL, "efts_gemm: null args");
     if (!(a->split == 1 || a->split == 2)) return efts_fail(EFTS_EINVAL, "efts_gemm: split must be 1 or 2");
-    if (!(a->taps == 1 || a->taps == 3 || a->taps == 5 || a->taps == 7 || a->taps == 11)) return efts_fail(EFTS_EINVAL, "efts_gemm: taps must be 1, 3, 5, 7 or 11");
+    if (!(a->taps == 1 || a->taps == 3 || a->taps == 5 || a->taps == 7 || a->taps == 9 || a->taps == 11)) return efts_fail(EFTS_EINVAL, "efts_gemm: taps must be 1, 3, 5, 7, 9 or 11");
     const int dil = a->dilation > 0 ? a->dilation : 1;
     if ((a->taps - 1) * dil > 64) return efts_fail(EFTS_ESHAPE, "efts_gemm: (taps - 1) * dilation must not exceed 64 rows");
     if (a->m <= 0 || a->n <= 0 || a->nchunk <= 0 || a->batch <= 0) return efts_fail(EFTS_ESHAPE, "efts_gemm: m, n, nchunk, batch must be positive");
@@ -599,6 +599,7 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     if (a->split == 1) {
         switch (a->taps) {
             case 11: launch_one<11, 1, 0>(grid, st, k); break;
+            case 9: launch_one<9, 1, 0>(grid, st, k); break;
             case 7: launch_one<7, 1, 0>(grid, st, k); break;
             case 5: launch_one<5, 1, 0>(grid, st, k); break;
             case 3: launch_one<3, 1, 0>(grid, st, k); break;
@@ -607,6 +608,7 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     } else {
         switch (a->taps) {
             case 11: launch_one<11, 2, 0>(grid, st, k); break;
+            case 9: launch_one<9, 2, 0>(grid, st, k); break;
             case 7: launch_one<7, 2, 0>(grid, st, k); break;
             case 5: launch_one<5, 2, 0>(grid, st, k); break;
             case 3: launch_one<3, 2, 0>(grid, st, k); break;
@@ -626,7 +628,7 @@ __attribute__((visibility("hidden"))) void efts_gemm_init(void) {
     if (!once) {
         conv5_set_lds_attr();
         set_lds_attr<5, 1>(); set_lds_attr<3, 1>(); set_lds_attr<1, 1>(); set_lds_attr<5, 2>(); set_lds_attr<3, 2>(); set_lds_attr<1, 2>();
-        set_lds_attr<7, 1>(); set_lds_attr<11, 1>(); set_lds_attr<7, 2>(); set_lds_attr<11, 2>();
+        set_lds_attr<7, 1>(); set_lds_attr<11, 1>(); set_lds_attr<7, 2>(); set_lds_attr<11, 2>(); set_lds_attr<9, 1>(); set_lds_attr<9, 2>();
         once = true;
     }
 }

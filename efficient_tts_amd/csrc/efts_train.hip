@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void pack_t_kernel(const float* __restrict__ x
                                                      long ldp, long plane_stride, int split, int rows, int c, int shift0,
                                                      int nshift, int kpad) {
     // nshift planes (shift0, shift0+1, ...) from ONE staged (64 + nshift - 1)-row tile
-    __shared__ float tile[64 + 8][33];
+    __shared__ float tile[64 + 10][33];
     const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int r = ty; r < 64 + nshift - 1; r += 8) {
@@ -820,7 +820,7 @@ extern "C" int efts_pack_t(const float* x, int64_t ldx, void* plane, int64_t ld_
                            int32_t c, int32_t shift0, int32_t nshift, int32_t kpad, void* stream) {
     if (!x || !plane) return efts_fail(EFTS_EINVAL, "efts_pack_t: null pointer");
     if (kpad % 64 || ld_plane < (split == 1 ? kpad * 2 : kpad * 4)) return efts_fail(EFTS_ESHAPE, "efts_pack_t: kpad must be a multiple of 64 and fit ld_plane");
-    if (nshift < 1 || nshift > 9) return efts_fail(EFTS_ESHAPE, "efts_pack_t: nshift must be in 1..9");
+    if (nshift < 1 || nshift > 11) return efts_fail(EFTS_ESHAPE, "efts_pack_t: nshift must be in 1..11");
     hipLaunchKernelGGL(pack_t_kernel, dim3(kpad / 64, (c + 31) / 32), dim3(256), 0, ST, x, (long)ldx, (char*)plane, (long)ld_plane, (long)plane_stride,
                        split, rows, c, shift0, nshift, kpad);
     return efts_check_launch("efts_pack_t");

@@ -19,6 +19,33 @@ GUARD_HI = 144
 TILE_M = 128
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 ACT_BWD_BIAS_PARTS = 16
+# EFTS_ACTFN_* (include/efts_abi.h): torch.nn module name -> (id, names of the module's scalar parameters in p0 / p1 order with torch's defaults)
+ACTFN = {
+    "Identity": (0, ()), "ReLU": (1, ()), "LeakyReLU": (2, (("negative_slope", 0.01),)), "ELU": (3, (("alpha", 1.0),)),
+    "CELU": (4, (("alpha", 1.0),)), "SELU": (5, ()), "GELU": (6, ()), "SiLU": (8, ()), "Mish": (9, ()), "Tanh": (10, ()), "Sigmoid": (11, ()),
+    "Softplus": (12, (("beta", 1.0), ("threshold", 20.0))), "Hardtanh": (13, (("min_val", -1.0), ("max_val", 1.0))), "ReLU6": (13, ()),
+    "Hardswish": (14, ()), "Hardsigmoid": (15, ()), "Softsign": (16, ()), "Tanhshrink": (17, ()), "LogSigmoid": (18, ()),
+}
+
+
+def actfn(name: str, params: dict):
+    """(EFTS_ACTFN id, p0, p1) of torch.nn.<name>(**params), or None when the library has no form of it (learnable or non-pointwise
+    modules: PReLU, RReLU, Softmax, GLU, ...)"""
+    if name not in ACTFN:
+        return None
+    aid, keys = ACTFN[name]
+    extra = set(params) - {k for k, _ in keys} - {"inplace"} - ({"approximate"} if name == "GELU" else set())
+    if extra:
+        return None
+    if name == "GELU":
+        approx = params.get("approximate", "none")
+        if approx not in ("none", "tanh"):
+            return None
+        return (7 if approx == "tanh" else 6), 0.0, 0.0
+    if name == "ReLU6":
+        return aid, 0.0, 6.0
+    vals = [float(params.get(k, d)) for k, d in keys] + [0.0, 0.0]
+    return aid, vals[0], vals[1]
 TILING_AUTO, TILING_GENERIC, TILING_WIDE, TILING_NARROW, TILING_RESIDENT, TILING_SMALLM = 0, 1, 2, 3, 4, 5
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -104,6 +131,8 @@ _SIGS = {
     "efts_loss_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "efts_act_bwd": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, i64, i32, vp, i32, i32, vp]),
     "efts_act_bwd_dropout": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, i64, i32, vp, i32, i32, f32, C.c_uint32, vp]),
+    "efts_act_apply": (i32, [vp, vp, vp, i32, f32, f32, vp, vp, i64, i32, i32, i32, f32, C.c_uint32, vp]),
+    "efts_act_grad": (i32, [vp, vp, vp, i32, f32, f32, vp, vp, i64, i32, vp, i32, i32, f32, C.c_uint32, vp]),
     "efts_pack_t": (i32, [vp, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, vp]),
     "efts_wgrad_reduce": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
     "efts_wgrad_reduce_bias": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp, vp]),

@@ -183,14 +183,20 @@ class EfficientTTSCNN(torch.nn.Module):
         super().__init__()
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {list(PRECISIONS)}")
-        if nonlinear_activation not in ("LeakyReLU", "ReLU"):
-            raise NotImplementedError("the HIP conv epilogue implements LeakyReLU and ReLU (= slope 0); every reference config uses LeakyReLU")
+        # LeakyReLU (every reference config) and ReLU (= slope 0) live in the epilogues of the contraction kernels; the other pointwise
+        # torch.nn activations run as a separate elementwise launch behind the contraction (csrc/efts_act.hip)
+        act_general = None
+        if nonlinear_activation not in ("LeakyReLU", "ReLU") or set(nonlinear_activation_params) - {"negative_slope", "inplace"}:
+            act_general = L.actfn(nonlinear_activation, dict(nonlinear_activation_params))
+            if act_general is None:
+                raise NotImplementedError(f"nonlinear_activation={nonlinear_activation!r}({nonlinear_activation_params}): the library has forms of "
+                                          f"{sorted(L.ACTFN)} with their scalar parameters (learnable or non-pointwise modules have none)")
         if symbol_embedding_dim != n_channels:
             raise ValueError("symbol_embedding_dim must equal n_channels (the reference adds them residually)")
-        if k_size not in (1, 3, 5):
-            raise NotImplementedError("k_size must be 1, 3 or 5: the row space carries (5 - 1) / 2 = 2 zero gap rows between the items "
-                                      "(include/efts_abi.h EFTS_GAP); 5 (the value of every reference config) runs the mel-length stacks on "
-                                      "efts_resconv5, 1 and 3 on efts_gemm")
+        if k_size % 2 == 0 or not 1 <= k_size <= 11:
+            raise NotImplementedError("k_size must be odd and <= 11 (efts_gemm's tap counts; the guard rows in front of a row space hold "
+                                      "a padding of up to 5).  5, the value of every reference config, and 3 run the mel-length stacks on "
+                                      "efts_resconv5; 1, 7, 9 and 11 on efts_gemm")
         if use_weighted_masking:
             raise NotImplementedError("FastSpeechLoss(use_weighted_masking=True) is not implemented (no shipped config selects it)")
         if n_channels % 256 or odim > 128:
@@ -203,8 +209,10 @@ class EfficientTTSCNN(torch.nn.Module):
         self.share_text_encoder_key_value = share_text_encoder_key_value
         self.use_masking = bool(use_masking)        # False (the reference ctor default): the two losses are means over the padded tensors
         self.k_size = int(k_size)
+        self.row_gap = max(L.GAP, (self.k_size - 1) // 2)           # zero rows between the items of a row space (include/efts_abi.h "Row space")
         # LeakyReLU's own default slope is 0.01 (torch.nn.LeakyReLU); ReLU = slope 0 through the same epilogue
         self.slope = float(nonlinear_activation_params.get("negative_slope", 0.01)) if nonlinear_activation == "LeakyReLU" else 0.0
+        self.act_general = act_general                                # (EFTS_ACTFN id, p0, p1) or None = the fused (Leaky)ReLU
         self.dropout_rate = dropout_rate
         a, ap = nonlinear_activation, nonlinear_activation_params
         # construction order == reference (efficient_tts.py:57-112) so a given torch seed
@@ -345,7 +353,7 @@ class EfficientTTSCNN(torch.nn.Module):
         """tap_table [k_size][num_symbols][C] of text-encoder layer 0: tap k's weights applied to every symbol's embedding, in the
         operand format the model runs in (k_size one-tap efts_gemm launches over the embedding rows); rebuilt when the weights were
         re-packed.  None when the look-up form does not apply."""
-        if not self.embed_conv or len(self.text_encoder.layers) == 0 or self.n_channels % 32 or self._drop(0)[0] > 0.0:
+        if not self.embed_conv or len(self.text_encoder.layers) == 0 or self.n_channels % 32 or self._drop(0)[0] > 0.0 or self.k_size > 5 or self.act_general:
             return None                      # (a Dropout mask sits between layer 0's activation and its residual add: no look-up form)
         if getattr(self, "_te0_gen", None) == self._packed_gen and getattr(self, "_te0_tab", None) is not None:
             return self._te0_tab
@@ -450,14 +458,14 @@ class EfficientTTSCNN(torch.nn.Module):
     def _til(self, rows: int):
         """efts_gemm tiling for a 512-column launch over `rows` rows: the small-M kernel (64 x 32 tiles, K split across the waves:
         ~4x shorter dependent chain per layer) for one-utterance row spaces of the free-running path, else the library's rules"""
-        if self._free_running and self.small_m and rows <= self.SMALL_M_ROWS and self.n_channels % 32 == 0:
+        if self._free_running and self.small_m and rows <= self.SMALL_M_ROWS and self.n_channels % 32 == 0 and self.k_size <= 5:
             return L.TILING_SMALLM
         return None
 
     def _on_resconv(self, rs: Rows) -> bool:
         if self._drop(0)[0] > 0.0:           # conv Dropout in the pass in progress: efts_gemm's epilogue carries the masks
             return False
-        return self.resconv and rs.rows >= self.RESCONV_MIN_ROWS and self.n_channels % 256 == 0 and self.k_size in (3, 5)
+        return self.resconv and rs.rows >= self.RESCONV_MIN_ROWS and self.n_channels % 256 == 0 and self.k_size in (3, 5) and self.act_general is None
 
     def _stream_in(self, ws, tag, rs: Rows):
         """Buffers the producer of a residual stack's input writes: (fp32 stream or None, operand plane, lo plane or None).
@@ -514,6 +522,14 @@ class EfficientTTSCNN(torch.nn.Module):
             o_f32 = ws.f32(f"{tag}_f{i & 1}", rs, C) if (not last or last_f32) else None
             o_pl = ws.plane(f"{tag}_p{i & 1}", rs, C, o_split)
             dp_, dseed = self._drop(kbase + i)               # efts_modules.py:38-47: Dropout behind the activation, in front of the residual add
+            if self.act_general is not None:                 # any other torch.nn activation: pre-activation in fp32, then one elementwise launch
+                z = ws.f32(f"{tag}_z", rs, C)
+                O.gemm(a=x_pl, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=self.k_size, m=rs.rows, n=C,
+                       bias=getattr(self, blk).layers[i].conv[0].bias, out_f32_ptr=z.ptr, ldo=C, tiling=self._til(rs.rows))
+                o_f32 = ws.f32(f"{tag}_f{i & 1}", rs, C)
+                O.act_apply(self.act_general, z.ptr, x_f32.ptr, gap_ptr, o_f32, o_pl, rs.rows, C, dp_, dseed)
+                x_f32, x_pl = o_f32, o_pl
+                continue
             O.gemm(a=x_pl, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=self.k_size, m=rs.rows, n=C,
                    act=L.ACT_LEAKY, slope=self.slope, bias=getattr(self, blk).layers[i].conv[0].bias,
                    resid_ptr=x_f32.ptr, ldr=C, rowmask_ptr=gap_ptr,
@@ -698,7 +714,7 @@ class EfficientTTSCNN(torch.nn.Module):
         speech = speech.contiguous().float()
         pk = self._weights()
         ws = self._workspace(("fwd", B, T1, T2), dev)
-        rs1, rs2 = Rows(B, T1), Rows(B, T2)
+        rs1, rs2 = Rows(B, T1, self.row_gap), Rows(B, T2, self.row_gap)
         gap1, len1 = ws.tensor("gap1", (rs1.rows,)), ws.tensor("len1", (rs1.rows,))
         gap2, len2 = ws.tensor("gap2", (rs2.rows,)), ws.tensor("len2", (rs2.rows,))
         tl_d, ml_d = text_lengths.to(dev), speech_lengths.to(dev)
@@ -723,7 +739,13 @@ class EfficientTTSCNN(torch.nn.Module):
             pre_f, pre_p, pre_l = self._stream_in(ws, "pre", rs2)
             wp = pk["prenet"]
             pre_dp, pre_seed = self._drop(40)                                      # mel_prenet's Dropout (:76-80)
-            if pre_dp == 0.0 and self.fuse_prenet and self.odim % 8 == 0 and self.odim <= 128 and C % 128 == 0:
+            if self.act_general is not None:
+                mel_in = ws.plane("mel_in", rs2, self.odim, self.split)
+                O.pack_rows(speech, None, mel_in, rs2)
+                z = ws.f32("pre_z", rs2, C)
+                O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, bias=self.mel_prenet[0].bias, out_f32_ptr=z.ptr, ldo=C)
+                O.act_apply(self.act_general, z.ptr, None, gap2.data_ptr(), pre_f, pre_p, rs2.rows, C, pre_dp, pre_seed)
+            elif pre_dp == 0.0 and self.fuse_prenet and self.odim % 8 == 0 and self.odim <= 128 and C % 128 == 0:
                 # straight from the caller's fp32 frames: no operand plane of the mel input, one launch (bit-identical on every frame)
                 O.frame_linear(x=speech, w=wp, bias=self.mel_prenet[0].bias, act=L.ACT_LEAKY, slope=self.slope, rs=rs2,
                                y=pre_p, y_lo=pre_l, y_f32=pre_f, max_workgroups=max_wgs)
@@ -879,7 +901,7 @@ class EfficientTTSCNN(torch.nn.Module):
         T1, C = text.shape[1], self.n_channels
         pk = self._weights()
         ws = self._workspace(("inf", 1, T1), dev)
-        rs1 = Rows(1, T1)
+        rs1 = Rows(1, T1, self.row_gap)
         full = torch.full((1,), T1, dtype=torch.int32, device=dev)
         gap1 = ws.tensor("gap1", (rs1.rows,))
         O.row_masks(full, rs1, gap1, None)
@@ -892,7 +914,7 @@ class EfficientTTSCNN(torch.nn.Module):
             e = e - delta[:T1].view(1, T1)
         if t2 <= 0:
             raise ValueError("predicted total duration rounds to 0 frames")
-        rs2 = Rows(1, t2)
+        rs2 = Rows(1, t2, self.row_gap)
         ws2 = self._workspace(("inf2", 1, T1, t2), dev, pin=(ws,))
         gap2 = ws2.tensor("gap2", (rs2.rows,))
         O.row_masks(torch.full((1,), t2, dtype=torch.int32, device=dev), rs2, gap2, None)
@@ -910,7 +932,7 @@ class EfficientTTSCNN(torch.nn.Module):
         B, T1 = text.shape
         C = self.n_channels
         pk = self._weights()
-        rs1 = Rows(B, T1)
+        rs1 = Rows(B, T1, self.row_gap)
         gap1, len1 = ws.tensor("gap1", (rs1.rows,)), ws.tensor("len1", (rs1.rows,))
         O.row_masks(tl, rs1, gap1, len1)
         # embedding with padded positions zeroed, then every layer masked by the item length
@@ -948,7 +970,7 @@ class EfficientTTSCNN(torch.nn.Module):
         B, T1 = e.shape
         C = self.n_channels
         pk = self._weights()
-        rs1, rs2 = Rows(B, T1), Rows(B, T2)
+        rs1, rs2 = Rows(B, T1, self.row_gap), Rows(B, T2, self.row_gap)
         val_f = ws.f32("val_f", rs1, C)
         gap2, len2 = ws2.tensor("gap2", (rs2.rows,)), ws2.tensor("len2", (rs2.rows,))
         O.row_masks(ml, rs2, gap2, len2)

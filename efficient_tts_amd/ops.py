@@ -79,8 +79,10 @@ def chunk_k(split: int) -> int:
 class Rows:
     """Geometry of a padded row space (include/efts_abi.h "Row space")."""
 
-    def __init__(self, B: int, T: int):
-        self.B, self.T, self.Tp = B, T, T + L.GAP
+    def __init__(self, B: int, T: int, gap: int = L.GAP):
+        # gap: zero rows behind every item, >= the widest convolution's padding on this row space (L.GAP = 2 for k5; a model with
+        # k_size 7 / 9 / 11 builds its row spaces with 3 / 4 / 5)
+        self.B, self.T, self.Tp, self.gap = B, T, T + gap, gap
         self.rows = B * self.Tp
         self.alloc = L.GUARD_LO + roundup(self.rows, L.TILE_M) + L.GUARD_HI
 
@@ -329,6 +331,23 @@ def pack_rows(x: torch.Tensor, out: Optional[F32Rows], plane: Optional[Plane], r
                                     None if plane is None else plane.ptr, 0 if plane is None else plane.ld,
                                     rs.B, rs.T, rs.Tp, c, kp, 1 if plane is None else plane.split, _stream()),
             "efts_pack_rows")
+
+
+def act_apply(act, z_ptr: int, resid_ptr: Optional[int], rowmask_ptr: Optional[int], y: Optional[F32Rows], plane: Optional[Plane],
+              rows: int, c: int, drop_p: float = 0.0, drop_seed: int = 0) -> None:
+    """y = (resid + Dropout(f(z))) * rowmask for a torch.nn activation outside the contraction epilogues (csrc/efts_act.hip);
+    act = (EFTS_ACTFN id, p0, p1)"""
+    L.check(L.load().efts_act_apply(z_ptr, resid_ptr, rowmask_ptr, act[0], act[1], act[2], None if y is None else y.ptr,
+                                    None if plane is None else plane.ptr, 0 if plane is None else plane.ld, 1 if plane is None else plane.split,
+                                    rows, c, drop_p, drop_seed & 0xFFFFFFFF, _stream()), "efts_act_apply")
+
+
+def act_grad(act, g_ptr: int, z_ptr: int, rowmask_ptr: Optional[int], dz: Optional[F32Rows], plane: Optional[Plane], dbias, rows: int, c: int,
+             drop_p: float = 0.0, drop_seed: int = 0) -> None:
+    """dZ = G * rowmask * Dropout'(.) * f'(z), bias gradient += column sums"""
+    L.check(L.load().efts_act_grad(g_ptr, z_ptr, rowmask_ptr, act[0], act[1], act[2], None if dz is None else dz.ptr,
+                                   None if plane is None else plane.ptr, 0 if plane is None else plane.ld, 1 if plane is None else plane.split,
+                                   _p(dbias), rows, c, drop_p, drop_seed & 0xFFFFFFFF, _stream()), "efts_act_grad")
 
 
 def attn_soft_index(scores, ld, tl, ml, soft_idx, alpha_out, B, T1, T2) -> None:

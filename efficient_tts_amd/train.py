@@ -249,6 +249,15 @@ class TrainEngine:
             o_f = ws.f32(f"T{tag}_f{i}", rs, C)
             o_p = ws.plane(f"T{tag}_p{i}", rs, C, last_split if last else m.split)
             dp, dseed = self._conv_drop(dict(te=10, me=20, dec=30)[tag] + i)
+            if m.act_general is not None:
+                # a torch.nn activation outside the contraction epilogues (csrc/efts_act.hip): the pre-activation is kept in fp32 for f'(z)
+                z = ws.f32(f"T{tag}_z{i}", rs, C)
+                O.gemm(a=x_p, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=m.k_size, m=rs.rows, n=C, bias=layer.conv[0].bias,
+                       out_f32_ptr=z.ptr, ldo=C)
+                O.act_apply(m.act_general, z.ptr, x_f.ptr, gap_ptr, o_f, o_p, rs.rows, C, dp, dseed)
+                saved.append((x_f, o_f, x_p, (z, "z"), dp, dseed))
+                x_f, x_p = o_f, o_p
+                continue
             # under Dropout y - x no longer carries the activation's sign where the element was dropped: always the sign words then
             sg = ws.tensor(f"T{tag}_sg{i}", (rs.rows, C // 8), torch.uint8) if ((0 < _SIGN_MIN_ROWS <= rs.rows or dp > 0) and C % 128 == 0) else None
             O.gemm(a=x_p, b_ptr=w.ptr, ldb=w.ld, b_tap_stride=w.tap_stride, taps=m.k_size, m=rs.rows, n=C, act=L.ACT_LEAKY, slope=m.slope,
@@ -267,7 +276,7 @@ class TrainEngine:
             conv = layers[i].conv[0]
             pre = f"{blk}.layers.{i}.conv.0."
             dz_p = ws.plane(f"B{tag}_dzp", rs, C, m.split)
-            direct = _WGRAD_TN_SPLITS > 0 and C % 128 == 0 and x_pl.split == dz_p.split
+            direct = _WGRAD_TN_SPLITS > 0 and C % 128 == 0 and x_pl.split == dz_p.split and m.k_size <= 5     # (efts_wgrad_tn: taps 1 / 3 / 5)
             # the direct wgrad and the dgrad both read dZ as the bf16 plane: its fp32 copy is only written for the
             # transposed-plane path
             dz_f = None if direct else ws.f32(f"B{tag}_dz", rs, C)
@@ -275,7 +284,10 @@ class TrainEngine:
             # (no same-address atomics: ~8 of 22 us per launch at mel length)
             bp = ws.tensor(f"B{tag}_bp", ((rs.rows + 63) // 64, C)) if (direct and _BIAS_PARTS) else None
             db, parts = (bp, L.ACT_BWD_BIAS_PARTS) if bp is not None else (self.g[pre + "bias"], 0)
-            if sg is not None:                                   # (sign words of efts_gemm: mode 4; sign bits of efts_resconv5: mode 5)
+            if sg is not None and sg[1] == "z":                  # general activation: f'(z) from the kept pre-activation, bias gradient by atomics
+                bp = None
+                O.act_grad(m.act_general, G.ptr, sg[0].ptr, gap_ptr, dz_f, dz_p, self.g[pre + "bias"], rs.rows, C, dp, dseed)
+            elif sg is not None:                                 # (sign words of efts_gemm: mode 4; sign bits of efts_resconv5: mode 5)
                 self._act_bwd(G.ptr, sg[0].data_ptr(), None, gap_ptr, sg[1] | parts, dz_f, dz_p, db, rs.rows, C, dp, dseed)
             else:
                 self._act_bwd(G.ptr, y_f.ptr, x_f.ptr, gap_ptr, 1 | parts, dz_f, dz_p, db, rs.rows, C, dp, dseed)
@@ -320,7 +332,7 @@ class TrainEngine:
         ml = speech_lengths.to(device=dev, dtype=torch.int32)
         pk = self._prepare_weights()
         ws = m._workspace(("train", B, T1, T2), dev)
-        rs1, rs2 = Rows(B, T1), Rows(B, T2)
+        rs1, rs2 = Rows(B, T1, m.row_gap), Rows(B, T2, m.row_gap)
         gap1, len1 = ws.tensor("gap1", (rs1.rows,)), ws.tensor("len1", (rs1.rows,))
         gap2, len2 = ws.tensor("gap2", (rs2.rows,)), ws.tensor("len2", (rs2.rows,))
         O.row_masks(tl, rs1, gap1, len1)
@@ -395,7 +407,12 @@ class TrainEngine:
         pre_f, pre_p = ws.f32("Tpre_f", rs2, C), ws.plane("Tpre_p", rs2, C, split)
         wp = pk["prenet"]
         pre_dp, pre_seed = self._conv_drop(40)                       # mel_prenet's Dropout (efficient_tts.py:76-80)
-        if pre_dp == 0.0 and m.fuse_prenet and odim % 8 == 0 and odim <= 128 and C % 128 == 0:
+        pre_z = None
+        if m.act_general is not None:
+            pre_z = ws.f32("Tpre_z", rs2, C)
+            O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, bias=m.mel_prenet[0].bias, out_f32_ptr=pre_z.ptr, ldo=C)
+            O.act_apply(m.act_general, pre_z.ptr, None, gap2.data_ptr(), pre_f, pre_p, rs2.rows, C, pre_dp, pre_seed)
+        elif pre_dp == 0.0 and m.fuse_prenet and odim % 8 == 0 and odim <= 128 and C % 128 == 0:
             # no Dropout on the prenet (the shipped recipe): straight from the caller's frames, whole-line stores (efts_frame_linear;
             # bit-identical to the launch below)
             O.frame_linear(x=speech, w=wp, bias=m.mel_prenet[0].bias, act=L.ACT_LEAKY, slope=m.slope, rs=rs2, y=pre_p, y_f32=pre_f)
@@ -617,7 +634,10 @@ class TrainEngine:
         if self.mark is not None:
             self.mark("bwd_mel_encoder_done")
         dzp_f = ws.f32("Bpre_dz", rs2, C)
-        self._act_bwd(Gm.ptr, pre_f.ptr, None, gap2.data_ptr(), 3, dzp_f, None, g["mel_prenet.0.bias"], rs2.rows, C, pre_dp, pre_seed)
+        if pre_z is not None:
+            O.act_grad(m.act_general, Gm.ptr, pre_z.ptr, gap2.data_ptr(), dzp_f, None, g["mel_prenet.0.bias"], rs2.rows, C, pre_dp, pre_seed)
+        else:
+            self._act_bwd(Gm.ptr, pre_f.ptr, None, gap2.data_ptr(), 3, dzp_f, None, g["mel_prenet.0.bias"], rs2.rows, C, pre_dp, pre_seed)
         self._wgrad(ws, dzp_f.ptr, C, mel_in_f.ptr, odim, odim, 1, rs2.rows, None, None, g["mel_prenet.0.weight"], None)
         if self.bucket_hook:
             self.bucket_hook(1)

@@ -79,7 +79,7 @@ typedef struct efts_gemm_args {
     int64_t b_tap_stride;
     int64_t b_batch_stride;
     int32_t split;  /* 1 = bf16, 2 = bf16x3 (hi/lo interleaved) */
-    int32_t taps;   /* 1, 3, 5, 7 or 11 */
+    int32_t taps;   /* 1, 3, 5, 7, 9 or 11 */
     int32_t m;      /* rows per batch item */
     int32_t n;      /* output columns */
     int32_t nchunk; /* 128-byte K chunks per row */
@@ -451,6 +451,37 @@ int efts_act_bwd_dropout(const float* g, const float* y, const float* x, const f
 int efts_act_bwd(const float* g, const float* y, const float* x, const float* rowmask, float slope, int32_t mode,
                  float* dz, void* plane, int64_t ld_plane, int32_t split, float* dbias, int32_t rows, int32_t c,
                  void* stream);
+/* The residual layer's non-linearity when it is not (Leaky)ReLU: the reference builds getattr(torch.nn, nonlinear_activation)(**params)
+ * into every ResConv1d and into the mel prenet (nntts/layers/efts_modules.py:32-35, nntts/models/efficient_tts.py:76-80).  The contraction then
+ * writes the pre-activation z = conv(x) + bias in fp32 (efts_gemm with EFTS_ACT_NONE) and these two elementwise launches do the rest.
+ * p0 / p1: the module's scalar parameters, in the order of the comments below (unused ones are ignored). */
+#define EFTS_ACTFN_IDENTITY 0
+#define EFTS_ACTFN_RELU 1
+#define EFTS_ACTFN_LEAKY_RELU 2  /* p0 = negative_slope */
+#define EFTS_ACTFN_ELU 3         /* p0 = alpha */
+#define EFTS_ACTFN_CELU 4        /* p0 = alpha */
+#define EFTS_ACTFN_SELU 5
+#define EFTS_ACTFN_GELU 6        /* approximate="none" (erf) */
+#define EFTS_ACTFN_GELU_TANH 7   /* approximate="tanh" */
+#define EFTS_ACTFN_SILU 8
+#define EFTS_ACTFN_MISH 9
+#define EFTS_ACTFN_TANH 10
+#define EFTS_ACTFN_SIGMOID 11
+#define EFTS_ACTFN_SOFTPLUS 12   /* p0 = beta, p1 = threshold */
+#define EFTS_ACTFN_HARDTANH 13   /* p0 = min_val, p1 = max_val (ReLU6 = 0, 6) */
+#define EFTS_ACTFN_HARDSWISH 14
+#define EFTS_ACTFN_HARDSIGMOID 15
+#define EFTS_ACTFN_SOFTSIGN 16
+#define EFTS_ACTFN_TANHSHRINK 17
+#define EFTS_ACTFN_LOGSIGMOID 18
+#define EFTS_ACTFN_COUNT 19
+/* y = (resid + Dropout(f(z))) * rowmask over [rows][c] fp32 (c % 4 == 0): y_f32 and / or the operand plane (either may be NULL, not both);
+ * resid, rowmask may be NULL; Dropout as in the argument block of efts_gemm: drop_p / drop_seed, element index row * c + col */
+int efts_act_apply(const float* z, const float* resid, const float* rowmask, int32_t act, float p0, float p1, float* y_f32, void* plane,
+                   int64_t ld_plane, int32_t split, int32_t rows, int32_t c, float drop_p, uint32_t drop_seed, void* stream);
+/* dZ = G * rowmask * Dropout'(.) * f'(z): dz (fp32) and / or the operand plane; dbias (may be NULL) += column sums of dZ (atomic adds) */
+int efts_act_grad(const float* g, const float* z, const float* rowmask, int32_t act, float p0, float p1, float* dz, void* plane,
+                  int64_t ld_plane, int32_t split, float* dbias, int32_t rows, int32_t c, float drop_p, uint32_t drop_seed, void* stream);
 /* transposed operand planes out_s[ch][t] = x[t + shift0 + s][ch], s = 0..nshift-1 (plane s at
  * plane + s*plane_stride bytes), K = t padded with zeros to kpad: the wgrad operands of all taps
  * from one pass over x */

@@ -39,6 +39,8 @@ DEFAULT_HP = dict(
     n_duration_layer=2,
     k_size=5,
     leaky_slope=0.1,
+    activation=None,                       # (torch.nn module name, its keyword arguments) for a nonlinear_activation other than LeakyReLU
+                                           # (efts_modules.py:32-35, efficient_tts.py:76-80: getattr(torch.nn, name)(**params)); None: leaky_slope
     duration_offset=1.0,
     sigma=0.01,
     sigma_e=0.5,
@@ -149,13 +151,26 @@ def conv_weight(P: Params, prefix: str) -> torch.Tensor:
     return weight_norm_fold(P[prefix + "weight_v"], P[prefix + "weight_g"])
 
 
-def res_conv_block(x: torch.Tensor, P: Params, blk: str, n_layers: int, slope: float) -> torch.Tensor:
-    """x[B,C,T] -> n x ( x + LeakyReLU(conv1d_k(x)) ), no masking between layers
+def act_of(hp: dict):
+    """the stacks' and the prenet's non-linearity: LeakyReLU(leaky_slope) (every reference config), or the torch.nn module the
+    reference's ctor would build from (nonlinear_activation, nonlinear_activation_params) (efts_modules.py:32-35)"""
+    if hp.get("activation"):
+        name, params = hp["activation"]
+        return getattr(torch.nn, name)(**params)
+    slope = hp["leaky_slope"]
+    return lambda t: F.leaky_relu(t, slope)
+
+
+def res_conv_block(x: torch.Tensor, P: Params, blk: str, n_layers: int, act) -> torch.Tensor:
+    """x[B,C,T] -> n x ( x + act(conv1d_k(x)) ), no masking between layers; act = act_of(hp) (or a LeakyReLU slope)
     (nntts/layers/efts_modules.py:48-51,77-79; dropout_rate 0.0 => no Dropout module :30-37)."""
+    if not callable(act):
+        slope = float(act)
+        act = lambda t: F.leaky_relu(t, slope)                                   # noqa: E731
     for i in range(n_layers):
         p = f"{blk}.layers.{i}.conv.0."
         w = conv_weight(P, p)
-        x = x + F.leaky_relu(F.conv1d(x, w, P[p + "bias"], padding=(w.shape[-1] - 1) // 2), slope)
+        x = x + act(F.conv1d(x, w, P[p + "bias"], padding=(w.shape[-1] - 1) // 2))
     return x
 
 
@@ -242,7 +257,7 @@ def text_side(P: Params, text: torch.Tensor, hp: dict):
     """embed -> text encoder -> key, value  (efficient_tts.py:144-153 / :246-255)."""
     emb = P["text_embedding_table.weight"][text]                                  # [B,T1,C]
     h = res_conv_block(emb.transpose(1, 2), P, "text_encoder", hp["n_text_encoder_layer"],
-                       hp["leaky_slope"]).transpose(1, 2)
+                       act_of(hp)).transpose(1, 2)
     key = F.linear(h, P["text_encoder_key.weight"], P["text_encoder_key.bias"])
     if hp.get("share_text_encoder_key_value", False):                             # :150-151 / :252-253
         val = key
@@ -253,7 +268,7 @@ def text_side(P: Params, text: torch.Tensor, hp: dict):
 
 def decode(P: Params, expanded: torch.Tensor, hp: dict) -> torch.Tensor:
     """[B,C,T2] -> decoder -> mel head [B,T2,odim]  (efficient_tts.py:197-198 / :283-284)."""
-    d = res_conv_block(expanded, P, "decoder", hp["n_decoder_layer"], hp["leaky_slope"])
+    d = res_conv_block(expanded, P, "decoder", hp["n_decoder_layer"], act_of(hp))
     return F.linear(d.transpose(1, 2), P["mel_output_layer.weight"], P["mel_output_layer.bias"])
 
 
@@ -270,10 +285,9 @@ def forward(P: Params, text: torch.Tensor, text_lengths: torch.Tensor, speech: t
     key = key * text_mask[:, :, None]                                           # :155-157
     val = val * text_mask[:, :, None]
 
-    pre = F.leaky_relu(F.linear(speech, P["mel_prenet.0.weight"], P["mel_prenet.0.bias"]),
-                       hp["leaky_slope"])                                       # :161
+    pre = act_of(hp)(F.linear(speech, P["mel_prenet.0.weight"], P["mel_prenet.0.bias"]))   # :161 (:76-80)
     mel_h = res_conv_block(pre.transpose(1, 2), P, "mel_encoder", hp["n_mel_encoder_layer"],
-                           hp["leaky_slope"]).transpose(1, 2)                   # :162
+                           act_of(hp)).transpose(1, 2)                          # :162
     if hp.get("use_mel_query_fc", False):                                        # :163-164
         mel_h = F.linear(mel_h, P["mel_query_fc.weight"], P["mel_query_fc.bias"])
 

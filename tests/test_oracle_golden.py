@@ -110,7 +110,8 @@ def test_train3_matches_reference(golden_dir, params):
 
 
 VARIANTS = dict(nomask=dict(use_masking=False), sharekv=dict(share_text_encoder_key_value=True), queryfc=dict(use_mel_query_fc=True),
-                delta2=dict(delta_e_method_1=False), k3=dict(k_size=3), relu=dict(leaky_slope=0.0))     # (relu: the reference ctor's nonlinear_activation="ReLU")
+                delta2=dict(delta_e_method_1=False), k3=dict(k_size=3), relu=dict(leaky_slope=0.0), k7=dict(k_size=7), k11=dict(k_size=11),
+                gelu=dict(activation=("GELU", {})), elu=dict(activation=("ELU", {"alpha": 0.7})))     # (relu: the reference ctor's nonlinear_activation="ReLU")
 
 
 @pytest.mark.parametrize("name", list(VARIANTS))
@@ -133,11 +134,12 @@ def test_ctor_option_variants_match_reference(golden_dir, name):
         flat = p.grad.reshape(-1).numpy()
         if "grad_stride:" + k in g.files:
             flat = flat[:: int(g["grad_stride:" + k])]
-        if k == "text_encoder_key.bias" and np.abs(ref).max() <= 1e-5:    # identically zero (softmax shift invariance) unless the value
-            assert np.abs(flat).max() <= 1e-5                             # shares the key projection: fp noise on both sides
+        noise = 1e-7 * max(100.0, float(g["loss"]))                       # (fp noise grows with the loss: 863 with k_size 11, ~50-130 otherwise)
+        if k == "text_encoder_key.bias" and np.abs(ref).max() <= noise:   # identically zero (softmax shift invariance) unless the value
+            assert np.abs(flat).max() <= noise                            # shares the key projection: fp noise on both sides
             continue
         assert np.abs(flat - ref).max() <= 2e-4 * max(float(np.abs(ref).max()), 1e-3), (name, k)
-    if name in ("sharekv", "delta2", "k3"):
+    if name in ("sharekv", "delta2", "k3", "k7", "k11", "gelu", "elu"):
         o = O.inference(O.fill_params(hp), torch.from_numpy(g["inf_text"]), hp)
         assert o["mel_pred"].shape[1] == int(g["inf_t2"])
         assert float((o["mel_pred"] - torch.from_numpy(g["inf_mel_pred"])).abs().max()) <= 5e-4

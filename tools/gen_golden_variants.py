@@ -2,7 +2,7 @@
 """Golden fixtures for the ctor options outside the shipped YAML (efficient_tts.py:43-48), produced by the REFERENCE itself
 (build container only):
 
-    PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden_variants.py
+    PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden_variants.py [name ...]
 
 use_masking=False (the ctor default), share_text_encoder_key_value=True, use_mel_query_fc=True, delta_e_method_1=False, each on
 the ragged (2, 16, 64) case of gen_golden.py with parameter gradients (strided samples + norms); share_text_encoder_key_value and
@@ -25,15 +25,22 @@ VARIANTS = dict(
     delta2=dict(delta_e_method_1=False),
     k3=dict(k_size=3),                                              # ResConv1d's kernel size (efts_modules.py:19-46)
     relu=dict(nonlinear_activation="ReLU", nonlinear_activation_params={}),   # ... and its activation
+    k7=dict(k_size=7),                                              # kernel sizes past the shipped 5: row spaces with 3 / 5 gap rows,
+    k11=dict(k_size=11),                                            # the stacks on efts_gemm's 7- / 11-tap forms
+    gelu=dict(nonlinear_activation="GELU", nonlinear_activation_params={}),                 # any other torch.nn activation (efts_modules.py:32-35):
+    elu=dict(nonlinear_activation="ELU", nonlinear_activation_params={"alpha": 0.7}),       # a smooth one and one with a parameter
 )
 # what the oracle's hyper-parameter dict calls an option, where it differs from the reference ctor's keyword
-ORACLE_HP = dict(relu=dict(leaky_slope=0.0))
+ORACLE_HP = dict(relu=dict(leaky_slope=0.0), gelu=dict(activation=("GELU", {})), elu=dict(activation=("ELU", {"alpha": 0.7})))
 
 
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    only = set(sys.argv[1:])                                         # (names on the command line: only those fixtures are rewritten)
     for name, opt in VARIANTS.items():
+        if only and name not in only:
+            continue
         hp = dict(O.DEFAULT_HP, **ORACLE_HP.get(name, opt))
         kw = dict(num_symbols=76, dropout_rate=0.0, use_masking=True, use_weighted_masking=False, sigma=0.01)
         kw.update(opt)
@@ -69,7 +76,7 @@ def main():
             d["grad:" + k] = flat
             d["gradnorm:" + k] = np.float64(g.double().norm())
         print(f"  [{name}] oracle vs reference param-grad worst rel-to-max {worst:.3e}")
-        if name in ("sharekv", "delta2", "k3"):                # free-running path: value = key (:252-253) / positions from 0 (:261-265) / k3 stacks
+        if name in ("sharekv", "delta2", "k3", "k7", "k11", "gelu", "elu"):                # free-running path: value = key (:252-253) / positions from 0 (:261-265) / k3 stacks
             ids = torch.randint(1, 76, (1, 23), generator=torch.Generator().manual_seed(5))
             m.remove_weight_norm()
             with torch.no_grad():
