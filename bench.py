@@ -599,13 +599,19 @@ def conv_roofline(P, model, step, B, T2, precision, workload, a=None):
                 mfma_issue_frac=(3 if model.split == 2 else 1) * flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS)
 
 
-def _watchdog(seconds, rank, res, key):
-    """a timer that, when it fires, prints rank 0's line (with `key` marked as abandoned) and ends the process; .cancel() disarms it"""
+def _watchdog(seconds, rank, res, key, partial=None):
+    """a timer that, when it fires, prints rank 0's line (with `key` marked as abandoned, or holding what `partial()` returns: the part of
+    the record that had been measured) and ends the process; .cancel() disarms it"""
     import threading
 
     def fire():
         if res is not None and rank == 0:
-            res.setdefault(key, dict(error=f"abandoned after {seconds} s without finishing (a rank hung); the rest of the line stands"))
+            note = f"abandoned after {seconds} s without finishing (a rank hung); the rest of the line stands"
+            part = partial() if partial is not None else None
+            if isinstance(part, dict):
+                part.setdefault("config", {})["watchdog"] = note
+                res.setdefault(key, part)
+            res.setdefault(key, dict(error=note))
             try:
                 print(json.dumps(res), flush=True)
             except Exception:                                          # noqa: BLE001
@@ -751,7 +757,7 @@ def run_forward(a, world, rank, dev, wl):
         # N > 1: the forward result above must survive whatever the data-parallel record runs into on hardware this code has not seen
         # (a rank that fails alone leaves the others inside a collective).  An exception costs the record, not the line; a hang is
         # cut by a watchdog that prints the line with what there is and ends the process on every rank.
-        dog = _watchdog(int(os.environ.get("EFTS_BENCH_DP_TIMEOUT", "240")), rank, res, "train32") if world > 1 else None
+        dog = _watchdog(int(os.environ.get("EFTS_BENCH_DP_TIMEOUT", "240")), rank, res, "train32", partial=lambda: getattr(a, "partial_train", None)) if world > 1 else None
         failed = False
         try:
             tr = measure_train(a, world, rank, dev, WORKLOADS["train32"], steps=40, warmup=10)      # (None on ranks other than 0)

@@ -117,6 +117,52 @@ def measure_train(a, world, rank, dev, wl, steps, warmup, precision=None):
 
     rows = P.Rows(B, T2).rows
     want_graph = bool(getattr(a, "train_graph", 1))
+
+    def finish(dt, issue, lv, durs, eager_dt, graph_dt, graph_note, poisoned):
+        """the record from what has been measured (rank 0; None elsewhere)"""
+        assert lv == lv, "NaN loss"
+        avg = sum(durs) / max(len(durs), 1)
+        conv_flop = 2.0 * B * T2 * 512 * 512 * 5
+        from . import train as _tr
+        split = model.split
+        dg = _tr._RESCONV_DGRAD if _tr._RESCONV_DGRAD >= 0 else (1 if split == 1 else 3)
+        on_rc = model._on_resconv(P.Rows(B, T2))
+        big = split == 1 and ((rows + 251) // 252) * 4 >= 400           # efts_gemm's own rule for the 256-row kernel
+        other = "conv5_kernel<split=1> (256-row tiles)" if big else f"gemm_kernel<taps=5,split={split}> (124-row tiles)"
+        if on_rc and _tr._RESCONV_FWD:
+            kname = (f"the k5 launches at mel length: resconv5_kernel<split={split}> (forward of the stacks selected by _RESCONV_FWD={_tr._RESCONV_FWD}, "
+                     f"dgrad of those selected by {dg}: bit 0 decoder, bit 1 mel encoder) and {other} (the rest)")
+        else:
+            kname = other
+        if rank != 0:
+            return None
+        frames = world * B * T2 * steps
+        res = dict(metric="mel-frames/sec (EFTS-CNN training step, batch 32/GPU, 80-mel LJSpeech shape)", value=frames / dt,
+                   unit="mel-frames/s", n_gpus=world, steps=steps, warmup=warmup, ms_per_step=dt / steps * 1e3,
+                   higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="bf16" if precision == "bf16" else "bf16x3 (split-bf16 MFMA, fp32-class)", data="synthetic",
+                   config=dict(workload=wl["desc"], batch_per_gpu=B, phoneme_len=T1, mel_len=T2, precision=precision,
+                               parallelism=f"dp{world}", optimizer="Adam-amsgrad fused, clip 1.0, WarmupLR 4000",
+                               allreduce="RCCL, 3 buckets overlapped with backward" if world > 1 else "none", step_issue=issue),
+                   eager_ms_per_step=None if eager_dt is None else eager_dt / steps * 1e3,
+                   graph_ms_per_step=None if graph_dt is None else graph_dt / steps * 1e3,
+                   per_gpu=frames / dt / world, tflops=TRAIN_FLOP_PER_ITEM * B * world * steps / dt / 1e12, loss=lv,
+                   roofline=dict(bound="mfma", kernel=f"{kname}; fwd + dgrad launches, timed with events in the eager loop while the text-length stream runs beside them",
+                                 achieved=conv_flop / avg / 1e12 if avg else None, peak=2500.0, unit="TFLOP/s",
+                                 frac=conv_flop / avg / 1e12 / 2500.0 if avg else None, traffic=None,
+                                 avg_launch_us=avg * 1e6, launches_measured=len(durs)))
+        if graph_note:
+            res["config"]["graph_note"] = graph_note
+        if world > 1 and poisoned:
+            res["config"]["device_state"] = "a failed capture left streams in capture mode: no further device work in this process"
+        if ddp is not None:
+            # the last eager step's communication: one record that explains the scaling number (backend, ranks, algorithm,
+            # bytes and time per bucket, how much of it the backward did NOT hide)
+            res["dp"] = dict(backend=dist.get_backend(), ranks=dist.get_world_size(), grad_mb=ddp.engine.numel * 4 / 1e6,
+                             nccl_env={k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))},
+                             selfcheck=selfcheck, rccl_log=_rccl_log_lines(), **(dp_stats or {}))
+        return res
+
     selfcheck, dp_stats, eager_dt, graph_dt, graph_note, poisoned = None, None, None, None, None, False
     if world > 1:
         # ---- (1) self-validation before anything is timed
@@ -144,6 +190,8 @@ def measure_train(a, world, rank, dev, wl, steps, warmup, precision=None):
         # raises -- the eager numbers above must survive that, so everything from here on is inside one try, and the record is put
         # together from host values only.  gloo cannot be captured at all (its collectives synchronise the host): not attempted.
         poisoned = False
+        # what a watchdog prints if the attempt below never returns (bench.py, N > 1): the eager data-parallel record as it stands
+        a.partial_train = finish(eager_dt, "eager launches", lv_eager, durs, eager_dt, None, "graph attempt did not return: eager loop timed", False)
         if want_graph and backend != "nccl":
             graph_note = f"{backend} collectives cannot be captured; eager loop timed"
         elif want_graph:
@@ -200,53 +248,27 @@ def measure_train(a, world, rank, dev, wl, steps, warmup, precision=None):
         P.PROFILE, P.PROFILE_TAG = None, None
         issue = "one hipGraph replay per step (step_graph.GraphedStep)" if graphed is not None else "eager launches"
     lv = lv_eager if world > 1 else float(loss)
-    assert lv == lv, "NaN loss"
-    avg = sum(durs) / max(len(durs), 1)
-    conv_flop = 2.0 * B * T2 * 512 * 512 * 5
-    from . import train as _tr
-    split = model.split
-    dg = _tr._RESCONV_DGRAD if _tr._RESCONV_DGRAD >= 0 else (1 if split == 1 else 3)
-    on_rc = model._on_resconv(P.Rows(B, T2))
-    big = split == 1 and ((rows + 251) // 252) * 4 >= 400           # efts_gemm's own rule for the 256-row kernel
-    other = "conv5_kernel<split=1> (256-row tiles)" if big else f"gemm_kernel<taps=5,split={split}> (124-row tiles)"
-    if on_rc and _tr._RESCONV_FWD:
-        kname = (f"the k5 launches at mel length: resconv5_kernel<split={split}> (forward of the stacks selected by _RESCONV_FWD={_tr._RESCONV_FWD}, "
-                 f"dgrad of those selected by {dg}: bit 0 decoder, bit 1 mel encoder) and {other} (the rest)")
-    else:
-        kname = other
-    if rank != 0:
-        return None
-    frames = world * B * T2 * steps
-    res = dict(metric="mel-frames/sec (EFTS-CNN training step, batch 32/GPU, 80-mel LJSpeech shape)", value=frames / dt,
-               unit="mel-frames/s", n_gpus=world, steps=steps, warmup=warmup, ms_per_step=dt / steps * 1e3,
-               higher_is_better=True, scaling="weak", vs_baseline=None,
-               dtype="bf16" if precision == "bf16" else "bf16x3 (split-bf16 MFMA, fp32-class)", data="synthetic",
-               config=dict(workload=wl["desc"], batch_per_gpu=B, phoneme_len=T1, mel_len=T2, precision=precision,
-                           parallelism=f"dp{world}", optimizer="Adam-amsgrad fused, clip 1.0, WarmupLR 4000",
-                           allreduce="RCCL, 3 buckets overlapped with backward" if world > 1 else "none", step_issue=issue),
-               eager_ms_per_step=None if eager_dt is None else eager_dt / steps * 1e3,
-               graph_ms_per_step=None if graph_dt is None else graph_dt / steps * 1e3,
-               per_gpu=frames / dt / world, tflops=TRAIN_FLOP_PER_ITEM * B * world * steps / dt / 1e12, loss=lv,
-               roofline=dict(bound="mfma", kernel=f"{kname}; fwd + dgrad launches, timed with events in the eager loop while the text-length stream runs beside them",
-                             achieved=conv_flop / avg / 1e12 if avg else None, peak=2500.0, unit="TFLOP/s",
-                             frac=conv_flop / avg / 1e12 / 2500.0 if avg else None, traffic=None,
-                             avg_launch_us=avg * 1e6, launches_measured=len(durs)))
-    if graph_note:
-        res["config"]["graph_note"] = graph_note
-    if world > 1 and poisoned:
-        res["config"]["device_state"] = "a failed capture left streams in capture mode: no further device work in this process"
-    if ddp is not None:
-        # the last eager step's communication: one record that explains the scaling number (backend, ranks, algorithm,
-        # bytes and time per bucket, how much of it the backward did NOT hide)
-        res["dp"] = dict(backend=dist.get_backend(), ranks=dist.get_world_size(), grad_mb=ddp.engine.numel * 4 / 1e6,
-                         nccl_env={k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))},
-                         selfcheck=selfcheck, rccl_log=_rccl_log_lines(), **(dp_stats or {}))
-    return res
+    return finish(dt, issue, lv, durs, eager_dt, graph_dt, graph_note, poisoned)
 
 
 def run_train(a, world, rank, dev, wl, cpu_baseline_fn=None):
+    import threading
     import torch.distributed as dist
+    dog = None
+    if world > 1:
+        # a captured-step attempt that never returns must not take the eager data-parallel record with it (bench.py's watchdog, same idea)
+        def fire():
+            part = getattr(a, "partial_train", None)
+            if rank == 0 and isinstance(part, dict):
+                part.setdefault("config", {})["watchdog"] = "the run did not finish in time (a rank hung): the eager record as it stood"
+                print(json.dumps(part), flush=True)
+            os._exit(0 if isinstance(part, dict) or rank != 0 else 3)
+        dog = threading.Timer(int(os.environ.get("EFTS_BENCH_DP_TIMEOUT", "240")), fire)
+        dog.daemon = True
+        dog.start()
     res = measure_train(a, world, rank, dev, wl, a.steps, a.warmup)
+    if dog is not None:
+        dog.cancel()
     if rank == 0:
         if cpu_baseline_fn is not None and world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_fn(wl["T1"], wl["T2"])
