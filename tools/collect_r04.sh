@@ -28,10 +28,12 @@ fi
 if [ -z "$SKIP_PROF" ]; then
 PREC=bf16 TIMELINE=60 bash tools/prof_conv.sh ${TAGR}_bf16 > /dev/null 2>&1
 PREC=bf16x3 TIMELINE=60 bash tools/prof_conv.sh ${TAGR}_bf16x3 > /dev/null 2>&1
+# the forward with the one-wave-per-SIMD kernel behind efts_resconv5 (where it is eligible: the decoder's launches), same passes
+PREC=bf16 TIMELINE=60 BARGS="--rc-kernel 2" bash tools/prof_conv.sh ${TAGR}_bf16_w4 > /dev/null 2>&1
 WL=train32 STEPS=3 TSTEPS=3 TWARM=2 TIMELINE=240 BARGS="--train-graph 0" bash tools/prof_conv.sh ${TAGR}_train_bf16 > /dev/null 2>&1
 # the same training step as ONE hipGraph replay (what bench.py times): trace only, nothing issued behind the replays
 EFTS_BENCH_TRAIN_NO_EAGER=1 NOPMC=1 WL=train32 STEPS=6 TSTEPS=20 TWARM=5 TIMELINE=215 BARGS="--train-graph 1" bash tools/prof_conv.sh ${TAGR}_train_graph > /dev/null 2>&1
-for t in ${TAGR}_bf16 ${TAGR}_bf16x3 ${TAGR}_train_bf16 ${TAGR}_train_graph; do
+for t in ${TAGR}_bf16 ${TAGR}_bf16_w4 ${TAGR}_bf16x3 ${TAGR}_train_bf16 ${TAGR}_train_graph; do
   test -s gpurun_out/prof_$t/summary_$t.txt || { echo "PROFILE FAILED: $t"; exit 1; }
   cp gpurun_out/prof_$t/summary_$t.txt $O/rocprofv3_${t}_summary.txt
   cp gpurun_out/prof_$t/bench_line_$t.json $O/bench_line_under_rocprof_$t.json
