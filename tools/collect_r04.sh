@@ -22,6 +22,8 @@ probe rc_marks_$TAGR.txt rc_marks.so tools/gpu_probe_rc_marks.py
 # the same marks for the one-wave-per-SIMD kernel (bf16 planes only: RCK=2 falls back to the 8-wave kernel for split 2), and its micro benchmark
 probe rc_marks_w4_$TAGR.txt rc_marks.so tools/gpu_probe_rc_marks.py RCK=2
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I efficient_tts_amd/csrc tools/micro/rc4_loop_test.hip -o lab/rc4_loop_test > $O/rc4_micro_build.log 2>&1 && timeout 200 lab/rc4_loop_test > $O/rc4_loop_micro_$TAGR.txt 2>&1 || { echo "PROBE FAILED: rc4 micro benchmark"; exit 1; }
+# what the part gives a bare MFMA stream: zero / random operands, all CUs / one CU (TFLOP/s and the delivered shader clock)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_ceiling.hip -o lab/mfma_ceiling > /dev/null 2>&1 && timeout 200 lab/mfma_ceiling > $O/mfma_ceiling_$TAGR.txt 2>&1 || { echo "PROBE FAILED: mfma ceiling"; exit 1; }
 # ablations of the ping-pong kernel (us per B = 64 launch): all / no LDS-DMA / no epilogue traffic / neither / no MFMA + fragment reads
 GRAFT_REPO_ROOT=$R bash tools/rc_ab.sh 64x800 cur exp1 exp8 exp9 exp4 > $O/rc_ablate_$TAGR.txt 2>&1 || { echo "PROBE FAILED: ablations"; exit 1; }
 fi
