@@ -49,6 +49,12 @@ class GraphedStep:
         conv_dropout = m.training and float(getattr(m, "dropout_rate", 0.0)) >= 1e-5
         return isinstance(self.opt, EftsAdam) and hasattr(m, "_weights") and not conv_dropout and not torch.cuda.is_current_stream_capturing()
 
+    def inputs(self, text, text_lengths, speech, speech_lengths):
+        """The device tensors a captured step of this shape reads (text, text_lengths int32, speech, speech_lengths int32), or None before
+        the capture.  A data loader may copy its next batch straight into them and pass them back to the call: no second copy."""
+        ent = self.entries.get((tuple(text.shape), tuple(speech.shape), text.dtype, speech.dtype))
+        return None if ent is None or ent.get("graph") is None else tuple(ent["static"])
+
     def _eager(self, text, tl, speech, sl):
         loss, stats, *_ = self.model(text=text, text_lengths=tl, speech=speech, speech_lengths=sl)
         self.opt.zero_grad()
@@ -76,7 +82,7 @@ class GraphedStep:
         if not self._eligible():
             return self._eager(text, text_lengths, speech, speech_lengths)
         dev = text.device
-        key = (tuple(text.shape), tuple(speech.shape), text.dtype, speech.dtype, text_lengths.dtype, speech_lengths.dtype)
+        key = (tuple(text.shape), tuple(speech.shape), text.dtype, speech.dtype)      # (the lengths are copied into int32 buffers whatever they come as)
         ent = self.entries.get(key)
         if ent is None:
             ent = self.entries[key] = dict(calls=0, graph=None)
@@ -97,7 +103,10 @@ class GraphedStep:
             if self.words is None:
                 self.words = torch.zeros(8, dtype=torch.int32, device=dev)
             if ent["graph"] is None:
-                ent["static"] = [text.clone(), text_lengths.to(dev).clone(), speech.clone(), speech_lengths.to(dev).clone()]
+                # the captured launches read these; lengths are kept as int32 (what the kernels take: the copy below converts, so the
+                # replay holds no conversion launches of its own)
+                ent["static"] = [text.clone(), text_lengths.to(device=dev, dtype=torch.int32).clone(), speech.clone(),
+                                 speech_lengths.to(device=dev, dtype=torch.int32).clone()]
                 calls0 = int(getattr(m, "dropout_calls", 0))
                 m._packed_sig = None                                  # the weight planes are (re)packed INSIDE the graph, every step
                 g = torch.cuda.CUDAGraph()
@@ -132,7 +141,8 @@ class GraphedStep:
                 ent.update(graph=g, out3=out3, tag=self._tag(m._workspace(("train", text.shape[0], text.shape[1], speech.shape[1]), dev), eng), keep=(ws, eng))
             else:
                 for s_, t in zip(ent["static"], (text, text_lengths, speech, speech_lengths)):
-                    s_.copy_(t, non_blocking=True)
+                    if t is not s_:                                  # (a caller that fills `inputs(...)` in place passes them back: nothing to copy)
+                        s_.copy_(t, non_blocking=True)
             self._refresh(eng)
         ent["graph"].replay()
         self.replays += 1

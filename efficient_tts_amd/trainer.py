@@ -99,6 +99,14 @@ class EfficientTTSTrainer:
     def _stage(self, batch):
         """batch -> (text, text_lengths, mel, mel_lengths) on the device.  Waveform batches
         (efficient_tts_amd.datasets.TextMelCollate) go through the GPU log-mel front-end."""
+        if self.frontend is None and self._graphed_step() is not None and self._net.training:
+            # `graph_steps`: once this batch shape is captured, the host tensors go straight into the buffers the captured launches read
+            # (one host-to-device copy each, converting the lengths to int32 on the way; GraphedStep sees its own buffers and copies nothing)
+            bufs = self._graph.inputs(*batch)
+            if bufs is not None:
+                for s_, t in zip(bufs, batch):
+                    s_.copy_(t, non_blocking=True)
+                return bufs
         text, text_lengths, third, third_lengths = (t.to(self.device) for t in batch)
         if self.frontend is None:
             return text, text_lengths, third, third_lengths
