@@ -273,15 +273,20 @@ class EfficientTTSCNN(torch.nn.Module):
             out.append((f"dur.{i}", seq[0]))
         return out
 
+    _TEXT_SIDE = ("text_encoder.", "dur.", "key", "value")            # weights only the text-length launches read
+
     def _weights(self, folded: Optional[Dict[str, torch.Tensor]] = None,
-                 wt: Optional[Dict[str, PackedWeight]] = None, params=None) -> Dict[str, PackedWeight]:
+                 wt: Optional[Dict[str, PackedWeight]] = None, params=None, text_stream=None) -> Dict[str, PackedWeight]:
         """B operand planes of every Conv1d/Linear; repacked (weight-norm fold fused) whenever
         a parameter changed (optimizer step, load_state_dict, .to()).  Training engine extras, produced by the same
         launches: `folded[name]` (fp32 [cout][cin][taps]) receives the folded weight g * v / ||v|| of a weight-normed
         conv, `wt[name]` the transposed + tap-flipped dgrad plane.  Equally shaped weights go through ONE grouped
         call (`efts_pack_weights_grouped`, a device-side item table) instead of a launch each.
         `_packed_sig` cannot see in-place updates made by the fused optimizer kernel (no version bump), which is
-        why EftsAdam resets it and why consumers of derived data compare `_packed_gen`, never the signature."""
+        why EftsAdam resets it and why consumers of derived data compare `_packed_gen`, never the signature.
+        `text_stream`: the planes only the text-length launches read (text encoder, duration predictor, key / value) are packed on that
+        stream -- the training pass runs its text side there, so the two halves of the repack overlap each other and the other stream's
+        first launches instead of standing in front of both (the caller orders `text_stream` behind the parameters' last writer)."""
         sig = tuple((p.data_ptr(), p._version) for p in (params if params is not None else self.parameters()))
         if sig == self._packed_sig:
             return self._packed
@@ -302,10 +307,11 @@ class EfficientTTSCNN(torch.nn.Module):
             cout, cin = mod.weight_v.shape[:2] if hasattr(mod, "weight_g") else mod.weight.shape[:2]
             if name not in pk or pk[name].buf.device != dev:
                 pk[name] = PackedWeight(cout, cin, taps, self.split, dev)
-            groups.setdefault((cout, cin, taps, name in wt), []).append((name, mod))
+            on_text = text_stream is not None and name.startswith(self._TEXT_SIDE)
+            groups.setdefault((cout, cin, taps, name in wt, on_text), []).append((name, mod))
         lib = L.load()
         table_rows, launches = [], []
-        for (cout, cin, taps, with_t), members in groups.items():
+        for (cout, cin, taps, with_t, on_text), members in groups.items():
             first = len(table_rows)
             tiled = cout % 64 == 0 and cin % 64 == 0 and taps <= 5     # the library's one-pass path: no folded copy needed
             for name, mod in members:
@@ -320,7 +326,7 @@ class EfficientTTSCNN(torch.nn.Module):
                 table_rows.append((w.data_ptr(), 0 if g is None else g.data_ptr(), 0 if fo is None else fo.data_ptr(),
                                    pk[name].ptr, wt[name].ptr if with_t else 0))
             ref = pk[members[0][0]]
-            launches.append((first, len(members), ref.ld, wt[members[0][0]].ld if with_t else 0, cout, cin, taps, int(with_t)))
+            launches.append((first, len(members), ref.ld, wt[members[0][0]].ld if with_t else 0, cout, cin, taps, int(with_t), on_text))
         key = tuple(table_rows)
         tables = getattr(self, "_pack_tables", None)
         if tables is None:
@@ -334,15 +340,22 @@ class EfficientTTSCNN(torch.nn.Module):
             # parameters), which a captured step can no longer be replayed with either (its tag holds the storage signature)
             while len(tables) >= 8:
                 tables.pop(next(iter(tables)))
+            # (scale workspace: one region per stream, the launches of a stream run in order)
             tables[key] = (torch.tensor(table_rows, dtype=torch.int64, device=dev),
-                           torch.empty(max(n * co for _, n, _, _, co, _, _, _ in launches), device=dev))
+                           torch.empty(2 * max(n * co for _, n, _, _, co, _, _, _, _ in launches), device=dev))
         else:
             tables[key] = tables.pop(key)                                # most recently used last
         table, scale = tables[key]
         base = table.data_ptr()
-        for first, n, ld, ld_t, cout, cin, taps, with_t in launches:
-            L.check(lib.efts_pack_weights_grouped(base + first * 40, n, scale.data_ptr(), ld, ld_t, cout, cin, taps,
-                                                  self.split, with_t, O._stream()), "efts_pack_weights_grouped")
+        half = scale.numel() // 2 * 4
+        for first, n, ld, ld_t, cout, cin, taps, with_t, on_text in launches:
+            if on_text:
+                with O.on_stream(text_stream):
+                    L.check(lib.efts_pack_weights_grouped(base + first * 40, n, scale.data_ptr() + half, ld, ld_t, cout, cin, taps,
+                                                          self.split, with_t, O._stream()), "efts_pack_weights_grouped")
+            else:
+                L.check(lib.efts_pack_weights_grouped(base + first * 40, n, scale.data_ptr(), ld, ld_t, cout, cin, taps,
+                                                      self.split, with_t, O._stream()), "efts_pack_weights_grouped")
         self._packed_sig = sig
         self._packed_gen += 1
         if wt:

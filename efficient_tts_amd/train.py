@@ -39,9 +39,12 @@ _RESCONV_DGRAD = -1          # ... and whose DGRAD does (same bits as efts_gemm'
 _WGRAD_WGS = 480             # split-K target: 480 workgroups per wgrad launch measured best (6.30 vs 6.60 ms/step at 640)
 
 
+_PACK_SPLIT = 1              # the text-side operand planes are repacked on the side stream (A/B)
+
+
 def switch_tag() -> tuple:
     """every hook above, by value: part of the tag of a captured training step"""
-    return (_WGRAD_TN_SPLITS, _SIGN_MIN_ROWS, _BIAS_PARTS, _RESCONV_FWD, _RESCONV_DGRAD, _WGRAD_WGS)
+    return (_WGRAD_TN_SPLITS, _SIGN_MIN_ROWS, _BIAS_PARTS, _RESCONV_FWD, _RESCONV_DGRAD, _WGRAD_WGS, _PACK_SPLIT)
 
 
 class _TPlane(Plane):
@@ -129,7 +132,7 @@ class TrainEngine:
         return set(cur) != set(self.g) or any(cur[n].shape != self.g[n].shape or cur[n].device != self.dev for n in cur)
 
     # ------------------------------------------------------------------ weights for the backward
-    def _prepare_weights(self):
+    def _prepare_weights(self, text_stream=None):
         """forward planes, folded fp32 weights and transposed/flipped dgrad planes, all from `model._weights` (a handful
         of grouped launches).  The derived copies follow `model._packed_gen` / `_folded_gen`, the repack counters: the
         fused optimizer updates parameters in place without a version bump, so the signature of the parameters cannot
@@ -150,10 +153,10 @@ class TrainEngine:
         for name, lin in lins:
             if name not in self.wt:
                 self.wt[name] = PackedWeight(lin.in_features, lin.out_features, 1, m.split, dev)
-        pk = m._weights(self.folded, self.wt, self.step_params)
+        pk = m._weights(self.folded, self.wt, self.step_params, text_stream=text_stream)
         if m._folded_gen != m._packed_gen:
             m._packed_sig = None                # the last repack (an eval forward) did not write the copies kept here
-            pk = m._weights(self.folded, self.wt, self.step_params)
+            pk = m._weights(self.folded, self.wt, self.step_params, text_stream=text_stream)
         return pk
 
     # ------------------------------------------------------------------ small wrappers
@@ -330,13 +333,18 @@ class TrainEngine:
         speech = speech.contiguous().float()
         tl = text_lengths.to(device=dev, dtype=torch.int32)
         ml = speech_lengths.to(device=dev, dtype=torch.int32)
-        pk = self._prepare_weights()
         ws = m._workspace(("train", B, T1, T2), dev)
         rs1, rs2 = Rows(B, T1, m.row_gap), Rows(B, T2, m.row_gap)
         gap1, len1 = ws.tensor("gap1", (rs1.rows,)), ws.tensor("len1", (rs1.rows,))
         gap2, len2 = ws.tensor("gap2", (rs2.rows,)), ws.tensor("len2", (rs2.rows,))
         O.row_masks(tl, rs1, gap1, len1)
         O.row_masks(ml, rs2, gap2, len2)
+        # the repack of the operand planes (weight-norm fold + bf16 planes + dgrad planes, ~110 us on one stream): the text-side planes on
+        # the stream the text side runs on, the mel-side planes here -- both behind the masks and the previous step's optimizer
+        side0 = m._side_stream(dev) if _PACK_SPLIT else None
+        if side0 is not None:
+            side0.wait_stream(torch.cuda.current_stream(dev))
+        pk = self._prepare_weights(text_stream=side0)
         self.flat.zero_()
 
         # Two HIP streams.  The text-length work (embedding, text encoder, K/V, duration predictor and all of their
@@ -345,7 +353,8 @@ class TrainEngine:
         # stream and fills the idle CUs / tail rounds of the mel-length kernels; events mark the few hand-over points.
         main = torch.cuda.current_stream(dev)
         side = m._side_stream(dev)
-        side.wait_stream(main)
+        if side0 is None:
+            side.wait_stream(main)
         if self.mark is not None:
             self.mark("step_start")
         dp = m.duration_predictor
