@@ -42,9 +42,12 @@ _WGRAD_WGS = 480             # split-K target: 480 workgroups per wgrad launch m
 _PACK_SPLIT = 1              # the text-side operand planes are repacked on the side stream (A/B)
 
 
+_NARROW_TN = 1               # the 80-channel Linears' weight gradients on the direct kernel over the 128-wide planes (A/B; bf16 planes only)
+
+
 def switch_tag() -> tuple:
     """every hook above, by value: part of the tag of a captured training step"""
-    return (_WGRAD_TN_SPLITS, _SIGN_MIN_ROWS, _BIAS_PARTS, _RESCONV_FWD, _RESCONV_DGRAD, _WGRAD_WGS, _PACK_SPLIT)
+    return (_WGRAD_TN_SPLITS, _SIGN_MIN_ROWS, _BIAS_PARTS, _RESCONV_FWD, _RESCONV_DGRAD, _WGRAD_WGS, _PACK_SPLIT, _NARROW_TN)
 
 
 class _TPlane(Plane):
@@ -210,17 +213,33 @@ class TrainEngine:
         L.check(_lib().efts_wgrad_reduce(part.data_ptr(), S, _ptr(v), _ptr(g), out_dw.data_ptr(), _ptr(out_dg), cout, cin, taps,
                                          O._stream()), "efts_wgrad_reduce")
 
-    def _wgrad_tn(self, ws, dz_p: Plane, x_p: Plane, cout, cin, rows, v, g, out_dw, out_dg, bias_part=None, dbias=None, taps: int = 5):
+    def _wgrad_tn(self, ws, dz_p: Plane, x_p: Plane, cout, cin, rows, v, g, out_dw, out_dg, bias_part=None, dbias=None, taps: int = 5,
+                  splits: Optional[int] = None):
         """wgrad of a k5 / k3 convolution or a Linear (taps 5 / 3 / 1) straight from the row-major bf16 planes
         (csrc/efts_wgrad.hip): no transposed copies.
         bias_part: the [row blocks][cout] column sums efts_act_bwd left; the reduction adds them into dbias"""
-        S = _WGRAD_TN_SPLITS
+        S = _WGRAD_TN_SPLITS if splits is None else splits
         part = ws.get(("part", self._ws_tag, taps, S, cout, cin), lambda: torch.empty(taps, S, cout, cin, device=self.dev))
         L.check(_lib().efts_wgrad_tn(dz_p.ptr, dz_p.ld, x_p.ptr, x_p.ld, part.data_ptr(), rows, cout, cin, taps, S, dz_p.split, O._stream()),
                 "efts_wgrad_tn")
         L.check(_lib().efts_wgrad_reduce_bias(part.data_ptr(), S, _ptr(v), _ptr(g), out_dw.data_ptr(), _ptr(out_dg), cout, cin, taps,
                                               _ptr(bias_part), 0 if bias_part is None else bias_part.shape[0], _ptr(dbias), O._stream()),
                 "efts_wgrad_reduce_bias")
+
+    def _wgrad_narrow(self, ws, tag, dz_p: Plane, x_p: Plane, cout, cin, rows, out_dw) -> bool:
+        """weight gradient of a Linear with an 80-channel side (mel head 512 -> 80, prenet 80 -> 512) on the direct kernel: bf16 planes are
+        128 columns wide (two 64-channel chunks, zeros beyond the 80th), so the contraction runs on the padded 128 and the result's first
+        80 rows / columns are copied out -- instead of two transposed operand copies (efts_pack_t over the mel-length stream) + split-K
+        efts_gemm + reduction.  False: not applicable (bf16x3 planes are 96 wide), the caller takes the transposed-plane path."""
+        if not (_NARROW_TN and _WGRAD_TN_SPLITS > 0 and dz_p.split == 1 and x_p.split == 1 and max(cout, cin) % 128 == 0 and min(cout, cin) <= 128):
+            return False
+        co_p, ci_p = max(cout, 128), max(cin, 128)
+        if dz_p.ld < co_p * 2 or x_p.ld < ci_p * 2:
+            return False
+        scratch = ws.tensor(f"B{tag}_dw_pad", (co_p, ci_p))
+        self._wgrad_tn(ws, dz_p, x_p, co_p, ci_p, rows, None, None, scratch, None, taps=1, splits=32)     # 8 tiles x 32 row splits
+        out_dw.copy_(scratch[:cout, :cin])
+        return True
 
     # ------------------------------------------------------------------ forward with saved activations
     def _stack_fwd(self, ws, tag, blk, pk, rs, x_f, x_p, gap_ptr, last_split):
@@ -537,7 +556,8 @@ class TrainEngine:
             # the unmasked loss sees (0 - speech) on padded frames; mel_pred = masked_fill(head output) blocks that gradient (:199-200)
             dmel_m = ws.f32("Bdmel_m", rs2, odim)
             self._act_bwd(dmel_f.ptr, None, None, len2.data_ptr(), 0, dmel_m, dmel_p, g["mel_output_layer.bias"], rs2.rows, odim)
-        self._wgrad(ws, dmel_m.ptr, odim, d_f.ptr, C, C, 1, rs2.rows, None, None, g["mel_output_layer.weight"], None)
+        if not self._wgrad_narrow(ws, "head", dmel_p, d_p, odim, C, rs2.rows, g["mel_output_layer.weight"]):
+            self._wgrad(ws, dmel_m.ptr, odim, d_f.ptr, C, C, 1, rs2.rows, None, None, g["mel_output_layer.weight"], None)
         G = ws.f32("Bdec_Gh", rs2, C)
         wt = self.wt["head"]
         O.gemm(a=dmel_p, b_ptr=wt.ptr, ldb=wt.ld, m=rs2.rows, n=C, rowmask_ptr=gap2.data_ptr(), out_f32_ptr=G.ptr, ldo=C)
@@ -642,12 +662,16 @@ class TrainEngine:
         Gm = self._stack_bwd(ws, "me", "mel_encoder", rs2, G_me, me_saved, gap2.data_ptr(), gap2.data_ptr(), None)
         if self.mark is not None:
             self.mark("bwd_mel_encoder_done")
-        dzp_f = ws.f32("Bpre_dz", rs2, C)
+        narrow = _NARROW_TN and _WGRAD_TN_SPLITS > 0 and split == 1 and odim <= 128 and C % 128 == 0 and mel_in.ld >= 256
+        dzp_f = None if narrow else ws.f32("Bpre_dz", rs2, C)
+        dzp_p = ws.plane("Bpre_dzp", rs2, C, split) if narrow else None
         if pre_z is not None:
-            O.act_grad(m.act_general, Gm.ptr, pre_z.ptr, gap2.data_ptr(), dzp_f, None, g["mel_prenet.0.bias"], rs2.rows, C, pre_dp, pre_seed)
+            O.act_grad(m.act_general, Gm.ptr, pre_z.ptr, gap2.data_ptr(), dzp_f, dzp_p, g["mel_prenet.0.bias"], rs2.rows, C, pre_dp, pre_seed)
         else:
-            self._act_bwd(Gm.ptr, pre_f.ptr, None, gap2.data_ptr(), 3, dzp_f, None, g["mel_prenet.0.bias"], rs2.rows, C, pre_dp, pre_seed)
-        self._wgrad(ws, dzp_f.ptr, C, mel_in_f.ptr, odim, odim, 1, rs2.rows, None, None, g["mel_prenet.0.weight"], None)
+            self._act_bwd(Gm.ptr, pre_f.ptr, None, gap2.data_ptr(), 3, dzp_f, dzp_p, g["mel_prenet.0.bias"], rs2.rows, C, pre_dp, pre_seed)
+        if not (narrow and self._wgrad_narrow(ws, "pre", dzp_p, mel_in, C, odim, rs2.rows, g["mel_prenet.0.weight"])):
+            assert dzp_f is not None
+            self._wgrad(ws, dzp_f.ptr, C, mel_in_f.ptr, odim, odim, 1, rs2.rows, None, None, g["mel_prenet.0.weight"], None)
         if self.bucket_hook:
             self.bucket_hook(1)
 
