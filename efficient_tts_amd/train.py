@@ -350,14 +350,17 @@ class TrainEngine:
         C, odim, split = m.n_channels, m.odim, m.split
         text = text.contiguous()
         speech = speech.contiguous().float()
-        tl = text_lengths.to(device=dev, dtype=torch.int32)
-        ml = speech_lengths.to(device=dev, dtype=torch.int32)
         ws = m._workspace(("train", B, T1, T2), dev)
         rs1, rs2 = Rows(B, T1, m.row_gap), Rows(B, T2, m.row_gap)
         gap1, len1 = ws.tensor("gap1", (rs1.rows,)), ws.tensor("len1", (rs1.rows,))
         gap2, len2 = ws.tensor("gap2", (rs2.rows,)), ws.tensor("len2", (rs2.rows,))
-        O.row_masks(tl, rs1, gap1, len1)
-        O.row_masks(ml, rs2, gap2, len2)
+        tl_, ml_ = text_lengths.to(dev), speech_lengths.to(dev)
+        if tl_.dtype == ml_.dtype and tl_.dtype in (torch.int64, torch.int32) and tl_.is_contiguous() and ml_.is_contiguous():
+            tl, ml = O.row_masks_pair(tl_, ml_, rs1, rs2, gap1, len1, gap2, len2)       # both masks + the int32 lengths in one launch
+        else:
+            tl, ml = tl_.to(torch.int32), ml_.to(torch.int32)
+            O.row_masks(tl, rs1, gap1, len1)
+            O.row_masks(ml, rs2, gap2, len2)
         # the repack of the operand planes (weight-norm fold + bf16 planes + dgrad planes, ~110 us on one stream): the text-side planes on
         # the stream the text side runs on, the mel-side planes here -- both behind the masks and the previous step's optimizer
         side0 = m._side_stream(dev) if _PACK_SPLIT else None
