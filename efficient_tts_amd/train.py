@@ -45,9 +45,12 @@ _PACK_SPLIT = 1              # the text-side operand planes are repacked on the 
 _NARROW_TN = 1               # the 80-channel Linears' weight gradients on the direct kernel over the 128-wide planes (A/B; bf16 planes only)
 
 
+_EARLY_PACKS = 1             # alignment backward: the operand copies that depend on forward tensors only go to the side stream, early (A/B)
+
+
 def switch_tag() -> tuple:
     """every hook above, by value: part of the tag of a captured training step"""
-    return (_WGRAD_TN_SPLITS, _SIGN_MIN_ROWS, _BIAS_PARTS, _RESCONV_FWD, _RESCONV_DGRAD, _WGRAD_WGS, _PACK_SPLIT, _NARROW_TN)
+    return (_WGRAD_TN_SPLITS, _SIGN_MIN_ROWS, _BIAS_PARTS, _RESCONV_FWD, _RESCONV_DGRAD, _WGRAD_WGS, _PACK_SPLIT, _NARROW_TN, _EARLY_PACKS)
 
 
 class _TPlane(Plane):
@@ -550,6 +553,21 @@ class TrainEngine:
             O.gemm(a=dz1_p, b_ptr=wt.ptr, ldb=wt.ld, b_tap_stride=wt.tap_stride, taps=3, m=rs1.rows, n=C, out_f32_ptr=dV_dur.ptr, ldo=C)
             ev_durb = torch.cuda.Event()
             ev_durb.record(side)
+            ev_packs = None
+            if _EARLY_PACKS:
+                # operand copies of the alignment backward that depend on forward tensors only (V as an A operand, alpha' as an A operand,
+                # K^T, Q^T): this stream idles through the decoder's backward, the main one would run them one after the other in front of
+                # their GEMMs
+                val_p2 = ws.plane("Bval_p2", rs1, C, 2)
+                L.check(_lib().efts_pack_rows(val_f.ptr, None, val_p2.ptr, val_p2.ld, B, rs1.Tp, rs1.Tp, C, C, 2, O._stream()), "efts_pack_rows")
+                ra1_p = ws.plane("Bra1_p", rs1, T2, 2)
+                O.pack_rows(ralpha, None, ra1_p, rs1)
+                kt = ws.raw_plane("Bkt", B * C + 136, T1, 2)
+                O.pack_vt(key_f, kt, B, T1, rs1.Tp, C)
+                qt = ws.raw_plane("Bqt", B * C + 136, T2, 2)
+                O.pack_vt(q_f, qt, B, T2, rs2.Tp, C)
+                ev_packs = torch.cuda.Event()
+                ev_packs.record(side)
             self._ws_tag = ""
         # mel head (Linear 512->80, masked): bias grad + operand plane, wgrad, dgrad
         if m.use_masking:
@@ -573,13 +591,17 @@ class TrainEngine:
             self.bucket_hook(0)
 
         # ---- expand bmm backward: d alpha' [B,T1,T2] and dV
-        val_p2 = ws.plane("Bval_p2", rs1, C, 2)
-        L.check(_lib().efts_pack_rows(val_f.ptr, None, val_p2.ptr, val_p2.ld, B, rs1.Tp, rs1.Tp, C, C, 2, O._stream()), "efts_pack_rows")
+        if ev_packs is not None:
+            main.wait_event(ev_packs)
+        else:
+            val_p2 = ws.plane("Bval_p2", rs1, C, 2)
+            L.check(_lib().efts_pack_rows(val_f.ptr, None, val_p2.ptr, val_p2.ld, B, rs1.Tp, rs1.Tp, C, C, 2, O._stream()), "efts_pack_rows")
         dAp = ws.tensor("BdAp", (B, T1, T2))
         O.gemm(a=val_p2, b_ptr=dH_p.ptr, ldb=dH_p.ld, m=T1, n=T2, batch=B, a_batch_stride=rs1.Tp * val_p2.ld,
                b_batch_stride=rs2.Tp * dH_p.ld, out_f32_ptr=dAp.data_ptr(), ldo=T2, out_batch_stride=T1 * T2)
-        ra1_p = ws.plane("Bra1_p", rs1, T2, 2)                       # alpha' as an A operand: rows (b,i), K = j
-        O.pack_rows(ralpha, None, ra1_p, rs1)
+        if ev_packs is None:
+            ra1_p = ws.plane("Bra1_p", rs1, T2, 2)                   # alpha' as an A operand: rows (b,i), K = j
+            O.pack_rows(ralpha, None, ra1_p, rs1)
         dHt = ws.raw_plane("BdHt", B * C + 136, T2, 2)              # dH^T per item: [B][C][K = j]
         O.pack_vt(dH, dHt, B, T2, rs2.Tp, C)
         GV = ws.f32("BGV", rs1, C)
@@ -602,15 +624,17 @@ class TrainEngine:
         L.check(_lib().efts_attn_bwd(scores.data_ptr(), T1, sidx.data_ptr(), dsx.data_ptr(), tl.data_ptr(), ml.data_ptr(), dS.data_ptr(),
                                      T1, dS_p.ptr, dS_p.ld, B, T1, T2, rs2.Tp, O._stream()), "efts_attn_bwd")
         # dQ = scale * dS K ; dK = scale * dS^T Q
-        kt = ws.raw_plane("Bkt", B * C + 136, T1, 2)
-        O.pack_vt(key_f, kt, B, T1, rs1.Tp, C)
+        if ev_packs is None:
+            kt = ws.raw_plane("Bkt", B * C + 136, T1, 2)
+            O.pack_vt(key_f, kt, B, T1, rs1.Tp, C)
         GQ = ws.f32("BGQ", rs2, C)
         O.gemm(a=dS_p, b_ptr=kt.ptr, ldb=kt.ld, m=T2, n=C, batch=B, a_batch_stride=rs2.Tp * dS_p.ld, b_batch_stride=C * kt.ld, alpha=scale,
                out_f32_ptr=GQ.ptr, ldo=C, out_batch_stride=rs2.Tp * C)
         dSt = ws.raw_plane("BdSt", B * T1 + 264, T2, 2)             # dS^T: rows (b,i), K = j
         L.check(_lib().efts_pack_vt(dS.data_ptr(), T1, dSt.ptr, dSt.ld, B, T2, T2, T1, O._stream()), "efts_pack_vt")
-        qt = ws.raw_plane("Bqt", B * C + 136, T2, 2)
-        O.pack_vt(q_f, qt, B, T2, rs2.Tp, C)
+        if ev_packs is None:
+            qt = ws.raw_plane("Bqt", B * C + 136, T2, 2)
+            O.pack_vt(q_f, qt, B, T2, rs2.Tp, C)
         GK = ws.f32("BGK", rs1, C)
         GK_p = ws.plane("BGK_p", rs1, C, split)
         shared = m.share_text_encoder_key_value                     # value = key projection: its gradient joins dK here (residual)
