@@ -181,7 +181,7 @@ def measure_train(a, world, rank, dev, wl, steps, warmup, precision=None):
             step()
         P.PROFILE, P.PROFILE_TAG = [], (5, rows, 512)
         eager_dt, loss = timed(step, steps)
-        durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in P.PROFILE if tag == (5, rows, 512)]
+        durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in (P.PROFILE or []) if tag == (5, rows, 512)]
         P.PROFILE, P.PROFILE_TAG = None, None
         dp_stats = ddp.reducer.stats()
         lv_eager = float(loss)
@@ -251,7 +251,7 @@ def measure_train(a, world, rank, dev, wl, steps, warmup, precision=None):
             P.PROFILE, P.PROFILE_TAG = [], (5, rows, 512)
             eager_dt, _ = timed(step, max(3, min(steps, 10)))
             eager_dt = eager_dt / max(3, min(steps, 10)) * steps
-        durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in P.PROFILE if tag == (5, rows, 512)]
+        durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in (P.PROFILE or []) if tag == (5, rows, 512)]
         P.PROFILE, P.PROFILE_TAG = None, None
         issue = ("one hipGraph replay per step (step_graph.GraphedStep), the batch resident in the buffers the captured launches read "
                  "(GraphedStep.inputs: where the trainer's loader copies it, trainer._stage)") if graphed is not None else "eager launches"
