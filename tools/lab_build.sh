@@ -11,6 +11,7 @@ set -e
 cd "$(dirname "$0")/.."
 python -m efficient_tts_amd.build > /dev/null
 mkdir -p lab
+rm -f lab/rc_*.so            # (left-overs of earlier experiments would fail the symbol check below: every library here is rebuilt)
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OBJS=$(ls efficient_tts_amd/build/*.o | grep -v efts_resconv.o)
 build_one() {   # name, define
