@@ -114,3 +114,39 @@ def test_lazy_stats_behaves_like_a_dict():
     assert s["loss"] == 3.0 and s.get("mel_loss") == 2.0 and s.get("nope", 7) == 7
     assert dict(s) == dict(loss=3.0, mel_loss=2.0, duration_loss=1.0)
     assert list(s.keys()) == ["loss", "mel_loss", "duration_loss"] and sorted(s.values()) == [1.0, 2.0, 3.0]
+
+
+def test_ctor_option_space_is_decided_on_the_host():
+    """k_size and nonlinear_activation (efts_modules.py:19-46: any odd kernel, any getattr(torch.nn, name)(**params)): what the ctor accepts,
+    which path it selects, and what it refuses by name -- no device needed.  The arithmetic of every accepted option is tested on the GPU
+    (tests/test_gpu_variants.py)."""
+    import pytest
+    from efficient_tts_amd import EfficientTTSCNN, lib as L
+
+    def make(**kw):
+        return EfficientTTSCNN(num_symbols=76, n_text_encoder_layer=1, n_mel_encoder_layer=1, n_decoder_layer=1, **kw)
+    for k, gap in ((1, 2), (3, 2), (5, 2), (7, 3), (9, 4), (11, 5)):
+        m = make(k_size=k)
+        assert m.row_gap == gap and m.text_encoder.layers[0].conv[0].kernel_size == (k,)
+    for k in (0, 2, 4, 13):
+        with pytest.raises(NotImplementedError):
+            make(k_size=k)
+    assert make().act_general is None and make().slope == pytest.approx(0.1)
+    assert make(nonlinear_activation="LeakyReLU", nonlinear_activation_params={"negative_slope": 0.3, "inplace": True}).slope == pytest.approx(0.3)
+    assert make(nonlinear_activation="ReLU", nonlinear_activation_params={}).slope == 0.0
+    assert make(nonlinear_activation="GELU", nonlinear_activation_params={}).act_general == (6, 0.0, 0.0)
+    assert make(nonlinear_activation="GELU", nonlinear_activation_params={"approximate": "tanh"}).act_general == (7, 0.0, 0.0)
+    assert make(nonlinear_activation="ELU", nonlinear_activation_params={"alpha": 0.5}).act_general == (3, 0.5, 0.0)
+    assert make(nonlinear_activation="Softplus", nonlinear_activation_params={"beta": 2.0}).act_general == (12, 2.0, 20.0)
+    assert make(nonlinear_activation="ReLU6", nonlinear_activation_params={}).act_general == (13, 0.0, 6.0)
+    # every name the table lists is a torch.nn module with those keyword arguments, and the ids are the header's
+    import re
+    import torch
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "efts_abi.h")).read()
+    ids = {int(v) for v in re.findall(r"#define EFTS_ACTFN_(?!COUNT)\w+ (\d+)", hdr)}
+    assert {aid for aid, _ in L.ACTFN.values()} | {7} == ids and int(re.search(r"#define EFTS_ACTFN_COUNT (\d+)", hdr).group(1)) == max(ids) + 1
+    for name, (aid, keys) in L.ACTFN.items():
+        getattr(torch.nn, name)(**{k: d for k, d in keys})
+    for name, params in (("PReLU", {}), ("RReLU", {}), ("Softmax", {"dim": 1}), ("GLU", {}), ("GELU", {"approximate": "x"}), ("ELU", {"beta": 1.0})):
+        with pytest.raises(NotImplementedError):
+            make(nonlinear_activation=name, nonlinear_activation_params=params)
