@@ -453,6 +453,29 @@ def run_infer_lj(a, world, rank, dev):
                rtf=dt1 / audio, batched=dict(value=frames / dtb, ms=dtb * 1e3, rtf=dtb / audio, note="same 10 utterances as one ragged batch (inference_batch)"),
                end_to_end=dict(ms=dte * 1e3, rtf=dte / audio, note="inference() + HiFi-GAN V1 generator per utterance (random-init vocoder weights): what nntts/bin/inference.py:105-111 calls RTF"),
                end_to_end_batched=dict(ms=dteb * 1e3, rtf=dteb / audio, note="the 10 utterances as one ragged batch through inference_batch() and the batched generator"))
+    # roofline of the dominant kernel at one utterance: the decoder's k5 Conv1d 512 -> 512 launches (T2 = 400-800 rows each: the small-M
+    # tiling of efts_gemm), HIP events around every such launch of one eager pass over the 10 utterances
+    from efficient_tts_amd import ops as Pops
+    keep = model.graphs
+    model.graphs = False
+    for x in dids[:2]:
+        model.inference(x)
+    torch.cuda.synchronize()
+    Pops.PROFILE, Pops.PROFILE_TAG = [], None
+    for x in dids:
+        model.inference(x)
+    torch.cuda.synchronize()
+    k5 = [(tag[1], s0.elapsed_time(s1) * 1e-3) for (tag, s0, s1) in Pops.PROFILE if tag[0] == 5 and tag[2] == 512 and tag[1] >= 256]
+    Pops.PROFILE, Pops.PROFILE_TAG = None, None
+    model.graphs = keep
+    if k5:
+        flop = sum(2.0 * m * 512 * 512 * 5 for m, _ in k5)
+        tsum = sum(t for _, t in k5)
+        res["roofline"] = dict(bound="mfma", kernel="the decoder's k5 Conv1d 512 -> 512 launches at ONE utterance (mel-length row spaces of 400-800 rows: "
+                               "efts_gemm's small-M tiling, K split across the waves); latency-bound by construction, the figure says how far",
+                               achieved=flop / tsum / 1e12, peak=PEAK_MFMA_BF16_TFLOPS, unit="TFLOP/s", frac=flop / tsum / 1e12 / PEAK_MFMA_BF16_TFLOPS,
+                               traffic=None, avg_launch_us=tsum / len(k5) * 1e6, launches_measured=len(k5),
+                               rows_per_launch=[min(m for m, _ in k5), max(m for m, _ in k5)])
     if not a.no_cpu_baseline:
         from oracle import efts_oracle as O           # cpu_baseline leg: the oracle as the thing timed
         torch.set_num_threads(min(os.cpu_count() or 1, 16))
