@@ -14,6 +14,10 @@ __attribute__((visibility("hidden"))) void efts_gemm_init(void);
 // number of compute units of the current device (cached)
 int efts_num_cus(void);
 
+// geometry of a grouped (stream-K) wgrad launch, shared by efts_wgrad_tn_grouped and efts_wgrad_reduce_grouped (efts_wgrad.hip)
+struct efts_wgrad_sk_geom { int steps_tile, tiles_item, ntn, nx, q, total, workgroups, maxseg; };
+__attribute__((visibility("hidden"))) int efts_wgrad_sk_geometry(int count, int rows, int cout, int cin, int split, int workgroups, efts_wgrad_sk_geom* gm);
+
 namespace efts {
 
 // round-to-nearest-even fp32 -> bf16 bits (same rounding as torch's .to(bfloat16)), integer arithmetic: the reference form

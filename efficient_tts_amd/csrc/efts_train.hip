@@ -836,6 +836,92 @@ extern "C" int efts_wgrad_reduce_bias(const float* part, int32_t nsplit, const f
     return efts_check_launch("efts_wgrad_reduce");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Reduction of a grouped (stream-K) wgrad launch (efts_wgrad_tn_grouped): one block per (item, output channel).  The slabs
+// that hold a tile's partial sums follow from the launch geometry -- list x = T % nx, position j = T / nx, workgroups
+// floor(j N / q) .. floor(((j + 1) N - 1) / q) of that list, N = steps per tile, q = steps per workgroup -- and are added
+// in that (fixed) order; then, as in wgrad_reduce_kernel, the weight-norm backward and the bias gradient.
+// ---------------------------------------------------------------------------------------------
+struct WrItem { const float* v; const float* g; float* dw_or_dv; float* dg; const float* bias_part; float* dbias; int nparts; };
+struct WrSkArgs {
+    WrItem it[EFTS_WGRAD_MAX_ITEMS];
+    const float* part;
+    int cout, cin, taps;
+    int tiles_item, ntn, nx, steps_tile, q, maxseg;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_sk_kernel(WrSkArgs p) {
+    extern __shared__ float dw_s[];                    // [cin * taps]
+    __shared__ float sh[4];
+    const int item = blockIdx.x / p.cout, co = blockIdx.x - item * p.cout;
+    const WrItem& q = p.it[item];
+    const int cin = p.cin, taps = p.taps, n = cin * taps;
+    if (q.bias_part) {
+        float b = 0.f;
+        for (int i = threadIdx.x; i < q.nparts; i += 256) b += q.bias_part[(long)i * p.cout + co];
+        b = block_sum256t(b, sh);
+        if (threadIdx.x == 0) q.dbias[co] += b;
+        __syncthreads();
+    }
+    const int mt = co >> 7, col = co & 127;
+    const int q4 = cin >> 2;
+    const long slab = (long)taps * 128 * 64;
+    for (int it = threadIdx.x; it < taps * q4; it += 256) {
+        const int k = it / q4, c4 = (it - k * q4) << 2;
+        const int nt = c4 >> 6, cil = c4 & 63;
+        const int T = item * p.tiles_item + mt * p.ntn + nt;
+        const int x = T % p.nx, j = T / p.nx;
+        const int l0 = (int)(((long)j * p.steps_tile) / p.q), l1 = (int)(((long)(j + 1) * p.steps_tile - 1) / p.q);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int l = l0; l <= l1; ++l) {
+            const int seg = j - (int)(((long)l * p.q) / p.steps_tile);
+            const float4 a = *(const float4*)(p.part + (long)((l * p.nx + x) * p.maxseg + seg) * slab + (k * 128 + col) * 64 + cil);
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        dw_s[(c4 + 0) * taps + k] = s.x; dw_s[(c4 + 1) * taps + k] = s.y;
+        dw_s[(c4 + 2) * taps + k] = s.z; dw_s[(c4 + 3) * taps + k] = s.w;
+    }
+    __syncthreads();
+    float* out = q.dw_or_dv + (long)co * n;
+    if (!q.g) {
+        for (int idx = threadIdx.x; idx < n; idx += 256) out[idx] = dw_s[idx];
+        return;
+    }
+    const float* vr = q.v + (long)co * n;
+    float dot = 0.f, nn = 0.f;
+    for (int idx = threadIdx.x; idx < n; idx += 256) {
+        const float vv = vr[idx];
+        dot += dw_s[idx] * vv;
+        nn += vv * vv;
+    }
+    dot = block_sum256t(dot, sh);
+    nn = block_sum256t(nn, sh);
+    const float nrm = sqrtf(nn), gg = q.g[co];
+    if (threadIdx.x == 0) q.dg[co] = dot / nrm;
+    const float a = gg / nrm, bcoef = dot / nn;
+    for (int idx = threadIdx.x; idx < n; idx += 256) out[idx] = a * (dw_s[idx] - vr[idx] * bcoef);
+}
+
+extern "C" int efts_wgrad_reduce_grouped(const efts_wgrad_item* items, int32_t count, const float* part, int32_t rows, int32_t cout, int32_t cin,
+                                         int32_t taps, int32_t split, int32_t workgroups, void* stream) {
+    if (!items || !part) return efts_fail(EFTS_EINVAL, "efts_wgrad_reduce_grouped: null pointer");
+    if ((size_t)cin * taps * 4 > 60000) return efts_fail(EFTS_ESHAPE, "efts_wgrad_reduce_grouped: cin*taps too large for LDS");
+    efts_wgrad_sk_geom gm;
+    const int rc = efts_wgrad_sk_geometry(count, rows, cout, cin, split, workgroups, &gm);
+    if (rc) return rc;
+    WrSkArgs k;
+    for (int i = 0; i < EFTS_WGRAD_MAX_ITEMS; ++i) {
+        const efts_wgrad_item* q = items + (i < count ? i : 0);
+        if (!q->dw_or_dv || (q->g && (!q->v || !q->dg))) return efts_fail(EFTS_EINVAL, "efts_wgrad_reduce_grouped: null pointer in item %d", i);
+        if (q->bias_part && (!q->dbias || q->nparts < 1)) return efts_fail(EFTS_EINVAL, "efts_wgrad_reduce_grouped: bias_part needs dbias and nparts >= 1");
+        k.it[i] = WrItem{q->v, q->g, q->dw_or_dv, q->dg, q->bias_part, q->dbias, q->nparts};
+    }
+    k.part = part; k.cout = cout; k.cin = cin; k.taps = taps;
+    k.tiles_item = gm.tiles_item; k.ntn = gm.ntn; k.nx = gm.nx; k.steps_tile = gm.steps_tile; k.q = gm.q; k.maxseg = gm.maxseg;
+    hipLaunchKernelGGL(wgrad_reduce_sk_kernel, dim3(count * cout), dim3(256), (size_t)cin * taps * sizeof(float), ST, k);
+    return efts_check_launch("efts_wgrad_reduce_grouped");
+}
+
 extern "C" int efts_wgrad_reduce(const float* part, int32_t nsplit, const float* v, const float* g, float* dw_or_dv, float* dg, int32_t cout,
                                  int32_t cin, int32_t taps, void* stream) {
     return efts_wgrad_reduce_bias(part, nsplit, v, g, dw_or_dv, dg, cout, cin, taps, nullptr, 0, nullptr, stream);

@@ -68,22 +68,15 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
     return r;
 }
 
-// grid: x = (cout/128) * (cin/64) tiles, y = nsplit; split s covers steps [s*steps_per_split, ...) of ROWS rows each.
+// One segment of one output tile as seen by one workgroup: rows [t_begin, t_begin + nsteps * ROWS) of the item's planes, tile (mt, nt);
+// leaves the partial sums in the accumulators `acc` (zeroed here).  All LDS traffic of the segment is retired on return.
 template <int SPLIT, int TAPS>
-__global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const char* __restrict__ dz, long ldz, const char* __restrict__ x, long ldx,
-                                                           float* __restrict__ part, int steps_per_split, int steps_total, int cout, int cin, int nsplit) {
+__device__ __forceinline__ void wg_run(char* smem, unsigned lds0, const char* __restrict__ dz, long ldz, const char* __restrict__ x, long ldx,
+                                       int mt, int nt, int t_begin, int nsteps, f32x16 (&acc)[TAPS][2]) {
     using C = WgCfg<SPLIT>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntn = cin >> 6;
-    const int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
-    const int sp = blockIdx.y;
-    const int t_begin = sp * steps_per_split * C::ROWS;
-    int nsteps = steps_total - sp * steps_per_split;             // the last splits may be short or empty (they then write zeros)
-    nsteps = nsteps < 0 ? 0 : (nsteps > steps_per_split ? steps_per_split : nsteps);
 
     // ---- DMA plan of this wave.  dZ: 16 pieces of 8 rows (chunk = piece / APP), wave w owns 4w..4w+3.
     // X window: NBP pieces (chunk = piece / BPP), wave w owns the pieces p with p % 4 == w (2 or 3 of them).
@@ -123,7 +116,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const char* __restrict
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     };
 
-    f32x16 acc[TAPS][2];
 #pragma unroll
     for (int k = 0; k < TAPS; ++k)
 #pragma unroll
@@ -137,6 +129,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const char* __restrict
     const int t_lane = (lane >> 5) * 8 + (q16 >> 2);             // + kk * 16 + h * 4
     const int ch_lane = ((lane >> 4) & 1) * 16 + (q16 & 3) * 4;  // channel inside the 32-channel block of this lane group pair
 
+    // (a stream-K workgroup enters with the previous segment's slab stores in flight: stores and loads retire out of order with
+    //  respect to each other, so the counted waits below must start from an empty queue)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (nsteps > 0) issue(0);
     if (nsteps > 1) issue(1);
     wait_next(nsteps > 1);
@@ -190,6 +185,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const char* __restrict
         __builtin_amdgcn_s_barrier();
     }
 
+}
+
+// grid: x = (cout/128) * (cin/64) tiles, y = nsplit; split s covers steps [s*steps_per_split, ...) of ROWS rows each.
+template <int SPLIT, int TAPS>
+__global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const char* __restrict__ dz, long ldz, const char* __restrict__ x, long ldx,
+                                                           float* __restrict__ part, int steps_per_split, int steps_total, int cout, int cin, int nsplit) {
+    using C = WgCfg<SPLIT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem));
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = cin >> 6;
+    const int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
+    const int sp = blockIdx.y;
+    int nsteps = steps_total - sp * steps_per_split;             // the last splits may be short or empty (they then write zeros)
+    nsteps = nsteps < 0 ? 0 : (nsteps > steps_per_split ? steps_per_split : nsteps);
+    f32x16 acc[TAPS][2];
+    wg_run<SPLIT, TAPS>(smem, lds0, dz, ldz, x, ldx, mt, nt, sp * steps_per_split * C::ROWS, nsteps, acc);
+
     // ---- partials: C/D layout col n = lane & 31 (ci), row m = (r&3) + 8*(r>>2) + 4*(lane>>5) (co)
     const int ci = nt * 64 + wn * 32 + (lane & 31);
 #pragma unroll
@@ -202,6 +217,62 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const char* __restrict
                 const int co = mt * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 o[(long)co * cin + ci] = acc[k][i][r];
             }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Grouped form (round 5): the weight gradients of ALL layers of a residual stack in one launch, the work dealt out
+// stream-K style.  The (item, tile, step) space of an XCD -- the tiles T = 8 j + xcd of the launch, 401 steps each at
+// B = 32 x 800 frames -- is cut into equal contiguous ranges, one per workgroup; a workgroup runs the segments of the
+// (at most `maxseg`) tiles its range touches and leaves one [taps][128][64] fp32 slab per segment.  Against one launch
+// per layer with 8 K-splits: 2.3 slabs per tile instead of 8 (12 instead of 42 MB of partials per layer written and
+// read back), no partial last round, one launch boundary per stack instead of one per layer; the reduction
+// (wgrad_reduce_sk_kernel, efts_train.hip) derives the slabs of a tile from the same geometry, in a fixed order.
+// ---------------------------------------------------------------------------------------------------------------
+struct WgItem { const char* dz; const char* x; long ldz, ldx; };
+struct WgSkArgs {
+    WgItem it[EFTS_WGRAD_MAX_ITEMS];
+    float* part;
+    int tiles_item, ntn;          // tiles per item, ci tiles per co tile
+    int nx;                       // 8: tile T belongs to XCD T % 8 (workgroup w runs on XCD w % 8); 1: one list
+    int steps_tile, q, total;     // steps per tile; steps per workgroup; steps of one list
+    int maxseg;
+};
+
+template <int SPLIT, int TAPS>
+__global__ __launch_bounds__(256, 2) void wgrad_sk_kernel(WgSkArgs p) {
+    using C = WgCfg<SPLIT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem));
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int w = blockIdx.x;
+    const int xcd = w % p.nx, loc = w / p.nx;
+    int g = loc * p.q;
+    const int g1 = g + p.q < p.total ? g + p.q : p.total;
+    for (int seg = 0; g < g1; ++seg) {
+        const int j = g / p.steps_tile, s0 = g - j * p.steps_tile;
+        const int n = p.steps_tile - s0 < g1 - g ? p.steps_tile - s0 : g1 - g;
+        const int T = j * p.nx + xcd;
+        const int item = T / p.tiles_item, tt = T - item * p.tiles_item;
+        const int mt = tt / p.ntn, nt = tt - mt * p.ntn;
+        const WgItem& q = p.it[item];
+        f32x16 acc[TAPS][2];
+        wg_run<SPLIT, TAPS>(smem, lds0, q.dz, q.ldz, q.x, q.ldx, mt, nt, s0 * C::ROWS, n, acc);
+        // slab [k][128 co][64 ci]: lanes along ci (128-byte runs), the two lane halves on rows 4 apart; one per-lane offset, the
+        // (tap, block, register) displacement in the scalar offset: no address registers beside the 160 accumulators
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.part + (long)(w * p.maxseg + seg) * (TAPS * 128 * 64)), 0,
+                                                                            TAPS * 128 * 64 * 4, 0x00020000);
+        const unsigned vo = (unsigned)(((wm * 64 + 4 * (lane >> 5)) * 64 + wn * 32 + (lane & 31)) * 4);
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[k][i][r]), rs, vo, ((k * 128 + i * 32 + (r & 3) + 8 * (r >> 2)) * 64) * 4, 0);
+        g += n;
     }
 }
 
@@ -234,4 +305,66 @@ extern "C" int efts_wgrad_tn(const void* dz_plane, int64_t ldz, const void* x_pl
     else { if (taps == 5) EFTS_WGTN(2, 5); else if (taps == 3) EFTS_WGTN(2, 3); else EFTS_WGTN(2, 1); }
 #undef EFTS_WGTN
     return efts_check_launch("efts_wgrad_tn");
+}
+
+// geometry shared by the grouped launch and its reduction (efts_train.hip): steps per tile, lists, steps per workgroup, slabs per workgroup
+int efts_wgrad_sk_geometry(int count, int rows, int cout, int cin, int split, int workgroups, efts_wgrad_sk_geom* gm) {
+    if (count < 1 || count > EFTS_WGRAD_MAX_ITEMS) return efts_fail(EFTS_EINVAL, "efts_wgrad_tn_grouped: 1..%d items", EFTS_WGRAD_MAX_ITEMS);
+    if (!(split == 1 || split == 2)) return efts_fail(EFTS_EINVAL, "efts_wgrad_tn_grouped: split must be 1 or 2");
+    if (rows <= 0 || cout <= 0 || cin <= 0 || (cout & 127) || (cin & 63))
+        return efts_fail(EFTS_ESHAPE, "efts_wgrad_tn_grouped: cout must be a multiple of 128, cin of 64");
+    const int rps = split == 1 ? WgCfg<1>::ROWS : WgCfg<2>::ROWS;
+    gm->steps_tile = (rows + rps - 1) / rps;
+    gm->tiles_item = (cout / 128) * (cin / 64);
+    gm->ntn = cin / 64;
+    const int ntiles = count * gm->tiles_item;
+    int G = workgroups > 0 ? workgroups : 2 * efts_num_cus();
+    gm->nx = (ntiles % 8 == 0 && G >= 8) ? 8 : 1;
+    G -= G % gm->nx;
+    const long total = (long)(ntiles / gm->nx) * gm->steps_tile;          // steps of one list
+    int per_list = G / gm->nx;
+    if (per_list > total) per_list = (int)total;
+    gm->q = (int)((total + per_list - 1) / per_list);
+    per_list = (int)((total + gm->q - 1) / gm->q);                        // (no empty workgroups)
+    gm->total = (int)total;
+    gm->workgroups = per_list * gm->nx;
+    gm->maxseg = (gm->q + gm->steps_tile - 1) / gm->steps_tile + 1;
+    return 0;
+}
+
+extern "C" int64_t efts_wgrad_grouped_part_bytes(int32_t count, int32_t rows, int32_t cout, int32_t cin, int32_t taps, int32_t split, int32_t workgroups) {
+    efts_wgrad_sk_geom gm;
+    if (efts_wgrad_sk_geometry(count, rows, cout, cin, split, workgroups, &gm)) return -1;
+    return (int64_t)gm.workgroups * gm.maxseg * taps * 128 * 64 * 4;
+}
+
+extern "C" int efts_wgrad_tn_grouped(const efts_wgrad_item* items, int32_t count, float* part, int32_t rows, int32_t cout, int32_t cin,
+                                     int32_t taps, int32_t split, int32_t workgroups, void* stream) {
+    if (!items || !part) return efts_fail(EFTS_EINVAL, "efts_wgrad_tn_grouped: null pointer");
+    if (!(taps == 1 || taps == 3 || taps == 5)) return efts_fail(EFTS_EINVAL, "efts_wgrad_tn_grouped: implemented for taps 1, 3, 5");
+    efts_wgrad_sk_geom gm;
+    const int rc = efts_wgrad_sk_geometry(count, rows, cout, cin, split, workgroups, &gm);
+    if (rc) return rc;
+    WgSkArgs k;
+    for (int i = 0; i < EFTS_WGRAD_MAX_ITEMS; ++i) {
+        const efts_wgrad_item* q = items + (i < count ? i : 0);
+        if (!q->dz_plane || !q->x_plane) return efts_fail(EFTS_EINVAL, "efts_wgrad_tn_grouped: null operand plane");
+        if ((q->ldz & 15) || (q->ldx & 15) || q->ldz < (int64_t)cout * 2 * split || q->ldx < (int64_t)cin * 2 * split || q->ldz > (1 << 20) || q->ldx > (1 << 20) ||
+            ((uintptr_t)q->dz_plane & 15) || ((uintptr_t)q->x_plane & 15))
+            return efts_fail(EFTS_EALIGN, "efts_wgrad_tn_grouped: plane strides / alignment");
+        k.it[i].dz = (const char*)q->dz_plane; k.it[i].x = (const char*)q->x_plane; k.it[i].ldz = q->ldz; k.it[i].ldx = q->ldx;
+    }
+    k.part = part; k.tiles_item = gm.tiles_item; k.ntn = gm.ntn; k.nx = gm.nx; k.steps_tile = gm.steps_tile; k.q = gm.q; k.total = gm.total;
+    k.maxseg = gm.maxseg;
+    const dim3 grid(gm.workgroups);
+#define EFTS_WGSK(S, T)                                                                                                                  \
+    do {                                                                                                                                 \
+        static bool attr = false;                                                                                                        \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_sk_kernel<S, T>, hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<S>::LDS); attr = true; } \
+        hipLaunchKernelGGL((wgrad_sk_kernel<S, T>), grid, dim3(256), WgCfg<S>::LDS, (hipStream_t)stream, k);                              \
+    } while (0)
+    if (split == 1) { if (taps == 5) EFTS_WGSK(1, 5); else if (taps == 3) EFTS_WGSK(1, 3); else EFTS_WGSK(1, 1); }
+    else { if (taps == 5) EFTS_WGSK(2, 5); else if (taps == 3) EFTS_WGSK(2, 3); else EFTS_WGSK(2, 1); }
+#undef EFTS_WGSK
+    return efts_check_launch("efts_wgrad_tn_grouped");
 }

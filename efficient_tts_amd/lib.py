@@ -95,6 +95,14 @@ class ResConv5Args(C.Structure):
     ]
 
 
+class WgradItem(C.Structure):
+    """mirror of `struct efts_wgrad_item` (include/efts_abi.h)"""
+    _fields_ = [("dz_plane", vp), ("ldz", i64), ("x_plane", vp), ("ldx", i64), ("v", vp), ("g", vp), ("dw_or_dv", vp), ("dg", vp),
+                ("bias_part", vp), ("dbias", vp), ("nparts", i32), ("reserved", i32)]
+
+
+WGRAD_MAX_ITEMS = 8
+
 _SIGS = {
     "efts_version": (i32, []),
     "efts_last_error": (C.c_char_p, []),
@@ -137,6 +145,9 @@ _SIGS = {
     "efts_wgrad_reduce": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
     "efts_wgrad_reduce_bias": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp, vp]),
     "efts_wgrad_tn": (i32, [vp, i64, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "efts_wgrad_grouped_part_bytes": (i64, [i32, i32, i32, i32, i32, i32, i32]),
+    "efts_wgrad_tn_grouped": (i32, [C.POINTER(WgradItem), i32, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "efts_wgrad_reduce_grouped": (i32, [C.POINTER(WgradItem), i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "efts_layernorm_bwd": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, i32, i32, f32, C.c_uint32, vp, vp]),
     "efts_alpha_bwd": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, vp]),
     "efts_e_bwd": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, vp]),

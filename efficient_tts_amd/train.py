@@ -48,9 +48,16 @@ _NARROW_TN = 1               # the 80-channel Linears' weight gradients on the d
 _EARLY_PACKS = 1             # alignment backward: the operand copies that depend on forward tensors only go to the side stream, early (A/B)
 
 
+_WGRAD_GROUP = 1             # the direct weight gradients of a residual stack in ONE stream-K launch + ONE reduction at the end of the stack's backward
+                             # (efts_wgrad_tn_grouped; 0: one efts_wgrad_tn + efts_wgrad_reduce_bias per layer, 8 K-splits each: tests compare)
+_WGRAD_GROUP_WGS = 384       # workgroups of a grouped launch (0: two per CU).  Swept 256..512 on the graphed B = 32 step: 3.27-3.32 ms at 384 against 3.33-3.34 at 512,
+                             # 3.28-3.34 at 256 (per-layer launches: 3.48-3.50); the launch is bound by the chip, not by its busiest CU
+
+
 def switch_tag() -> tuple:
     """every hook above, by value: part of the tag of a captured training step"""
-    return (_WGRAD_TN_SPLITS, _SIGN_MIN_ROWS, _BIAS_PARTS, _RESCONV_FWD, _RESCONV_DGRAD, _WGRAD_WGS, _PACK_SPLIT, _NARROW_TN, _EARLY_PACKS)
+    return (_WGRAD_TN_SPLITS, _SIGN_MIN_ROWS, _BIAS_PARTS, _RESCONV_FWD, _RESCONV_DGRAD, _WGRAD_WGS, _PACK_SPLIT, _NARROW_TN, _EARLY_PACKS,
+            _WGRAD_GROUP, _WGRAD_GROUP_WGS)
 
 
 class _TPlane(Plane):
@@ -229,6 +236,25 @@ class TrainEngine:
                                               _ptr(bias_part), 0 if bias_part is None else bias_part.shape[0], _ptr(dbias), O._stream()),
                 "efts_wgrad_reduce_bias")
 
+    def _wgrad_group(self, ws, items, cout, cin, rows, taps: int, split: int):
+        """the direct weight gradients of several layers of one stack (same shape, same row space) as ONE stream-K launch and ONE
+        reduction (csrc/efts_wgrad.hip `wgrad_sk_kernel`, csrc/efts_train.hip `wgrad_reduce_sk_kernel`).
+        items: (dz_p, x_p, v, g, out_dw, out_dg, bias_part, dbias) per layer"""
+        lib = _lib()
+        n = len(items)
+        arr = (L.WgradItem * n)()
+        for a, (dz_p, x_p, v, g, dw, dg, bp, db) in zip(arr, items):
+            a.dz_plane, a.ldz, a.x_plane, a.ldx = dz_p.ptr, dz_p.ld, x_p.ptr, x_p.ld
+            a.v, a.g, a.dw_or_dv, a.dg = _ptr(v), _ptr(g), dw.data_ptr(), _ptr(dg)
+            a.bias_part, a.dbias, a.nparts = _ptr(bp), _ptr(db), 0 if bp is None else bp.shape[0]
+        nbytes = lib.efts_wgrad_grouped_part_bytes(n, rows, cout, cin, taps, split, _WGRAD_GROUP_WGS)
+        if nbytes < 0:
+            L.check(-1, "efts_wgrad_grouped_part_bytes")
+        part = ws.get(("gpart", self._ws_tag, n, rows, cout, cin, taps, split, _WGRAD_GROUP_WGS), lambda: torch.empty(nbytes // 4, device=self.dev))
+        L.check(lib.efts_wgrad_tn_grouped(arr, n, part.data_ptr(), rows, cout, cin, taps, split, _WGRAD_GROUP_WGS, O._stream()), "efts_wgrad_tn_grouped")
+        L.check(lib.efts_wgrad_reduce_grouped(arr, n, part.data_ptr(), rows, cout, cin, taps, split, _WGRAD_GROUP_WGS, O._stream()),
+                "efts_wgrad_reduce_grouped")
+
     def _wgrad_narrow(self, ws, tag, dz_p: Plane, x_p: Plane, cout, cin, rows, out_dw) -> bool:
         """weight gradient of a Linear with an 80-channel side (mel head 512 -> 80, prenet 80 -> 512) on the direct kernel: bf16 planes are
         128 columns wide (two 64-channel chunks, zeros beyond the 80th), so the contraction runs on the padded 128 and the result's first
@@ -296,18 +322,21 @@ class TrainEngine:
         """backward through n x (x + leaky(conv(x))); returns the gradient w.r.t. the stack input"""
         m, C = self.m, self.m.n_channels
         layers = getattr(m, blk).layers
+        group = []                                               # (grouped direct wgrads: every layer keeps its dZ plane and bias sums until the stack is through)
+        grouped = _WGRAD_GROUP and _WGRAD_TN_SPLITS > 0 and len(layers) <= L.WGRAD_MAX_ITEMS
         for i in reversed(range(len(layers))):
             x_f, y_f, x_pl, sg, dp, dseed = saved[i]
             conv = layers[i].conv[0]
             pre = f"{blk}.layers.{i}.conv.0."
-            dz_p = ws.plane(f"B{tag}_dzp", rs, C, m.split)
-            direct = _WGRAD_TN_SPLITS > 0 and C % 128 == 0 and x_pl.split == dz_p.split and m.k_size <= 5     # (efts_wgrad_tn: taps 1 / 3 / 5)
+            direct = _WGRAD_TN_SPLITS > 0 and C % 128 == 0 and x_pl.split == m.split and m.k_size <= 5     # (efts_wgrad_tn: taps 1 / 3 / 5)
+            keep = "" if not (direct and grouped) else str(i)
+            dz_p = ws.plane(f"B{tag}_dzp{keep}", rs, C, m.split)
             # the direct wgrad and the dgrad both read dZ as the bf16 plane: its fp32 copy is only written for the
             # transposed-plane path
             dz_f = None if direct else ws.f32(f"B{tag}_dz", rs, C)
             # direct path: the bias gradient leaves act_bwd as per-row-block sums and is finished by the wgrad reduction
             # (no same-address atomics: ~8 of 22 us per launch at mel length)
-            bp = ws.tensor(f"B{tag}_bp", ((rs.rows + 63) // 64, C)) if (direct and _BIAS_PARTS) else None
+            bp = ws.tensor(f"B{tag}_bp{keep}", ((rs.rows + 63) // 64, C)) if (direct and _BIAS_PARTS) else None
             db, parts = (bp, L.ACT_BWD_BIAS_PARTS) if bp is not None else (self.g[pre + "bias"], 0)
             if sg is not None and sg[1] == "z":                  # general activation: f'(z) from the kept pre-activation, bias gradient by atomics
                 bp = None
@@ -319,7 +348,9 @@ class TrainEngine:
             wn = hasattr(conv, "weight_g")
             v_, g_ = (conv.weight_v.detach(), conv.weight_g.detach()) if wn else (None, None)
             dw_, dg_ = (self.g[pre + "weight_v"], self.g[pre + "weight_g"]) if wn else (self.g[pre + "weight"], None)
-            if direct:
+            if direct and grouped:
+                group.append((dz_p, x_pl, v_, g_, dw_, dg_, bp, self.g[pre + "bias"]))
+            elif direct:
                 self._wgrad_tn(ws, dz_p, x_pl, C, C, rs.rows, v_, g_, dw_, dg_, bias_part=bp, dbias=self.g[pre + "bias"], taps=m.k_size)
             else:
                 self._wgrad(ws, dz_f.ptr, C, x_f.ptr, C, C, m.k_size, rs.rows, v_, g_, dw_, dg_)
@@ -336,6 +367,8 @@ class TrainEngine:
                        rowmask_ptr=final_mask_ptr if last else gap_ptr, out_f32_ptr=Gn.ptr, ldo=C,
                        out_plane=final_plane if last else None)
             G = Gn
+        if group:
+            self._wgrad_group(ws, group, C, C, rs.rows, m.k_size, m.split)
         return G
 
     def forward_backward(self, text, text_lengths, speech, speech_lengths, gscale: Optional[torch.Tensor] = None,

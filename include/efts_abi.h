@@ -503,6 +503,33 @@ int efts_wgrad_reduce(const float* part, int32_t nsplit, const float* v, const f
 int efts_wgrad_reduce_bias(const float* part, int32_t nsplit, const float* v, const float* g, float* dw_or_dv, float* dg,
                            int32_t cout, int32_t cin, int32_t taps, const float* bias_part, int32_t nparts, float* dbias,
                            void* stream);
+/* Grouped form: the weight gradients of up to EFTS_WGRAD_MAX_ITEMS layers of one residual stack (same rows, cout, cin, taps and plane
+ * format; autograd of the Conv1d of every ResConv1d of `ResConvBlock`, nntts/layers/efts_modules.py:77-79 under
+ * nntts/trainers/efficient_tts_trainer.py:146) in ONE launch.  The (layer, tile, 64-row step) space is dealt out to `workgroups`
+ * workgroups (0: two per CU) as equal contiguous ranges (stream-K); every workgroup leaves one fp32 slab per tile its range touches
+ * in `part` (efts_wgrad_grouped_part_bytes() bytes; -1: bad arguments), and efts_wgrad_reduce_grouped -- called with the SAME count, rows, cout, cin,
+ * taps, split and workgroups -- adds a tile's slabs in a fixed order and finishes every layer like efts_wgrad_reduce_bias. */
+#define EFTS_WGRAD_MAX_ITEMS 8
+typedef struct efts_wgrad_item {
+    const void* dz_plane;   /* operand plane of dZ, row 0 (efts_wgrad_tn) */
+    int64_t ldz;
+    const void* x_plane;    /* operand plane of the layer's input, row 0 */
+    int64_t ldx;
+    const float* v;         /* weight_v [cout][cin][taps] (with g) or NULL */
+    const float* g;         /* weight_g [cout] or NULL: no weight-norm backward, dw_or_dv receives dW */
+    float* dw_or_dv;        /* [cout][cin][taps] */
+    float* dg;              /* [cout] or NULL */
+    const float* bias_part; /* [nparts][cout] column sums efts_act_bwd left (EFTS_ACT_BWD_BIAS_PARTS), or NULL */
+    float* dbias;           /* [cout], += */
+    int32_t nparts;
+    int32_t reserved;
+} efts_wgrad_item;
+int64_t efts_wgrad_grouped_part_bytes(int32_t count, int32_t rows, int32_t cout, int32_t cin, int32_t taps, int32_t split,
+                                      int32_t workgroups);
+int efts_wgrad_tn_grouped(const efts_wgrad_item* items, int32_t count, float* part, int32_t rows, int32_t cout, int32_t cin,
+                          int32_t taps, int32_t split, int32_t workgroups, void* stream);
+int efts_wgrad_reduce_grouped(const efts_wgrad_item* items, int32_t count, const float* part, int32_t rows, int32_t cout,
+                              int32_t cin, int32_t taps, int32_t split, int32_t workgroups, void* stream);
 /* backward of [ReLU ->] LayerNorm [-> Linear(c,1)] (duration_predictor.py:57-77); accumulates
  * dgamma, dbeta, conv-bias grad (dbias), and with ddur != NULL the Linear's dw, db. */
 int efts_layernorm_bwd(const float* x, const float* gamma, const float* beta, float eps, const float* dy,
