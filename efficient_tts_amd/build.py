@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["efts_common.hip", "efts_gemm.hip", "efts_gemm_narrow.hip", "efts_conv5.hip", "efts_smallm.hip", "efts_resconv.hip", "efts_prenet.hip", "efts_ops.hip", "efts_align.hip", "efts_train.hip", "efts_frontend.hip", "efts_wgrad.hip", "efts_vocoder.hip", "efts_act.hip"]
+SOURCES = ["efts_common.hip", "efts_gemm.hip", "efts_gemm_narrow.hip", "efts_conv5.hip", "efts_smallm.hip", "efts_resconv.hip", "efts_resconv_bwd.hip", "efts_prenet.hip", "efts_ops.hip", "efts_align.hip", "efts_train.hip", "efts_frontend.hip", "efts_wgrad.hip", "efts_vocoder.hip", "efts_act.hip"]
 LIB = os.path.join(HERE, "libefts_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 

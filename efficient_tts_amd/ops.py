@@ -163,9 +163,14 @@ def gemm(*, a: Plane, a_ptr: Optional[int] = None, b_ptr: int, ldb: int, b_tap_s
 def _resconv5_fill(g, *, x: Plane, x_lo: Optional[Plane] = None, x_f32_ptr: Optional[int] = None, ldr: int = 0, w: "PackedWeight",
                    m: int, n: int, bias: Optional[torch.Tensor] = None, slope: float = 0.1, rowmask_ptr: Optional[int] = None,
                    y_f32_ptr: Optional[int] = None, ldo: int = 0, y: Optional[Plane] = None, y_lo: Optional[Plane] = None,
-                   plan=None, taps: int = 5, no_residual: bool = False, sign_bits_ptr: Optional[int] = None) -> None:
+                   plan=None, taps: int = 5, no_residual: bool = False, sign_bits_ptr: Optional[int] = None,
+                   act_bwd_sign_ptr: Optional[int] = None, act_bwd_slope: float = 0.0, act_bwd_bias_part: Optional[torch.Tensor] = None) -> None:
     if plan is not None:
         g.plan = plan
+    if act_bwd_sign_ptr is not None:                 # training backward: the activation backward of the layer below in this dgrad launch's epilogue
+        g.act_bwd_sign, g.act_bwd_slope = act_bwd_sign_ptr, act_bwd_slope
+        if act_bwd_bias_part is not None:
+            g.act_bwd_bias_part, g.act_bwd_bias_rows = act_bwd_bias_part.data_ptr(), act_bwd_bias_part.shape[0]
     g.taps, g.no_residual, g.sign_bits = taps, int(no_residual), sign_bits_ptr
     g.x, g.x_lo, g.ldx = x.ptr, (None if x_lo is None else x_lo.ptr), x.ld
     g.x_f32, g.ldr = x_f32_ptr, ldr
@@ -224,6 +229,19 @@ def frame_linear(*, x: torch.Tensor, w: "PackedWeight", bias: Optional[torch.Ten
         g.y, g.ldy, g.y_split = y.ptr, y.ld, y.split
         g.y_lo = None if y_lo is None else y_lo.ptr
     L.check(L.load().efts_frame_linear(C.byref(g), _stream()), "efts_frame_linear")
+
+
+_bias_rows_cache = {}
+
+
+def resconv5_bias_rows(m: int, n: int) -> int:
+    """rows of the column-sum table a dgrad launch with the fused activation backward fills (efts_resconv5_bias_rows)"""
+    if (m, n) not in _bias_rows_cache:
+        rc = L.load().efts_resconv5_bias_rows(m, n)
+        if rc < 0:
+            L.check(rc, "efts_resconv5_bias_rows")
+        _bias_rows_cache[(m, n)] = rc
+    return _bias_rows_cache[(m, n)]
 
 
 def resconv5_plan(m: int, n: int, cus: int = 0):

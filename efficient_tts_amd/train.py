@@ -48,6 +48,8 @@ _NARROW_TN = 1               # the 80-channel Linears' weight gradients on the d
 _EARLY_PACKS = 1             # alignment backward: the operand copies that depend on forward tensors only go to the side stream, early (A/B)
 
 
+_FUSE_ACT_BWD = 1            # stacks whose dgrad runs on efts_resconv5: the activation backward of layer l - 1 in the epilogue of layer l's dgrad launch
+                             # (csrc/efts_resconv_bwd.hip) instead of an efts_act_bwd launch of its own (0: separate launches; tests compare)
 _WGRAD_GROUP = 1             # the direct weight gradients of a residual stack in ONE stream-K launch + ONE reduction at the end of the stack's backward
                              # (efts_wgrad_tn_grouped; 0: one efts_wgrad_tn + efts_wgrad_reduce_bias per layer, 8 K-splits each: tests compare)
 _WGRAD_GROUP_WGS = 384       # workgroups of a grouped launch (0: two per CU).  Swept 256..512 on the graphed B = 32 step: 3.27-3.32 ms at 384 against 3.33-3.34 at 512,
@@ -57,7 +59,7 @@ _WGRAD_GROUP_WGS = 384       # workgroups of a grouped launch (0: two per CU).  
 def switch_tag() -> tuple:
     """every hook above, by value: part of the tag of a captured training step"""
     return (_WGRAD_TN_SPLITS, _SIGN_MIN_ROWS, _BIAS_PARTS, _RESCONV_FWD, _RESCONV_DGRAD, _WGRAD_WGS, _PACK_SPLIT, _NARROW_TN, _EARLY_PACKS,
-            _WGRAD_GROUP, _WGRAD_GROUP_WGS)
+            _WGRAD_GROUP, _WGRAD_GROUP_WGS, _FUSE_ACT_BWD)
 
 
 class _TPlane(Plane):
@@ -324,27 +326,33 @@ class TrainEngine:
         layers = getattr(m, blk).layers
         group = []                                               # (grouped direct wgrads: every layer keeps its dZ plane and bias sums until the stack is through)
         grouped = _WGRAD_GROUP and _WGRAD_TN_SPLITS > 0 and len(layers) <= L.WGRAD_MAX_ITEMS
+        on_rc = bool((_RESCONV_DGRAD if _RESCONV_DGRAD >= 0 else (1 if m.split == 1 else 3)) & dict(dec=1, me=2, te=0)[tag]) and m._on_resconv(rs)
+        fused = None                                             # (dZ plane, bias sums) of layer i the dgrad launch of layer i + 1 has already written
         for i in reversed(range(len(layers))):
             x_f, y_f, x_pl, sg, dp, dseed = saved[i]
             conv = layers[i].conv[0]
             pre = f"{blk}.layers.{i}.conv.0."
             direct = _WGRAD_TN_SPLITS > 0 and C % 128 == 0 and x_pl.split == m.split and m.k_size <= 5     # (efts_wgrad_tn: taps 1 / 3 / 5)
             keep = "" if not (direct and grouped) else str(i)
-            dz_p = ws.plane(f"B{tag}_dzp{keep}", rs, C, m.split)
-            # the direct wgrad and the dgrad both read dZ as the bf16 plane: its fp32 copy is only written for the
-            # transposed-plane path
-            dz_f = None if direct else ws.f32(f"B{tag}_dz", rs, C)
-            # direct path: the bias gradient leaves act_bwd as per-row-block sums and is finished by the wgrad reduction
-            # (no same-address atomics: ~8 of 22 us per launch at mel length)
-            bp = ws.tensor(f"B{tag}_bp{keep}", ((rs.rows + 63) // 64, C)) if (direct and _BIAS_PARTS) else None
-            db, parts = (bp, L.ACT_BWD_BIAS_PARTS) if bp is not None else (self.g[pre + "bias"], 0)
-            if sg is not None and sg[1] == "z":                  # general activation: f'(z) from the kept pre-activation, bias gradient by atomics
-                bp = None
-                O.act_grad(m.act_general, G.ptr, sg[0].ptr, gap_ptr, dz_f, dz_p, self.g[pre + "bias"], rs.rows, C, dp, dseed)
-            elif sg is not None:                                 # (sign words of efts_gemm: mode 4; sign bits of efts_resconv5: mode 5)
-                self._act_bwd(G.ptr, sg[0].data_ptr(), None, gap_ptr, sg[1] | parts, dz_f, dz_p, db, rs.rows, C, dp, dseed)
+            if fused is not None:
+                dz_p, bp = fused
+                dz_f = None
             else:
-                self._act_bwd(G.ptr, y_f.ptr, x_f.ptr, gap_ptr, 1 | parts, dz_f, dz_p, db, rs.rows, C, dp, dseed)
+                dz_p = ws.plane(f"B{tag}_dzp{keep}", rs, C, m.split)
+                # the direct wgrad and the dgrad both read dZ as the bf16 plane: its fp32 copy is only written for the
+                # transposed-plane path
+                dz_f = None if direct else ws.f32(f"B{tag}_dz", rs, C)
+                # direct path: the bias gradient leaves act_bwd as per-row-block sums and is finished by the wgrad reduction
+                # (no same-address atomics: ~8 of 22 us per launch at mel length)
+                bp = ws.tensor(f"B{tag}_bp{keep}", ((rs.rows + 63) // 64, C)) if (direct and _BIAS_PARTS) else None
+                db, parts = (bp, L.ACT_BWD_BIAS_PARTS) if bp is not None else (self.g[pre + "bias"], 0)
+                if sg is not None and sg[1] == "z":                  # general activation: f'(z) from the kept pre-activation, bias gradient by atomics
+                    bp = None
+                    O.act_grad(m.act_general, G.ptr, sg[0].ptr, gap_ptr, dz_f, dz_p, self.g[pre + "bias"], rs.rows, C, dp, dseed)
+                elif sg is not None:                                 # (sign words of efts_gemm: mode 4; sign bits of efts_resconv5: mode 5)
+                    self._act_bwd(G.ptr, sg[0].data_ptr(), None, gap_ptr, sg[1] | parts, dz_f, dz_p, db, rs.rows, C, dp, dseed)
+                else:
+                    self._act_bwd(G.ptr, y_f.ptr, x_f.ptr, gap_ptr, 1 | parts, dz_f, dz_p, db, rs.rows, C, dp, dseed)
             wn = hasattr(conv, "weight_g")
             v_, g_ = (conv.weight_v.detach(), conv.weight_g.detach()) if wn else (None, None)
             dw_, dg_ = (self.g[pre + "weight_v"], self.g[pre + "weight_g"]) if wn else (self.g[pre + "weight"], None)
@@ -357,11 +365,23 @@ class TrainEngine:
             wt = self.wt[f"{blk}.{i}"]
             Gn = ws.f32(f"B{tag}_G{i & 1}", rs, C)
             last = i == 0
-            if ((_RESCONV_DGRAD if _RESCONV_DGRAD >= 0 else (1 if m.split == 1 else 3)) & dict(dec=1, me=2, te=0)[tag]) and m._on_resconv(rs) and dz_p.split == m.split:
+            fused = None
+            if on_rc and dz_p.split == m.split:
                 # dgrad on the persistent kernel: G' = (G + conv_T(dZ)) * mask = a residual layer with the transposed weights, no bias
                 # and slope 1, fp32 gradient stream in and out (bit-identical to the efts_gemm launch)
-                O.resconv5(x=dz_p, x_f32_ptr=G.ptr, ldr=C, w=wt, taps=m.k_size, m=rs.rows, n=C, slope=1.0,
-                           rowmask_ptr=final_mask_ptr if last else gap_ptr, y_f32_ptr=Gn.ptr, ldo=C, y=final_plane if last else None)
+                below = saved[i - 1] if i > 0 else None
+                if (_FUSE_ACT_BWD and below is not None and below[3] is not None and below[3][1] == 5 and below[4] == 0.0 and direct and grouped
+                        and _BIAS_PARTS and m.k_size == 5 and below[2].split == m.split):
+                    # ... and the activation backward of layer i - 1 on G' while the epilogue holds it: dZ_{i-1} as its operand plane and one
+                    # row of column sums per tile (the launch efts_act_bwd would otherwise read G' back for)
+                    nz_p = ws.plane(f"B{tag}_dzp{i - 1}", rs, C, m.split)
+                    nbp = ws.tensor(f"B{tag}_bq{i - 1}", (O.resconv5_bias_rows(rs.rows, C), C))
+                    O.resconv5(x=dz_p, x_f32_ptr=G.ptr, ldr=C, w=wt, taps=5, m=rs.rows, n=C, slope=1.0, rowmask_ptr=gap_ptr, y_f32_ptr=Gn.ptr, ldo=C,
+                               y=nz_p, act_bwd_sign_ptr=below[3][0].data_ptr(), act_bwd_slope=m.slope, act_bwd_bias_part=nbp)
+                    fused = (nz_p, nbp)
+                else:
+                    O.resconv5(x=dz_p, x_f32_ptr=G.ptr, ldr=C, w=wt, taps=m.k_size, m=rs.rows, n=C, slope=1.0,
+                               rowmask_ptr=final_mask_ptr if last else gap_ptr, y_f32_ptr=Gn.ptr, ldo=C, y=final_plane if last else None)
             else:
                 O.gemm(a=dz_p, b_ptr=wt.ptr, ldb=wt.ld, b_tap_stride=wt.tap_stride, taps=m.k_size, m=rs.rows, n=C, resid_ptr=G.ptr, ldr=C,
                        rowmask_ptr=final_mask_ptr if last else gap_ptr, out_f32_ptr=Gn.ptr, ldo=C,

@@ -193,9 +193,21 @@ typedef struct efts_resconv5_args {
     void* sign_bits;     /* training forward, optional: the sign of every activated output BEFORE the residual add as plain bit rows for
                           * efts_act_bwd mode 5 -- row stride n / 8 bytes, bit j of byte c = column 8 c + j is positive (the same
                           * information as efts_gemm_args.sign_mask, in the order this kernel's epilogue holds it).  NULL: not written */
+    /* training backward, optional: this launch is the DGRAD of stack layer l -- x = the operand plane of dZ_l, w = the transposed weights,
+     * x_f32 = G, y_f32 = G' = d loss / d x_l, slope 1, no bias -- and its epilogue also runs the activation backward of layer l - 1
+     * (efts_act_bwd mode 5 | EFTS_ACT_BWD_BIAS_PARTS) on the values it holds: y receives dZ_{l-1} = G' * (bit ? 1 : act_bwd_slope) as an
+     * operand plane of format y_split = split, act_bwd_bias_part one row of column sums of dZ_{l-1} per tile and wave row
+     * (efts_resconv5_bias_rows(m, n) rows of n floats, zero-filled by the caller once: rows of tiles the schedule does not have are never
+     * written; NULL: no sums).  act_bwd_sign = the sign_bits layer l - 1's forward launch wrote.  NULL: a plain layer. */
+    const void* act_bwd_sign;
+    float* act_bwd_bias_part;
+    int32_t act_bwd_bias_rows;
+    float act_bwd_slope;
 } efts_resconv5_args;
 
 int efts_resconv5(const efts_resconv5_args* a, void* stream);
+/* rows of efts_resconv5_args.act_bwd_bias_part for an m x n layer on the current device (the automatic schedule) */
+int efts_resconv5_bias_rows(int32_t m, int32_t n);
 
 /* `count` (1 or 2) independent residual layers of the same geometry (split, n, nchunk, ldw) in ONE persistent launch: the rows of
  * the layers are laid end to end and scheduled over the compute units as one row space; a tile never crosses from one layer
