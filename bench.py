@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--call-modes", type=int, default=1, help="forward workloads, N=1: 10 extra steps per call mode (plain call / bench graph / eager) -> `call_modes`")
     ap.add_argument("--train-record", type=int, default=1, help="fwd64, N=1: also time BASELINE config 3 (training step B=32, 40 steps) under the same invocation -> `train32` in the JSON line")
     ap.add_argument("--measure-traffic", type=int, default=1, help="forward workloads, N=1: roofline.traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) over a 2-step child run, when rocprofv3 is on the box; 0: the committed profiles/traffic.json")
-    ap.add_argument("--rc-kernel", type=int, default=0, help="A/B: efts_resconv5_kernel(which): 0 / 1 the 8-wave ping-pong kernel (default), 2 the one-wave-per-SIMD kernel where it applies")
+    ap.add_argument("--rc-kernel", type=int, default=0, help="A/B: efts_resconv5_args.kernel of every launch: 0 the 8-wave ping-pong kernel (default), 2 the one-wave-per-SIMD kernel where it applies")
     return ap.parse_args()
 
 
@@ -245,6 +245,46 @@ def run_infer64(a, world, rank, dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     dt /= a.steps
+    # roofline of the dominant kernel: the decoder's six efts_resconv5 launches at 64 x 802 rows, HIP events on the launch stream around
+    # each of them over three more calls
+    from efficient_tts_amd import ops as Pops
+    rows = Pops.Rows(B, T2).rows
+    keep_graphs, model.graphs = model.graphs, False      # (the timed calls replay graphs: the launches are issued eagerly here so that they can be bracketed)
+    model.inference_batch(text, tl, force_delta=T2 / T1)
+    torch.cuda.synchronize()
+    Pops.PROFILE, Pops.PROFILE_TAG = [], None
+    for _ in range(3):
+        model.inference_batch(text, tl, force_delta=T2 / T1)
+    torch.cuda.synchronize()
+    durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in Pops.PROFILE if tag[0] == 5 and tag[2] == 512 and tag[1] >= B * T2]
+    Pops.PROFILE, Pops.PROFILE_TAG = None, None
+    model.graphs = keep_graphs
+    roof, cpu = None, None
+    if durs:
+        avg = sum(durs) / len(durs)
+        flop = 2.0 * B * T2 * 512 * 512 * 5
+        alg_bytes = rows * 512 * 8 + 5 * 512 * 512 * (2 if model.split == 1 else 4)
+        roof = dict(bound="mfma", kernel=f"resconv5_kernel<split={model.split}>: the decoder's k5 Conv1d 512->512 launches of the free-running pass, {B}x{T2} frames",
+                    achieved=flop / avg / 1e12, peak=PEAK_MFMA_BF16_TFLOPS, unit="TFLOP/s", frac=flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS, traffic=None,
+                    traffic_note="the forward's measurement applies (same kernel, same launch shape): the fwd64 line's roofline.traffic",
+                    avg_launch_us=avg * 1e6, launches_measured=len(durs), algorithmic_flop_per_launch=flop, algorithmic_bytes_per_launch=alg_bytes)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        # the oracle's free-running pass on this box's host cores: a bounded sample (4 items one by one -- the reference's inference() is
+        # B = 1 by construction, efficient_tts.py:230-285 -- with the same forced durations), 16 threads
+        from oracle import efts_oracle as O          # the cpu_baseline leg: oracle as the thing timed
+        Pm = {k: v.detach().cpu().float() for k, v in model.state_dict().items()}
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        fd = torch.full((1, T1), T2 / T1)
+        tc = text.cpu()
+        with torch.no_grad():
+            O.inference(Pm, tc[:1], forced_delta=fd)
+            t0 = time.perf_counter()
+            for i in range(32):
+                O.inference(Pm, tc[i:i + 1], forced_delta=fd)
+            dc = time.perf_counter() - t0
+        cpu = dict(value=32 * T2 / dc, unit="mel-frames/s", cores=torch.get_num_threads(), kind="port",
+                   sample=f"oracle inference() fp32, 32 of the 64 items one by one (B = 1 is the reference's free-running form), durations forced to {T2 / T1} "
+                          f"frames per phoneme, after 1 warm-up call ({dc:.2f} s)")
     if rank == 0:
         res = dict(metric="mel-frames/sec (EFTS-CNN batched free-running inference, batch 64/GPU, 80-mel)", value=world * B * T2 / dt,
                    unit="mel-frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt * 1e3, higher_is_better=True,
@@ -252,7 +292,7 @@ def run_infer64(a, world, rank, dev):
                    data="synthetic", config={"workload": "EFTS-CNN inference_batch B=64 phon=128, durations forced to 6.25 -> mel=800 (eager, one host sync per call)",
                                               "batch_per_gpu": B, "phoneme_len": T1, "mel_len": T2, "precision": a.precision,
                                               "parallelism": f"replicas x{world}"},
-                   rtf=dt / (world * B * T2 * 256 / 22050.0), roofline=None, cpu_baseline=None)
+                   rtf=dt / (world * B * T2 * 256 / 22050.0), roofline=roof, cpu_baseline=cpu)
         print(json.dumps(res), flush=True)
 
 
@@ -563,8 +603,7 @@ def main():
 
     from efficient_tts_amd import EfficientTTSCNN, ops as P
     if a.rc_kernel:
-        from efficient_tts_amd import lib as _L
-        _L.load().efts_resconv5_kernel(a.rc_kernel)
+        P.RC_KERNEL = a.rc_kernel
     if a.workload == "infer_lj":
         return run_infer_lj(a, world, rank, dev)
     if a.workload == "infer64":
@@ -622,7 +661,7 @@ def conv_roofline(P, model, step, B, T2, precision, workload, a=None):
                 mfma_issue_frac=(3 if model.split == 2 else 1) * flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS)
 
 
-def _watchdog(seconds, rank, res, key, partial=None):
+def _watchdog(seconds, rank, res, key, partial=None, code=3):
     """a timer that, when it fires, prints rank 0's line (with `key` marked as abandoned, or holding what `partial()` returns: the part of
     the record that had been measured) and ends the process; .cancel() disarms it"""
     import threading
@@ -636,10 +675,11 @@ def _watchdog(seconds, rank, res, key, partial=None):
                 res.setdefault(key, part)
             res.setdefault(key, dict(error=note))
             try:
-                print(json.dumps(res), flush=True)
+                import copy
+                print(json.dumps(copy.deepcopy(res)), flush=True)      # (a snapshot: the main thread may still be writing `res`)
             except Exception:                                          # noqa: BLE001
                 pass
-        os._exit(0)
+        os._exit(code)                                                 # a fired watchdog is a failed run for callers that gate on the code
     t = threading.Timer(seconds, fire)
     t.daemon = True
     t.start()
@@ -809,19 +849,32 @@ def run_forward(a, world, rank, dev, wl):
                 got = measure_traffic(a, a.precision, "train32") if (a.measure_traffic and a.gpus == 1) else None
                 if got is not None:
                     tr["roofline"]["traffic"], tr["roofline"]["traffic_source"] = got
+                if trp is not None:
+                    gotp = measure_traffic(a, "bf16x3", "train32") if (a.measure_traffic and a.gpus == 1) else None
+                    if gotp is not None:
+                        tr["parity_mode"]["roofline"]["traffic"], tr["parity_mode"]["roofline"]["traffic_source"] = gotp
                 if not a.no_cpu_baseline:
                     tr["cpu_baseline"] = cpu_train_baseline(T1, T2)
             res["train32"] = tr
+            if world > 1 and isinstance(tr.get("dp"), dict):
+                # what a reader of the N > 1 line wants first: the top-level `value` is the collective-free replica forward; the path WITH
+                # the RCCL exchange is the training step, lifted here (whole-job frames/s, ms per step, this run's own scaling efficiency
+                # = step without the exchange / step with it, and the part of the exchange the backward did not hide)
+                res["dp_value"], res["dp_unit"], res["dp_ms_per_step"] = tr["value"], tr["unit"], tr["ms_per_step"]
+                res["dp_efficiency"], res["dp_exposed_ms"] = tr["dp"].get("efficiency"), tr["dp"].get("exposed_ms")
+                res["dp_note"] = ("training step B=32/GPU with the bucketed RCCL gradient exchange (train32); dp_efficiency = the same step's time with the "
+                                  "exchange switched off / with it, both eager, same run (train32.dp.step_ms_*)")
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist
-        _watchdog(60, rank, None, None)                                # the line is out: a tear-down that hangs must not hold the launcher
+        _watchdog(60, rank, None, None, code=0)                                # the line is out: a tear-down that hangs must not hold the launcher
         try:
             dist.destroy_process_group()
         except Exception:                                              # noqa: BLE001 -- the line is out; nothing left to lose
             pass
-        os._exit(0)
+        bad = rank == 0 and isinstance(res, dict) and isinstance(res.get("train32"), dict) and "error" in res["train32"]
+        os._exit(3 if bad else 0)
 
 
 if __name__ == "__main__":

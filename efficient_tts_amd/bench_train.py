@@ -46,6 +46,26 @@ def _rccl_log_lines(limit: int = 12):
     return out or None
 
 
+XGMI_LINKS, XGMI_LINK_GBPS = 7, 153.0        # per GPU, SURVEY.md section 5 (point-to-point: a ring is bound by ONE link)
+
+
+def exchange_model(stats: dict, with_ms: float, without_ms: float, world: int) -> dict:
+    """what the data-parallel line says about its own collectives (pure arithmetic: unit-tested on the CPU): the step with and without
+    the exchange under the same clock, their ratio as the scaling efficiency of this run, and per bucket the all-reduce BUS bandwidth
+    2 (N - 1) / N * bytes / time against one xGMI link (what a ring can reach) and against all seven (the direct exchange's ceiling)"""
+    out = dict(step_ms_with_exchange=with_ms, step_ms_no_exchange=without_ms,
+               efficiency=(without_ms / with_ms) if with_ms > 0 else None,
+               xgmi=dict(links_per_gpu=XGMI_LINKS, link_gbps=XGMI_LINK_GBPS, all_links_gbps=XGMI_LINKS * XGMI_LINK_GBPS))
+    mb, ms = stats.get("bucket_mb") or [], stats.get("bucket_ms") or []
+    if world > 1 and mb and len(mb) == len(ms):
+        f = 2.0 * (world - 1) / world
+        bw = [f * m / t if t and t > 0 else None for m, t in zip(mb, ms)]           # MB / ms = GB/s
+        out["bucket_busbw_gbps"] = bw
+        out["bucket_busbw_frac_of_one_link"] = [None if b is None else b / XGMI_LINK_GBPS for b in bw]
+        out["bucket_busbw_frac_of_all_links"] = [None if b is None else b / (XGMI_LINKS * XGMI_LINK_GBPS) for b in bw]
+    return out
+
+
 def measure_train(a, world, rank, dev, wl, steps, warmup, precision=None):
     """K timed training steps (barrier + synchronize on both sides, max over ranks) -> the record (rank 0; None elsewhere).
 
@@ -185,6 +205,31 @@ def measure_train(a, world, rank, dev, wl, steps, warmup, precision=None):
         P.PROFILE, P.PROFILE_TAG = None, None
         dp_stats = ddp.reducer.stats()
         lv_eager = float(loss)
+        # ---- (2b) the same K steps with the exchange switched off (the engine's bucket hooks detached): what the step costs this rank
+        # without its collectives, under the same clock -- so that the line states its own scaling efficiency.  Replicas diverge in this
+        # loop (every rank applies its own gradient), hence parameters, optimizer moments, step counters and the learning-rate schedule
+        # are put back afterwards, and the fingerprint check is repeated
+        eng = ddp.engine
+        snap = (opt.flat_p.clone(), opt.m.clone(), opt.v.clone(), opt.vmax.clone(), opt.t, sch.state_dict(), model.dropout_calls,
+                [dict(g_) for g_ in ({k: v for k, v in g.items() if k != "params"} for g in opt.param_groups)])
+        hooks = (eng.bucket_hook, eng.join_reduce)
+        eng.bucket_hook, eng.join_reduce = None, None
+        try:
+            noex_dt, _ = timed(step, steps)
+        finally:
+            eng.bucket_hook, eng.join_reduce = hooks
+            opt.flat_p.copy_(snap[0]); opt.m.copy_(snap[1]); opt.v.copy_(snap[2]); opt.vmax.copy_(snap[3])
+            opt.t = snap[4]
+            sch.load_state_dict(snap[5])
+            model.dropout_calls = snap[6]
+            for g_, old in zip(opt.param_groups, snap[7]):
+                g_.update(old)
+            model._packed_sig = None
+        torch.cuda.synchronize()
+        same_again, every_again = fingerprints()
+        assert same_again, "replicas differ after the no-exchange loop was undone: " + str([e.tolist() for e in every_again])
+        dp_stats = dict(dp_stats or {})
+        dp_stats.update(exchange_model(dp_stats, eager_dt / steps * 1e3, noex_dt / steps * 1e3, world))
         # ---- (3) the step as one hipGraph replay per rank, collectives inside.  LAST device work of the measurement, and fenced: a
         # capture that fails half-way can leave its forked streams in capture mode (ROCm 7.2), after which any use of the default stream
         # raises -- the eager numbers above must survive that, so everything from here on is inside one try, and the record is put
@@ -275,7 +320,7 @@ def run_train(a, world, rank, dev, wl, cpu_baseline_fn=None):
             if rank == 0 and isinstance(part, dict):
                 part.setdefault("config", {})["watchdog"] = "the run did not finish in time (a rank hung): the eager record as it stood"
                 print(json.dumps(part), flush=True)
-            os._exit(0 if isinstance(part, dict) or rank != 0 else 3)
+            os._exit(3)                       # (a fired watchdog is a failed run, whatever part of the record could be printed)
         dog = threading.Timer(int(os.environ.get("EFTS_BENCH_DP_TIMEOUT", "240")), fire)
         dog.daemon = True
         dog.start()

@@ -146,15 +146,6 @@ static int rc_check(const efts_resconv5_args* a, const char* who) {
     return 0;
 }
 
-// which kernel efts_resconv5 launches: 0 = default (the 8-wave ping-pong kernel), 1 = the same, explicitly, 2 = the one-wave-per-SIMD
-// kernel wherever it applies (bf16 planes, 5 taps, >= 2 K chunks; the 8-wave kernel elsewhere).  Process-wide; for A/B measurements and the bit-equality tests between the two.
-static int g_rc_kernel = 0;
-extern "C" int efts_resconv5_kernel(int32_t which) {
-    const int prev = g_rc_kernel;
-    if (which >= 0 && which <= 2) g_rc_kernel = which;
-    return prev;
-}
-
 extern "C" int efts_resconv5_multi(const efts_resconv5_args* a, int32_t count, void* stream) {
     if (!a) return efts_fail(EFTS_EINVAL, "efts_resconv5: null args");
     if (count < 1 || count > RC_MAXPROB) return efts_fail(EFTS_EINVAL, "efts_resconv5_multi: 1..%d layers per launch", RC_MAXPROB);
@@ -215,10 +206,11 @@ extern "C" int efts_resconv5_multi(const efts_resconv5_args* a, int32_t count, v
     }
 #endif
     // The one-wave-per-SIMD kernel with the generated main loop (efts_resconv4.h; bf16 planes, 5 taps) is launched on request only
-    // (efts_resconv5_kernel(2)): its main loop needs 8 % fewer cycles than the ping-pong kernel's (2 210 vs ~2 400 per full step), but on
+    // (efts_resconv5_args.kernel = 2): its main loop needs 8 % fewer cycles than the ping-pong kernel's (2 210 vs ~2 400 per full step), but on
     // MI355X both run at the clock the power budget leaves (1.4-1.5 GHz with every CU issuing MFMAs on random operands) and take the same
     // time -- measured in one process: forward 1.596 vs 1.561 ms, training step 3.80 vs 3.70 ms, the 8-wave kernel ahead (DESIGN.md 4a').
-    bool w4 = g_rc_kernel == 2 && a->split == 1 && k.nchunk >= 2;
+    if (!(a->kernel == 0 || a->kernel == 1 || a->kernel == 2)) return efts_fail(EFTS_EINVAL, "efts_resconv5: kernel must be 0 (the 8-wave kernel) or 2");
+    bool w4 = a->kernel == 2 && a->split == 1 && k.nchunk >= 2;
     for (int i = 0; i < count; ++i) w4 = w4 && k.pr[i].taps == 5;
     if (w4) {
         static bool attr4 = false;

@@ -92,7 +92,7 @@ class ResConv5Args(C.Structure):
         ("bias", vp), ("slope", f32), ("rowmask", vp),
         ("y_f32", vp), ("ldo", i64), ("y", vp), ("y_lo", vp), ("ldy", i64), ("y_split", i32),
         ("plan", C.POINTER(i32)), ("taps", i32), ("no_residual", i32), ("sign_bits", vp),
-        ("act_bwd_sign", vp), ("act_bwd_bias_part", vp), ("act_bwd_bias_rows", i32), ("act_bwd_slope", f32),
+        ("act_bwd_sign", vp), ("act_bwd_bias_part", vp), ("act_bwd_bias_rows", i32), ("act_bwd_slope", f32), ("kernel", i32),
     ]
 
 
@@ -112,7 +112,6 @@ _SIGS = {
     "efts_resconv5": (i32, [C.POINTER(ResConv5Args), vp]),
     "efts_resconv5_multi": (i32, [C.POINTER(ResConv5Args), i32, vp]),
     "efts_resconv5_plan": (i32, [i32, i32, i32, C.POINTER(i32), i32]),
-    "efts_resconv5_kernel": (i32, [i32]),
     "efts_resconv5_bias_rows": (i32, [i32, i32]),
     "efts_pack_weight": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "efts_row_masks": (i32, [vp, vp, vp, i32, i32, i32, vp]),

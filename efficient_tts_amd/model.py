@@ -162,7 +162,7 @@ class LaunchOptions:
     small_m_rows: int = 1024        # ... up to this many rows
 
     def tag(self) -> tuple:
-        return dataclasses.astuple(self)
+        return dataclasses.astuple(self) + (O.RC_KERNEL, O.GEMM_TILING)       # (the launch-level switches of ops.py change the launches too)
 
 
 class EfficientTTSCNN(torch.nn.Module):
@@ -186,6 +186,9 @@ class EfficientTTSCNN(torch.nn.Module):
         # LeakyReLU (every reference config) and ReLU (= slope 0) live in the epilogues of the contraction kernels; the other pointwise
         # torch.nn activations run as a separate elementwise launch behind the contraction (csrc/efts_act.hip)
         act_general = None
+        if nonlinear_activation == "ReLU" and set(nonlinear_activation_params) - {"inplace"}:
+            # the reference builds torch.nn.ReLU(**params) (efts_modules.py:32-35): anything but `inplace` is a TypeError there
+            raise TypeError(f"ReLU.__init__() got an unexpected keyword argument {sorted(set(nonlinear_activation_params) - {'inplace'})[0]!r}")
         if nonlinear_activation not in ("LeakyReLU", "ReLU") or set(nonlinear_activation_params) - {"negative_slope", "inplace"}:
             act_general = L.actfn(nonlinear_activation, dict(nonlinear_activation_params))
             if act_general is None:
@@ -681,8 +684,8 @@ class EfficientTTSCNN(torch.nn.Module):
         if self.training:
             # train() mode without gradients (a validation pass that forgot eval(), a probe): the reference applies its Dropouts here --
             # the duration predictor's 0.1 always (duration_predictor.py:61), ResConv1d's and the prenet's when dropout_rate > 0
-            # (efts_modules.py:38-47, efficient_tts.py:76-80).  Same counter-based masks as the fused training pass (one draw per
-            # train-mode pass: `dropout_calls` advances); the seeds are by-value launch arguments, so no graph
+            # (efts_modules.py:38-47, efficient_tts.py:76-80).  Same counter-based masks as the fused training pass would draw for the
+            # next step (`_forward_impl`: `dropout_calls` itself is left alone); the seeds are by-value launch arguments, so no graph
             return self._forward_impl(text, text_lengths, speech, speech_lengths)[0]
         if not self.graphs or torch.cuda.is_current_stream_capturing():
             return self._forward_impl(text, text_lengths, speech, speech_lengths)[0]
@@ -706,8 +709,16 @@ class EfficientTTSCNN(torch.nn.Module):
     def _forward_impl(self, text, text_lengths, speech, speech_lengths, keep: bool = False):
         prev = getattr(self, "_drop_now", None)
         if self.training:
-            self.dropout_calls = int(self.dropout_calls) + 1
-            conv, s0, s1 = self._dropout_seeds(self.dropout_calls)
+            # a gradient-free pass in train() mode (a probe, a validation pass that forgot eval()) does NOT advance `dropout_calls`: that counter
+            # sequences the masks of the optimisation steps (GraphedStep's step words, the trainer's --resume), and a resumed run must
+            # reproduce the uninterrupted one whatever was probed in between.  Probes draw the masks of the step that comes next, then of
+            # the ones behind it, from a counter of their own that restarts whenever a real step has moved the sequence on
+            base = int(self.dropout_calls)
+            if getattr(self, "_probe_base", None) != base:
+                object.__setattr__(self, "_probe_base", base)
+                object.__setattr__(self, "_probe_calls", 0)
+            conv, s0, s1 = self._dropout_seeds(base + 1 + self._probe_calls)
+            object.__setattr__(self, "_probe_calls", self._probe_calls + 1)
             conv_p = float(self.dropout_rate) if self.dropout_rate >= 1e-5 else 0.0
             object.__setattr__(self, "_drop_now", (conv_p, conv, float(self.duration_predictor.conv[0][3].p), (s0, s1)))
         else:

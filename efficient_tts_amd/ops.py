@@ -17,6 +17,9 @@ from . import lib as L
 # stream (torch's current stream) and (tag, start, end) is appended; tag = (taps, m, n).
 # Default `tiling` of efts_gemm launches (L.TILING_*): AUTO in the product; the equality tests between the kernels flip it
 GEMM_TILING = 0
+# `kernel` of every efts_resconv5 launch (include/efts_abi.h): 0 the 8-wave kernel (the product), 2 the one-wave-per-SIMD kernel where it applies.
+# Part of every graph tag (model.LaunchOptions.tag, train.switch_tag): a captured pass is valid for the kernel it was captured with
+RC_KERNEL = 0
 PROFILE = None
 # optional filter: only launches whose tag equals PROFILE_TAG are bracketed (keeps the host light)
 PROFILE_TAG = None
@@ -167,6 +170,7 @@ def _resconv5_fill(g, *, x: Plane, x_lo: Optional[Plane] = None, x_f32_ptr: Opti
                    act_bwd_sign_ptr: Optional[int] = None, act_bwd_slope: float = 0.0, act_bwd_bias_part: Optional[torch.Tensor] = None) -> None:
     if plan is not None:
         g.plan = plan
+    g.kernel = RC_KERNEL
     if act_bwd_sign_ptr is not None:                 # training backward: the activation backward of the layer below in this dgrad launch's epilogue
         g.act_bwd_sign, g.act_bwd_slope = act_bwd_sign_ptr, act_bwd_slope
         if act_bwd_bias_part is not None:

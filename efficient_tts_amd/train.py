@@ -59,7 +59,7 @@ _WGRAD_GROUP_WGS = 384       # workgroups of a grouped launch (0: two per CU).  
 def switch_tag() -> tuple:
     """every hook above, by value: part of the tag of a captured training step"""
     return (_WGRAD_TN_SPLITS, _SIGN_MIN_ROWS, _BIAS_PARTS, _RESCONV_FWD, _RESCONV_DGRAD, _WGRAD_WGS, _PACK_SPLIT, _NARROW_TN, _EARLY_PACKS,
-            _WGRAD_GROUP, _WGRAD_GROUP_WGS, _FUSE_ACT_BWD)
+            _WGRAD_GROUP, _WGRAD_GROUP_WGS, _FUSE_ACT_BWD, O.RC_KERNEL)
 
 
 class _TPlane(Plane):
@@ -257,16 +257,20 @@ class TrainEngine:
         L.check(lib.efts_wgrad_reduce_grouped(arr, n, part.data_ptr(), rows, cout, cin, taps, split, _WGRAD_GROUP_WGS, O._stream()),
                 "efts_wgrad_reduce_grouped")
 
+    @staticmethod
+    def _narrow_ok(dz_split: int, x_split: int, cout: int, cin: int, ldz: int, ldx: int) -> bool:
+        """THE applicability test of _wgrad_narrow (callers that allocate differently for the two paths ask this, not a copy of it)"""
+        return bool(_NARROW_TN and _WGRAD_TN_SPLITS > 0 and dz_split == 1 and x_split == 1 and max(cout, cin) % 128 == 0 and min(cout, cin) <= 128
+                    and ldz >= max(cout, 128) * 2 and ldx >= max(cin, 128) * 2)
+
     def _wgrad_narrow(self, ws, tag, dz_p: Plane, x_p: Plane, cout, cin, rows, out_dw) -> bool:
         """weight gradient of a Linear with an 80-channel side (mel head 512 -> 80, prenet 80 -> 512) on the direct kernel: bf16 planes are
         128 columns wide (two 64-channel chunks, zeros beyond the 80th), so the contraction runs on the padded 128 and the result's first
         80 rows / columns are copied out -- instead of two transposed operand copies (efts_pack_t over the mel-length stream) + split-K
         efts_gemm + reduction.  False: not applicable (bf16x3 planes are 96 wide), the caller takes the transposed-plane path."""
-        if not (_NARROW_TN and _WGRAD_TN_SPLITS > 0 and dz_p.split == 1 and x_p.split == 1 and max(cout, cin) % 128 == 0 and min(cout, cin) <= 128):
+        if not self._narrow_ok(dz_p.split, x_p.split, cout, cin, dz_p.ld, x_p.ld):
             return False
         co_p, ci_p = max(cout, 128), max(cin, 128)
-        if dz_p.ld < co_p * 2 or x_p.ld < ci_p * 2:
-            return False
         scratch = ws.tensor(f"B{tag}_dw_pad", (co_p, ci_p))
         self._wgrad_tn(ws, dz_p, x_p, co_p, ci_p, rows, None, None, scratch, None, taps=1, splits=32)     # 8 tiles x 32 row splits
         out_dw.copy_(scratch[:cout, :cin])
@@ -742,7 +746,7 @@ class TrainEngine:
         Gm = self._stack_bwd(ws, "me", "mel_encoder", rs2, G_me, me_saved, gap2.data_ptr(), gap2.data_ptr(), None)
         if self.mark is not None:
             self.mark("bwd_mel_encoder_done")
-        narrow = _NARROW_TN and _WGRAD_TN_SPLITS > 0 and split == 1 and odim <= 128 and C % 128 == 0 and mel_in.ld >= 256
+        narrow = self._narrow_ok(split, mel_in.split, C, odim, max(C, 128) * 2, mel_in.ld)        # (the dZ plane allocated below is C wide)
         dzp_f = None if narrow else ws.f32("Bpre_dz", rs2, C)
         dzp_p = ws.plane("Bpre_dzp", rs2, C, split) if narrow else None
         if pre_z is not None:

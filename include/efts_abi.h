@@ -203,6 +203,10 @@ typedef struct efts_resconv5_args {
     float* act_bwd_bias_part;
     int32_t act_bwd_bias_rows;
     float act_bwd_slope;
+    int32_t kernel;      /* which kernel runs the launch (layers[0].kernel decides for a grouped launch).  0: the 8-wave ping-pong kernel -- the
+                          * product path.  2: the one-wave-per-SIMD kernel with the generated main loop wherever it applies (bf16 planes, 5 taps,
+                          * >= 2 K chunks, no fused activation backward; the 8-wave kernel elsewhere): same results bit for bit, same time on
+                          * MI355X (DESIGN.md 4a'), kept for the bit-equality tests between the two and for A/B measurements */
 } efts_resconv5_args;
 
 int efts_resconv5(const efts_resconv5_args* a, void* stream);
@@ -250,13 +254,6 @@ int efts_frame_linear(const efts_frame_linear_args* a, void* stream);
  * Returns the number of int32 written, or a negative EFTS_E* code.  No device work. */
 #define EFTS_RC_PLAN_INTS 42
 int efts_resconv5_plan(int32_t m, int32_t n, int32_t cus, int32_t* plan, int32_t cap);
-
-/* efts_resconv5 has two kernels with the same tiles, plans and results: the 8-wave ping-pong kernel (any plane format, 3 or 5 taps) and, for
- * bf16 planes (split 1) with 5 taps and >= 2 K chunks, the one-wave-per-SIMD kernel with the hand-scheduled main loop (round 4).
- * which = 0: the default (the 8-wave kernel: measured equal or ahead in situ, DESIGN.md 4a'); 1: the 8-wave kernel, explicitly; 2: the
- * one-wave-per-SIMD kernel wherever it applies (the 8-wave kernel elsewhere);
- * any other value only queries.  Process-wide; returns the previous setting.  For A/B measurements and the equality tests between the two. */
-int efts_resconv5_kernel(int32_t which);
 
 /* ------------------------------------------------------------------------------------
  * Parameter preparation.

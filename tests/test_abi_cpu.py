@@ -41,7 +41,7 @@ def test_args_layouts_match_header():
     import subprocess, tempfile, ctypes
     structs = {
         "efts_gemm_args": (L.GemmArgs, ["out_bf16_lo", "tiling", "sign_mask", "soft_index", "key_len", "query_len", "drop_p", "drop_seed"]),
-        "efts_resconv5_args": (L.ResConv5Args, ["x", "x_lo", "x_f32", "w", "split", "rowmask", "y_f32", "y", "y_lo", "y_split", "plan", "taps", "no_residual", "sign_bits", "act_bwd_sign", "act_bwd_bias_part", "act_bwd_bias_rows", "act_bwd_slope"]),
+        "efts_resconv5_args": (L.ResConv5Args, ["x", "x_lo", "x_f32", "w", "split", "rowmask", "y_f32", "y", "y_lo", "y_split", "plan", "taps", "no_residual", "sign_bits", "act_bwd_sign", "act_bwd_bias_part", "act_bwd_bias_rows", "act_bwd_slope", "kernel"]),
         "efts_frame_linear_args": (L.FrameLinearArgs, ["x", "w", "bias", "act", "B", "n", "y_f32", "y", "y_lo", "ldy", "y_split", "max_workgroups"]),
         "efts_wgrad_item": (L.WgradItem, ["dz_plane", "ldz", "x_plane", "ldx", "v", "g", "dw_or_dv", "dg", "bias_part", "dbias", "nparts", "reserved"]),
         "efts_expand_args": (L.ExpandArgs, ["e", "text_len", "mel_len", "sigma", "v", "ldv", "B", "n", "alpha_out", "y_f32", "ldo", "y", "y_lo", "ldy", "y_split"]),
@@ -135,6 +135,9 @@ def test_ctor_option_space_is_decided_on_the_host():
     assert make().act_general is None and make().slope == pytest.approx(0.1)
     assert make(nonlinear_activation="LeakyReLU", nonlinear_activation_params={"negative_slope": 0.3, "inplace": True}).slope == pytest.approx(0.3)
     assert make(nonlinear_activation="ReLU", nonlinear_activation_params={}).slope == 0.0
+    with pytest.raises(TypeError):                       # the reference's torch.nn.ReLU(**params) raises on anything but `inplace`
+        make(nonlinear_activation="ReLU", nonlinear_activation_params={"negative_slope": 0.1})
+    assert make(nonlinear_activation="ReLU", nonlinear_activation_params={"inplace": True}).slope == 0.0
     assert make(nonlinear_activation="GELU", nonlinear_activation_params={}).act_general == (6, 0.0, 0.0)
     assert make(nonlinear_activation="GELU", nonlinear_activation_params={"approximate": "tanh"}).act_general == (7, 0.0, 0.0)
     assert make(nonlinear_activation="ELU", nonlinear_activation_params={"alpha": 0.5}).act_general == (3, 0.5, 0.0)

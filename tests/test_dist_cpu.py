@@ -136,6 +136,23 @@ def test_dp_selfcheck_fingerprint_and_rccl_log_parsing(tmp_path, monkeypatch):
     assert _rccl_log_lines() is None
 
 
+def test_dp_record_states_its_own_scaling_efficiency():
+    """round 5: the arithmetic of the data-parallel record (bench_train.exchange_model): efficiency = step without the exchange / step with
+    it, and per bucket the all-reduce bus bandwidth 2 (N - 1) / N * bytes / time against one xGMI link and against all seven"""
+    from efficient_tts_amd.bench_train import exchange_model, XGMI_LINKS, XGMI_LINK_GBPS
+    stats = dict(bucket_mb=[36.4, 25.2, 20.8], bucket_ms=[0.40, 0.30, 0.25], exposed_ms=0.12)
+    rec = exchange_model(stats, with_ms=3.60, without_ms=3.42, world=8)
+    assert abs(rec["efficiency"] - 0.95) < 1e-9 and rec["step_ms_with_exchange"] == 3.60 and rec["step_ms_no_exchange"] == 3.42
+    want = [1.75 * 36.4 / 0.40, 1.75 * 25.2 / 0.30, 1.75 * 20.8 / 0.25]
+    assert all(abs(a - b) < 1e-9 for a, b in zip(rec["bucket_busbw_gbps"], want))
+    assert abs(rec["bucket_busbw_frac_of_one_link"][0] - want[0] / XGMI_LINK_GBPS) < 1e-12
+    assert abs(rec["bucket_busbw_frac_of_all_links"][2] - want[2] / (XGMI_LINKS * XGMI_LINK_GBPS)) < 1e-12
+    assert rec["xgmi"]["all_links_gbps"] == XGMI_LINKS * XGMI_LINK_GBPS
+    one = exchange_model({}, 3.0, 3.0, 1)                                   # a one-rank group: no bus figures, efficiency 1
+    assert one["efficiency"] == 1.0 and "bucket_busbw_gbps" not in one
+    assert exchange_model(dict(bucket_mb=[1.0], bucket_ms=[0.0]), 1.0, 1.0, 2)["bucket_busbw_gbps"] == [None]
+
+
 def test_bench_launches_its_own_ranks_and_refuses_fewer():
     """`python bench.py --gpus N` without a launcher must start N ranks itself (it used to run ONE rank silently and
     print n_gpus 1).  The `rendezvous` workload is the launch path only: every rank joins the group (gloo here, nccl on a GPU
@@ -167,11 +184,11 @@ def test_bench_watchdog_prints_the_line_and_ends_the_process():
     code = ("import sys, time; sys.path.insert(0, %r); import bench; res = dict(metric='m', value=1.0)\n"
             "bench._watchdog(1, 0, res, 'train32'); time.sleep(60); print('not reached')" % root)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and "not reached" not in out.stdout, out.stderr[-1000:]
+    assert out.returncode == 3 and "not reached" not in out.stdout, out.stderr[-1000:]      # (a fired watchdog is a failed run: non-zero)
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["value"] == 1.0 and "abandoned after 1 s" in rec["train32"]["error"]
     quiet = subprocess.run([sys.executable, "-c", code.replace("(1, 0, res", "(1, 1, res")], capture_output=True, text=True, timeout=300)
-    assert quiet.returncode == 0 and quiet.stdout.strip() == ""           # other ranks: no line, same exit
+    assert quiet.returncode == 3 and quiet.stdout.strip() == ""           # other ranks: no line, same exit
     code2 = code.replace("time.sleep(60)", "t = bench._watchdog(1, 0, res, 'x'); t.cancel(); [w.cancel() for w in __import__('threading').enumerate() if hasattr(w, 'cancel')]; time.sleep(2)")
     kept = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=300)
     assert "not reached" in kept.stdout                                   # a cancelled watchdog does nothing

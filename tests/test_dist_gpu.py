@@ -181,6 +181,10 @@ def test_bench_dp_record_two_ranks():
     dp = rec["dp"]
     assert dp["ranks"] == 2 and dp["selfcheck"]["replicas_bit_identical"] and len(dp["bucket_ms"]) == 3 and abs(sum(dp["bucket_mb"]) - 82.35) < 0.01
     assert rec["eager_ms_per_step"] > 0 and rec["value"] > 0
+    # round 5: the record states its own scaling efficiency (the same steps with the exchange switched off, state restored afterwards)
+    assert dp["step_ms_no_exchange"] > 0 and abs(dp["step_ms_with_exchange"] - rec["eager_ms_per_step"]) < 1e-6
+    assert abs(dp["efficiency"] - dp["step_ms_no_exchange"] / dp["step_ms_with_exchange"]) < 1e-9 and 0.0 < dp["efficiency"] < 1.5      # (gloo through the host on one shared GPU: a few per cent)
+    assert len(dp["bucket_busbw_gbps"]) == 3 and all(b > 0 for b in dp["bucket_busbw_gbps"]) and dp["xgmi"]["links_per_gpu"] == 7
     if rec["graph_ms_per_step"] is None:                      # (gloo: the capture fails on every rank alike)
         assert "eager" in rec["config"]["step_issue"]
     else:
@@ -207,3 +211,6 @@ def test_bench_two_ranks_end_to_end():
     tr = rec["train32"]
     assert tr["n_gpus"] == 2 and tr["config"]["parallelism"] == "dp2" and tr["dp"]["ranks"] == 2 and tr["dp"]["selfcheck"]["replicas_bit_identical"]
     assert len(tr["dp"]["bucket_ms"]) == 3 and tr["parity_mode"]["ms_per_step"] > 0
+    # the collective path lifted to the top level of the N > 1 line
+    assert rec["dp_value"] == tr["value"] and rec["dp_ms_per_step"] == tr["ms_per_step"] and rec["dp_efficiency"] == tr["dp"]["efficiency"] > 0
+    assert rec["dp_exposed_ms"] == tr["dp"]["exposed_ms"] and "exchange" in rec["dp_note"]

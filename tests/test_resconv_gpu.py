@@ -11,13 +11,13 @@ C = 512
 
 @pytest.fixture(autouse=True, params=["8-wave", "one-wave-per-SIMD"])
 def rc_kernel(request):
-    """every case of this file runs on both kernels of efts_resconv5 (include/efts_abi.h efts_resconv5_kernel): the 8-wave ping-pong
+    """every case of this file runs on both kernels of efts_resconv5 (include/efts_abi.h efts_resconv5_args.kernel): the 8-wave ping-pong
     kernel (the default) and the one-wave-per-SIMD kernel with the generated main loop (csrc/efts_resconv4.h), which takes over where it
     applies (bf16 planes, 5 taps) -- same tiles, plans and, bit for bit, the same results"""
-    from efficient_tts_amd import lib as L
-    prev = L.load().efts_resconv5_kernel(1 if request.param == "8-wave" else 2)
+    from efficient_tts_amd import ops as P
+    prev, P.RC_KERNEL = P.RC_KERNEL, (0 if request.param == "8-wave" else 2)
     yield request.param
-    L.load().efts_resconv5_kernel(prev)
+    P.RC_KERNEL = prev
 
 
 def _dev():

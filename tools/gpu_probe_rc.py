@@ -1,11 +1,11 @@
 """efts_resconv5 (persistent 8-wave k5 residual layer on hi/lo planes) vs efts_gemm: bit equality and time.
-  PSHAPES: "BxT,..."; PSPLIT: 1 | 2; RCK: kernel choice (efts_resconv5_kernel); PPLAN: explicit tile schedule, classes of tile heights in half units, e.g. "7,6|6,7" """
+  PSHAPES: "BxT,..."; PSPLIT: 1 | 2; RCK: kernel choice (efts_resconv5_args.kernel); PPLAN: explicit tile schedule, classes of tile heights in half units, e.g. "7,6|6,7" """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from efficient_tts_amd import lib as L, ops as P
 dev = torch.device("cuda:0"); L.load(); L.require_device()
-L.load().efts_resconv5_kernel(int(os.environ.get("RCK", "0")))     # RCK: 0 / 1 the 8-wave kernel (default), 2 the one-wave-per-SIMD kernel where it applies
+P.RC_KERNEL = int(os.environ.get("RCK", "0"))     # RCK: 0 / 1 the 8-wave kernel (default), 2 the one-wave-per-SIMD kernel where it applies
 C = 512
 def bf16_split(x):
     hi = x.to(torch.bfloat16); lo = (x - hi.float()).to(torch.bfloat16)

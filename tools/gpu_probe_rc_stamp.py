@@ -9,7 +9,7 @@ stamp = torch.zeros(64, 1024, dtype=torch.int64, device=dev)
 os.environ["EFTS_RC_STAMP"] = hex(stamp.data_ptr())
 from efficient_tts_amd import lib as L, ops as P
 L.load(); L.require_device()
-L.load().efts_resconv5_kernel(int(os.environ.get("RCK", "0")))     # RCK: 0 / 1 the 8-wave kernel (default), 2 the one-wave-per-SIMD kernel where it applies
+P.RC_KERNEL = int(os.environ.get("RCK", "0"))     # RCK: 0 / 1 the 8-wave kernel (default), 2 the one-wave-per-SIMD kernel where it applies
 C = 512
 B, T = int(os.environ.get("PB", 64)), int(os.environ.get("PT", 800))
 split = int(os.environ.get("PSPLIT", 1))
