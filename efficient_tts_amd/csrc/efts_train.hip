@@ -826,13 +826,12 @@ extern "C" int efts_pack_t(const float* x, int64_t ldx, void* plane, int64_t ld_
     return efts_check_launch("efts_pack_t");
 }
 
-extern "C" int efts_wgrad_reduce_bias(const float* part, int32_t nsplit, const float* v, const float* g, float* dw_or_dv, float* dg, int32_t cout,
-                                      int32_t cin, int32_t taps, const float* bias_part, int32_t nparts, float* dbias, void* stream) {
+extern "C" int efts_wgrad_reduce(const float* part, int32_t nsplit, const float* v, const float* g, float* dw_or_dv, float* dg, int32_t cout,
+                                 int32_t cin, int32_t taps, void* stream) {
     if (!part || !dw_or_dv || (g && (!v || !dg))) return efts_fail(EFTS_EINVAL, "efts_wgrad_reduce: null pointer");
-    if (bias_part && (!dbias || nparts < 1)) return efts_fail(EFTS_EINVAL, "efts_wgrad_reduce_bias: bias_part needs dbias and nparts >= 1");
     if ((size_t)cin * taps * 4 > 60000) return efts_fail(EFTS_ESHAPE, "efts_wgrad_reduce: cin*taps too large for LDS");
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cout), dim3(256), (size_t)cin * taps * sizeof(float), ST, part, nsplit, v, g, dw_or_dv, dg, cout, cin, taps,
-                       bias_part, nparts, dbias);
+                       (const float*)nullptr, 0, (float*)nullptr);
     return efts_check_launch("efts_wgrad_reduce");
 }
 
@@ -922,10 +921,6 @@ extern "C" int efts_wgrad_reduce_grouped(const efts_wgrad_item* items, int32_t c
     return efts_check_launch("efts_wgrad_reduce_grouped");
 }
 
-extern "C" int efts_wgrad_reduce(const float* part, int32_t nsplit, const float* v, const float* g, float* dw_or_dv, float* dg, int32_t cout,
-                                 int32_t cin, int32_t taps, void* stream) {
-    return efts_wgrad_reduce_bias(part, nsplit, v, g, dw_or_dv, dg, cout, cin, taps, nullptr, 0, nullptr, stream);
-}
 
 extern "C" int efts_layernorm_bwd(const float* x, const float* gamma, const float* beta, float eps, const float* dy, const float* ddur,
                                   const float* w, const float* rowmask, float* dz, void* plane, int64_t ld_plane, int32_t split,

@@ -2,7 +2,7 @@
 // Linears with 128 | cout, 64 | cin: TAPS = 3, 1) straight from the ROW-MAJOR operand planes the forward / dgrad
 // contractions already use (no transposed copies):
 //
-//   part[k][s][co][ci] = sum_{t in split s} dZ[t][co] * X[t + k - pad][ci]       (k = 0..taps-1, pad = (taps - 1) / 2)
+//   part[segment][k][co][ci] = sum_{t in segment} dZ[t][co] * X[t + k - pad][ci]       (k = 0..taps-1, pad = (taps - 1) / 2)
 //
 // Replaces, for the (512, 512, 5) layers, efts_pack_t (one transposed plane of dZ + FIVE shifted
 // transposed planes of X per layer, 183 MB of HBM traffic) + the split-K efts_gemm.
@@ -187,39 +187,6 @@ __device__ __forceinline__ void wg_run(char* smem, unsigned lds0, const char* __
 
 }
 
-// grid: x = (cout/128) * (cin/64) tiles, y = nsplit; split s covers steps [s*steps_per_split, ...) of ROWS rows each.
-template <int SPLIT, int TAPS>
-__global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const char* __restrict__ dz, long ldz, const char* __restrict__ x, long ldx,
-                                                           float* __restrict__ part, int steps_per_split, int steps_total, int cout, int cin, int nsplit) {
-    using C = WgCfg<SPLIT>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem));
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ntn = cin >> 6;
-    const int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
-    const int sp = blockIdx.y;
-    int nsteps = steps_total - sp * steps_per_split;             // the last splits may be short or empty (they then write zeros)
-    nsteps = nsteps < 0 ? 0 : (nsteps > steps_per_split ? steps_per_split : nsteps);
-    f32x16 acc[TAPS][2];
-    wg_run<SPLIT, TAPS>(smem, lds0, dz, ldz, x, ldx, mt, nt, sp * steps_per_split * C::ROWS, nsteps, acc);
-
-    // ---- partials: C/D layout col n = lane & 31 (ci), row m = (r&3) + 8*(r>>2) + 4*(lane>>5) (co)
-    const int ci = nt * 64 + wn * 32 + (lane & 31);
-#pragma unroll
-    for (int k = 0; k < TAPS; ++k) {
-        float* o = part + ((long)(k * nsplit + sp) * cout) * cin;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = mt * 128 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                o[(long)co * cin + ci] = acc[k][i][r];
-            }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Grouped form (round 5): the weight gradients of ALL layers of a residual stack in one launch, the work dealt out
 // stream-K style.  The (item, tile, step) space of an XCD -- the tiles T = 8 j + xcd of the launch, 401 steps each at
@@ -279,33 +246,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_sk_kernel(WgSkArgs p) {
 }  // namespace efts
 
 using namespace efts;
-
-extern "C" int efts_wgrad_tn(const void* dz_plane, int64_t ldz, const void* x_plane, int64_t ldx, float* part, int32_t rows,
-                             int32_t cout, int32_t cin, int32_t taps, int32_t nsplit, int32_t split, void* stream) {
-    if (!dz_plane || !x_plane || !part) return efts_fail(EFTS_EINVAL, "efts_wgrad_tn: null pointer");
-    if (!(taps == 1 || taps == 3 || taps == 5) || !(split == 1 || split == 2))
-        return efts_fail(EFTS_EINVAL, "efts_wgrad_tn: implemented for taps 1, 3, 5 and split 1 or 2");
-    if (rows <= 0 || nsplit <= 0 || cout <= 0 || cin <= 0 || (cout & 127) || (cin & 63))
-        return efts_fail(EFTS_ESHAPE, "efts_wgrad_tn: cout must be a multiple of 128, cin of 64");
-    if ((ldz & 15) || (ldx & 15) || ldz < (int64_t)cout * 2 * split || ldx < (int64_t)cin * 2 * split || ldz > (1 << 20) || ldx > (1 << 20) ||
-        ((uintptr_t)dz_plane & 15) || ((uintptr_t)x_plane & 15))
-        return efts_fail(EFTS_EALIGN, "efts_wgrad_tn: plane strides / alignment");
-    const int rps = split == 1 ? WgCfg<1>::ROWS : WgCfg<2>::ROWS;
-    const int steps = (rows + rps - 1) / rps;                // rows past `rows` (< 70 of them) are zero guard rows
-    const int per = (steps + nsplit - 1) / nsplit;
-    dim3 grid((cout / 128) * (cin / 64), nsplit);
-#define EFTS_WGTN(S, T)                                                                                                                  \
-    do {                                                                                                                                 \
-        static bool attr = false;                                                                                                        \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<S, T>, hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<S>::LDS); attr = true; } \
-        hipLaunchKernelGGL((wgrad_tn_kernel<S, T>), grid, dim3(256), WgCfg<S>::LDS, (hipStream_t)stream, (const char*)dz_plane, (long)ldz,  \
-                           (const char*)x_plane, (long)ldx, part, per, steps, cout, cin, nsplit);                                        \
-    } while (0)
-    if (split == 1) { if (taps == 5) EFTS_WGTN(1, 5); else if (taps == 3) EFTS_WGTN(1, 3); else EFTS_WGTN(1, 1); }
-    else { if (taps == 5) EFTS_WGTN(2, 5); else if (taps == 3) EFTS_WGTN(2, 3); else EFTS_WGTN(2, 1); }
-#undef EFTS_WGTN
-    return efts_check_launch("efts_wgrad_tn");
-}
 
 // geometry shared by the grouped launch and its reduction (efts_train.hip): steps per tile, lists, steps per workgroup, slabs per workgroup
 int efts_wgrad_sk_geometry(int count, int rows, int cout, int cin, int split, int workgroups, efts_wgrad_sk_geom* gm) {

@@ -144,8 +144,6 @@ _SIGS = {
     "efts_act_grad": (i32, [vp, vp, vp, i32, f32, f32, vp, vp, i64, i32, vp, i32, i32, f32, C.c_uint32, vp]),
     "efts_pack_t": (i32, [vp, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, vp]),
     "efts_wgrad_reduce": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
-    "efts_wgrad_reduce_bias": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp, vp]),
-    "efts_wgrad_tn": (i32, [vp, i64, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp]),
     "efts_wgrad_grouped_part_bytes": (i64, [i32, i32, i32, i32, i32, i32, i32]),
     "efts_wgrad_tn_grouped": (i32, [C.POINTER(WgradItem), i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "efts_wgrad_reduce_grouped": (i32, [C.POINTER(WgradItem), i32, vp, i32, i32, i32, i32, i32, i32, vp]),

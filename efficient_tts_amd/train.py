@@ -26,8 +26,8 @@ def _ptr(t):
 # Test / A-B hooks of the training pass (module-level: bench.py --train-set NAME=INT, tests).  `switch_tag()` is what a captured step
 # (step_graph.GraphedStep) is valid for.  Finished A/Bs of earlier rounds are no longer switches: the direct wgrad for taps 1 / 3
 # (was _WGRAD_TN_SMALL) and the prenet through efts_frame_linear (was _FRAME_PRENET) are simply the code.
-_WGRAD_TN_SPLITS = 8         # K-splits of the direct (row-major) wgrad; 0 = everything through the transposed planes + split-K efts_gemm (the path the
-                             # 80-channel layers always take: tests compare the two)
+_WGRAD_TN_SPLITS = 8         # > 0: weight gradients on the direct (row-major, stream-K) kernel wherever its tiles fit; 0 = everything through the transposed
+                             # planes + split-K efts_gemm (the path odd shapes always take: tests compare the two)
 _SIGN_MIN_ROWS = 16384       # row spaces from here on: the forward convolutions of the stacks write the activation's sign words
                              # (efts_gemm `sign_mask`) and efts_act_bwd reads those instead of y and x in fp32 (14 -> 6 B per element);
                              # shorter ones (the text side) keep the narrow tiling, which does not write them.  0 = never
@@ -50,8 +50,6 @@ _EARLY_PACKS = 1             # alignment backward: the operand copies that depen
 
 _FUSE_ACT_BWD = 1            # stacks whose dgrad runs on efts_resconv5: the activation backward of layer l - 1 in the epilogue of layer l's dgrad launch
                              # (csrc/efts_resconv_bwd.hip) instead of an efts_act_bwd launch of its own (0: separate launches; tests compare)
-_WGRAD_GROUP = 1             # the direct weight gradients of a residual stack in ONE stream-K launch + ONE reduction at the end of the stack's backward
-                             # (efts_wgrad_tn_grouped; 0: one efts_wgrad_tn + efts_wgrad_reduce_bias per layer, 8 K-splits each: tests compare)
 _WGRAD_GROUP_WGS = 384       # workgroups of a grouped launch (0: two per CU).  Swept 256..512 on the graphed B = 32 step: 3.27-3.32 ms at 384 against 3.33-3.34 at 512,
                              # 3.28-3.34 at 256 (per-layer launches: 3.48-3.50); the launch is bound by the chip, not by its busiest CU
 
@@ -59,7 +57,7 @@ _WGRAD_GROUP_WGS = 384       # workgroups of a grouped launch (0: two per CU).  
 def switch_tag() -> tuple:
     """every hook above, by value: part of the tag of a captured training step"""
     return (_WGRAD_TN_SPLITS, _SIGN_MIN_ROWS, _BIAS_PARTS, _RESCONV_FWD, _RESCONV_DGRAD, _WGRAD_WGS, _PACK_SPLIT, _NARROW_TN, _EARLY_PACKS,
-            _WGRAD_GROUP, _WGRAD_GROUP_WGS, _FUSE_ACT_BWD, O.RC_KERNEL)
+            _WGRAD_GROUP_WGS, _FUSE_ACT_BWD, O.RC_KERNEL)
 
 
 class _TPlane(Plane):
@@ -194,11 +192,17 @@ class TrainEngine:
         """the model's base seed mixed with the data-parallel rank"""
         return self.m._dropout_base()
 
-    def _wgrad_any(self, ws, dz_f_ptr, dz_p: Optional[Plane], x_f_ptr, x_p: Optional[Plane], cout, cin, taps, rows, out_dw):
-        """un-normed weights: the direct kernel when both operand planes exist in one format and the shape fits its tiles"""
+    def _wgrad_any(self, ws, dz_f_ptr, dz_p: Optional[Plane], x_f_ptr, x_p: Optional[Plane], cout, cin, taps, rows, out_dw, defer: Optional[list] = None):
+        """un-normed weights: the direct kernel when both operand planes exist in one format and the shape fits its tiles.
+        defer: a list that collects the direct items of equally shaped layers for ONE grouped launch (the caller passes it to
+        _wgrad_group once the operand planes of all of them are final and still intact)"""
         if (_WGRAD_TN_SPLITS > 0 and dz_p is not None and x_p is not None and dz_p.split == x_p.split
                 and cout % 128 == 0 and cin % 64 == 0 and taps in (1, 3, 5)):
-            self._wgrad_tn(ws, dz_p, x_p, cout, cin, rows, None, None, out_dw, None, taps=taps)
+            item = (dz_p, x_p, None, None, out_dw, None, None, None)
+            if defer is not None:
+                defer.append(item)
+            else:
+                self._wgrad_group(ws, [item], cout, cin, rows, taps, dz_p.split)
         else:
             self._wgrad(ws, dz_f_ptr, cout, x_f_ptr, cin, cin, taps, rows, None, None, out_dw, None)
 
@@ -225,23 +229,14 @@ class TrainEngine:
         L.check(_lib().efts_wgrad_reduce(part.data_ptr(), S, _ptr(v), _ptr(g), out_dw.data_ptr(), _ptr(out_dg), cout, cin, taps,
                                          O._stream()), "efts_wgrad_reduce")
 
-    def _wgrad_tn(self, ws, dz_p: Plane, x_p: Plane, cout, cin, rows, v, g, out_dw, out_dg, bias_part=None, dbias=None, taps: int = 5,
-                  splits: Optional[int] = None):
-        """wgrad of a k5 / k3 convolution or a Linear (taps 5 / 3 / 1) straight from the row-major bf16 planes
-        (csrc/efts_wgrad.hip): no transposed copies.
-        bias_part: the [row blocks][cout] column sums efts_act_bwd left; the reduction adds them into dbias"""
-        S = _WGRAD_TN_SPLITS if splits is None else splits
-        part = ws.get(("part", self._ws_tag, taps, S, cout, cin), lambda: torch.empty(taps, S, cout, cin, device=self.dev))
-        L.check(_lib().efts_wgrad_tn(dz_p.ptr, dz_p.ld, x_p.ptr, x_p.ld, part.data_ptr(), rows, cout, cin, taps, S, dz_p.split, O._stream()),
-                "efts_wgrad_tn")
-        L.check(_lib().efts_wgrad_reduce_bias(part.data_ptr(), S, _ptr(v), _ptr(g), out_dw.data_ptr(), _ptr(out_dg), cout, cin, taps,
-                                              _ptr(bias_part), 0 if bias_part is None else bias_part.shape[0], _ptr(dbias), O._stream()),
-                "efts_wgrad_reduce_bias")
-
     def _wgrad_group(self, ws, items, cout, cin, rows, taps: int, split: int):
         """the direct weight gradients of several layers of one stack (same shape, same row space) as ONE stream-K launch and ONE
         reduction (csrc/efts_wgrad.hip `wgrad_sk_kernel`, csrc/efts_train.hip `wgrad_reduce_sk_kernel`).
-        items: (dz_p, x_p, v, g, out_dw, out_dg, bias_part, dbias) per layer"""
+        items: (dz_p, x_p, v, g, out_dw, out_dg, bias_part, dbias) per layer (more than the library takes per launch: several launches)"""
+        if len(items) > L.WGRAD_MAX_ITEMS:
+            for i in range(0, len(items), L.WGRAD_MAX_ITEMS):
+                self._wgrad_group(ws, items[i:i + L.WGRAD_MAX_ITEMS], cout, cin, rows, taps, split)
+            return
         lib = _lib()
         n = len(items)
         arr = (L.WgradItem * n)()
@@ -272,7 +267,7 @@ class TrainEngine:
             return False
         co_p, ci_p = max(cout, 128), max(cin, 128)
         scratch = ws.tensor(f"B{tag}_dw_pad", (co_p, ci_p))
-        self._wgrad_tn(ws, dz_p, x_p, co_p, ci_p, rows, None, None, scratch, None, taps=1, splits=32)     # 8 tiles x 32 row splits
+        self._wgrad_group(ws, [(dz_p, x_p, None, None, scratch, None, None, None)], co_p, ci_p, rows, 1, 1)     # 8 tiles, stream-K over the rows
         out_dw.copy_(scratch[:cout, :cin])
         return True
 
@@ -329,15 +324,14 @@ class TrainEngine:
         m, C = self.m, self.m.n_channels
         layers = getattr(m, blk).layers
         group = []                                               # (grouped direct wgrads: every layer keeps its dZ plane and bias sums until the stack is through)
-        grouped = _WGRAD_GROUP and _WGRAD_TN_SPLITS > 0 and len(layers) <= L.WGRAD_MAX_ITEMS
         on_rc = bool((_RESCONV_DGRAD if _RESCONV_DGRAD >= 0 else (1 if m.split == 1 else 3)) & dict(dec=1, me=2, te=0)[tag]) and m._on_resconv(rs)
         fused = None                                             # (dZ plane, bias sums) of layer i the dgrad launch of layer i + 1 has already written
         for i in reversed(range(len(layers))):
             x_f, y_f, x_pl, sg, dp, dseed = saved[i]
             conv = layers[i].conv[0]
             pre = f"{blk}.layers.{i}.conv.0."
-            direct = _WGRAD_TN_SPLITS > 0 and C % 128 == 0 and x_pl.split == m.split and m.k_size <= 5     # (efts_wgrad_tn: taps 1 / 3 / 5)
-            keep = "" if not (direct and grouped) else str(i)
+            direct = _WGRAD_TN_SPLITS > 0 and C % 128 == 0 and x_pl.split == m.split and m.k_size <= 5     # (efts_wgrad_tn_grouped: taps 1 / 3 / 5)
+            keep = str(i) if direct else ""
             if fused is not None:
                 dz_p, bp = fused
                 dz_f = None
@@ -360,10 +354,8 @@ class TrainEngine:
             wn = hasattr(conv, "weight_g")
             v_, g_ = (conv.weight_v.detach(), conv.weight_g.detach()) if wn else (None, None)
             dw_, dg_ = (self.g[pre + "weight_v"], self.g[pre + "weight_g"]) if wn else (self.g[pre + "weight"], None)
-            if direct and grouped:
+            if direct:
                 group.append((dz_p, x_pl, v_, g_, dw_, dg_, bp, self.g[pre + "bias"]))
-            elif direct:
-                self._wgrad_tn(ws, dz_p, x_pl, C, C, rs.rows, v_, g_, dw_, dg_, bias_part=bp, dbias=self.g[pre + "bias"], taps=m.k_size)
             else:
                 self._wgrad(ws, dz_f.ptr, C, x_f.ptr, C, C, m.k_size, rs.rows, v_, g_, dw_, dg_)
             wt = self.wt[f"{blk}.{i}"]
@@ -374,7 +366,7 @@ class TrainEngine:
                 # dgrad on the persistent kernel: G' = (G + conv_T(dZ)) * mask = a residual layer with the transposed weights, no bias
                 # and slope 1, fp32 gradient stream in and out (bit-identical to the efts_gemm launch)
                 below = saved[i - 1] if i > 0 else None
-                if (_FUSE_ACT_BWD and below is not None and below[3] is not None and below[3][1] == 5 and below[4] == 0.0 and direct and grouped
+                if (_FUSE_ACT_BWD and below is not None and below[3] is not None and below[3][1] == 5 and below[4] == 0.0 and direct
                         and _BIAS_PARTS and m.k_size == 5 and below[2].split == m.split):
                     # ... and the activation backward of layer i - 1 on G' while the epilogue holds it: dZ_{i-1} as its operand plane and one
                     # row of column sums per tile (the launch efts_act_bwd would otherwise read G' back for)
@@ -594,7 +586,8 @@ class TrainEngine:
                                               g[gname(1, "0.bias")].data_ptr(), g["duration_predictor.linear.weight"].data_ptr(),
                                               g["duration_predictor.linear.bias"].data_ptr(), rs1.rows, C, drop_p, seed1, sadd, O._stream()),
                     "efts_layernorm_bwd")
-            self._wgrad_any(ws, dz2_f.ptr, dz2_p, l1_f.ptr, l1_p, C, C, 3, rs1.rows, g[gname(1, "0.weight")])
+            dur_items = []                                           # both k3 weight gradients in one grouped launch, below
+            self._wgrad_any(ws, dz2_f.ptr, dz2_p, l1_f.ptr, l1_p, C, C, 3, rs1.rows, g[gname(1, "0.weight")], defer=dur_items)
             G1 = ws.f32("Bdur_G1", rs1, C)
             wt = self.wt["dur.1"]
             O.gemm(a=dz2_p, b_ptr=wt.ptr, ldb=wt.ld, b_tap_stride=wt.tap_stride, taps=3, m=rs1.rows, n=C, out_f32_ptr=G1.ptr, ldo=C)
@@ -604,7 +597,9 @@ class TrainEngine:
                                               g[gname(0, "2.weight")].data_ptr(), g[gname(0, "2.bias")].data_ptr(),
                                               g[gname(0, "0.bias")].data_ptr(), None, None, rs1.rows, C, drop_p, seed0, sadd, O._stream()),
                     "efts_layernorm_bwd")
-            self._wgrad_any(ws, dz1_f.ptr, dz1_p, val_f.ptr, val_p, C, C, 3, rs1.rows, g[gname(0, "0.weight")])
+            self._wgrad_any(ws, dz1_f.ptr, dz1_p, val_f.ptr, val_p, C, C, 3, rs1.rows, g[gname(0, "0.weight")], defer=dur_items)
+            if dur_items:
+                self._wgrad_group(ws, dur_items, C, C, rs1.rows, 3, split)
             dV_dur = ws.f32("BdV_dur", rs1, C)
             wt = self.wt["dur.0"]
             O.gemm(a=dz1_p, b_ptr=wt.ptr, ldb=wt.ld, b_tap_stride=wt.tap_stride, taps=3, m=rs1.rows, n=C, out_f32_ptr=dV_dur.ptr, ldo=C)
@@ -708,13 +703,16 @@ class TrainEngine:
 
         def kv_param_grads():                                        # bias + weight gradients of the value / key Linears
             sc = ws.f32("Bscratch1" + self._ws_tag, rs1, C)
+            kv_items = []                                            # (value and key Linears: one grouped launch)
             if not shared:
                 L.check(_lib().efts_act_bwd(GV.ptr, None, None, None, 0.0, 0, sc.ptr, None, 0, 1,
                                             g["text_encoder_value.bias"].data_ptr(), rs1.rows, C, O._stream()), "efts_act_bwd")
-                self._wgrad_any(ws, GV.ptr, GV_p, te_f.ptr, te_p, C, C, 1, rs1.rows, g["text_encoder_value.weight"])
+                self._wgrad_any(ws, GV.ptr, GV_p, te_f.ptr, te_p, C, C, 1, rs1.rows, g["text_encoder_value.weight"], defer=kv_items)
             L.check(_lib().efts_act_bwd(GK.ptr, None, None, None, 0.0, 0, sc.ptr, None, 0, 1,
                                         g["text_encoder_key.bias"].data_ptr(), rs1.rows, C, O._stream()), "efts_act_bwd")
-            self._wgrad_any(ws, GK.ptr, GK_p, te_f.ptr, te_p, C, C, 1, rs1.rows, g["text_encoder_key.weight"])
+            self._wgrad_any(ws, GK.ptr, GK_p, te_f.ptr, te_p, C, C, 1, rs1.rows, g["text_encoder_key.weight"], defer=kv_items)
+            if kv_items:
+                self._wgrad_group(ws, kv_items, C, C, rs1.rows, 1, split)
 
         with O.on_stream(side):
             self._ws_tag = "s"

@@ -451,7 +451,7 @@ int efts_loss_bwd(const float* mel_pred, int64_t ldm, const float* speech, const
  * 4: LeakyReLU with the sign words efts_gemm wrote (`sign_mask` of the forward launch) passed as y (row stride c / 8 bytes,
  * c % 128 == 0), x unused.
  * mode | EFTS_ACT_BWD_BIAS_PARTS: dbias is a [ceil(rows / 64)][c] workspace that receives one column sum per 64-row block
- * (plain stores, overwritten) instead of atomic adds into the gradient; efts_wgrad_reduce_bias adds them up. */
+ * (plain stores, overwritten) instead of atomic adds into the gradient; efts_wgrad_reduce_grouped adds them up. */
 #define EFTS_ACT_BWD_BIAS_PARTS 16
 /* efts_act_bwd with the Dropout mask of the forward launch (efts_gemm_args.drop_p / drop_seed, c = that launch's n) applied too */
 int efts_act_bwd_dropout(const float* g, const float* y, const float* x, const float* rowmask, float slope, int32_t mode,
@@ -496,31 +496,26 @@ int efts_act_grad(const float* g, const float* z, const float* rowmask, int32_t 
  * from one pass over x */
 int efts_pack_t(const float* x, int64_t ldx, void* plane, int64_t ld_plane, int64_t plane_stride, int32_t split,
                 int32_t rows, int32_t c, int32_t shift0, int32_t nshift, int32_t kpad, void* stream);
-/* Direct wgrad partials of a k5 / k3 convolution or a Linear (taps 5, 3, 1) from the ROW-MAJOR bf16 planes (no transposed copies):
- * part[k][s][co][ci] = sum over the rows t of K-split s of dZ[t][co] * X[t + k - (taps - 1) / 2][ci], k = 0..taps-1
- * (autograd of the Conv1d in nntts/layers/efts_modules.py:48-51).  dz_plane / x_plane: operand planes of
- * the row space, both of format `split` (1 = bf16, 2 = bf16x3 hi/lo) (row 0 pointers; >= 2 zero rows before row 0 and >= 144 after `rows`),
- * cout % 128 == 0, cin % 64 == 0; part is what efts_wgrad_reduce consumes. */
-int efts_wgrad_tn(const void* dz_plane, int64_t ldz, const void* x_plane, int64_t ldx, float* part, int32_t rows,
-                  int32_t cout, int32_t cin, int32_t taps, int32_t nsplit, int32_t split, void* stream);
-/* dW[co][ci][k] = sum_s part[k][s][co][ci]; with g != NULL also the weight-norm backward
+/* Reduction of the transposed-plane path's split-K partials (taps x split-K efts_gemm launches over efts_pack_t planes: the path of shapes
+ * the direct kernel's tiles do not fit): dW[co][ci][k] = sum_s part[k][s][co][ci]; with g != NULL also the weight-norm backward
  * (dv -> dw_or_dv, dg) of w = g v / ||v|| */
 int efts_wgrad_reduce(const float* part, int32_t nsplit, const float* v, const float* g, float* dw_or_dv, float* dg,
                       int32_t cout, int32_t cin, int32_t taps, void* stream);
-/* the same, plus the bias gradient of the layer: dbias[co] += sum_i bias_part[i][co], i < nparts (the workspace efts_act_bwd
- * fills in EFTS_ACT_BWD_BIAS_PARTS mode), in a fixed order */
-int efts_wgrad_reduce_bias(const float* part, int32_t nsplit, const float* v, const float* g, float* dw_or_dv, float* dg,
-                           int32_t cout, int32_t cin, int32_t taps, const float* bias_part, int32_t nparts, float* dbias,
-                           void* stream);
-/* Grouped form: the weight gradients of up to EFTS_WGRAD_MAX_ITEMS layers of one residual stack (same rows, cout, cin, taps and plane
- * format; autograd of the Conv1d of every ResConv1d of `ResConvBlock`, nntts/layers/efts_modules.py:77-79 under
+/* Direct weight gradients of k5 / k3 convolutions and Linears (taps 5, 3, 1) from the ROW-MAJOR bf16 planes (no transposed copies):
+ *   dW[co][ci][k] = sum_t dZ[t][co] * X[t + k - (taps - 1) / 2][ci]      (autograd of the Conv1d in nntts/layers/efts_modules.py:48-51)
+ * dz_plane / x_plane: operand planes of the row space, both of format `split` (1 = bf16, 2 = bf16x3 hi/lo) (row 0 pointers; >= 2 zero rows
+ * before row 0 and >= 144 after `rows`), cout % 128 == 0, cin % 64 == 0.
+ * The weight gradients of up to EFTS_WGRAD_MAX_ITEMS layers (same rows, cout, cin, taps and plane
+ * format; e.g. the Conv1d of every ResConv1d of a `ResConvBlock`, nntts/layers/efts_modules.py:77-79 under
  * nntts/trainers/efficient_tts_trainer.py:146) in ONE launch.  The (layer, tile, 64-row step) space is dealt out to `workgroups`
  * workgroups (0: two per CU) as equal contiguous ranges (stream-K); every workgroup leaves one fp32 slab per tile its range touches
  * in `part` (efts_wgrad_grouped_part_bytes() bytes; -1: bad arguments), and efts_wgrad_reduce_grouped -- called with the SAME count, rows, cout, cin,
- * taps, split and workgroups -- adds a tile's slabs in a fixed order and finishes every layer like efts_wgrad_reduce_bias. */
+ * taps, split and workgroups -- adds a tile's slabs in a fixed order, then per layer the weight-norm backward (g != NULL) and the bias
+ * gradient dbias[co] += sum_i bias_part[i][co], i < nparts (the workspace efts_act_bwd fills in EFTS_ACT_BWD_BIAS_PARTS mode, or a dgrad
+ * launch's act_bwd_bias_part), in a fixed order. */
 #define EFTS_WGRAD_MAX_ITEMS 8
 typedef struct efts_wgrad_item {
-    const void* dz_plane;   /* operand plane of dZ, row 0 (efts_wgrad_tn) */
+    const void* dz_plane;   /* operand plane of dZ, row 0 */
     int64_t ldz;
     const void* x_plane;    /* operand plane of the layer's input, row 0 */
     int64_t ldx;
