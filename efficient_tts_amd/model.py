@@ -445,6 +445,16 @@ class EfficientTTSCNN(torch.nn.Module):
             object.__setattr__(self, "_side", st)
         return st
 
+    def _aux_stream(self, device) -> "torch.cuda.Stream":
+        """a third stream (the training pass: the decoder's grouped weight gradients beside the alignment block's backward)"""
+        if not self.side_stream:
+            return torch.cuda.current_stream(device)
+        st = getattr(self, "_aux", None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device)
+            object.__setattr__(self, "_aux", st)
+        return st
+
     def _workspace(self, key, device, pin=()) -> _Workspace:
         """The buffers of one shape.  Bounded LRU pools (each entry holds full activations): 4 teacher-forced / training
         shapes, 64 free-running ones (one or a few utterances, a few MB each).  `pin`: workspaces of the call in progress,

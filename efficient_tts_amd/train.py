@@ -8,6 +8,7 @@ ranges that become final early: mel head + decoder first, text encoder + embeddi
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -48,6 +49,10 @@ _NARROW_TN = 1               # the 80-channel Linears' weight gradients on the d
 _EARLY_PACKS = 1             # alignment backward: the operand copies that depend on forward tensors only go to the side stream, early (A/B)
 
 
+_WGRAD_STREAM = 3            # the mel-length weight gradients (mel head, decoder group, mel-encoder group, prenet) + their reductions on a third stream: nothing
+                             # on the dgrad chain waits for them, and they fill what that chain leaves idle -- above all the backward of the alignment block,
+                             # 0.25 ms of small latency-bound launches that use neither the matrix pipes nor the power budget.  Joined in front of a gradient
+                             # bucket's hand-over (data parallel) or of the optimizer.  Bit 0: decoder group, bit 1: head, mel-encoder group, prenet (A/B)
 _FUSE_ACT_BWD = 1            # stacks whose dgrad runs on efts_resconv5: the activation backward of layer l - 1 in the epilogue of layer l's dgrad launch
                              # (csrc/efts_resconv_bwd.hip) instead of an efts_act_bwd launch of its own (0: separate launches; tests compare)
 _WGRAD_GROUP_WGS = 384       # workgroups of a grouped launch (0: two per CU).  Swept 256..512 on the graphed B = 32 step: 3.27-3.32 ms at 384 against 3.33-3.34 at 512,
@@ -57,7 +62,7 @@ _WGRAD_GROUP_WGS = 384       # workgroups of a grouped launch (0: two per CU).  
 def switch_tag() -> tuple:
     """every hook above, by value: part of the tag of a captured training step"""
     return (_WGRAD_TN_SPLITS, _SIGN_MIN_ROWS, _BIAS_PARTS, _RESCONV_FWD, _RESCONV_DGRAD, _WGRAD_WGS, _PACK_SPLIT, _NARROW_TN, _EARLY_PACKS,
-            _WGRAD_GROUP_WGS, _FUSE_ACT_BWD, O.RC_KERNEL)
+            _WGRAD_GROUP_WGS, _FUSE_ACT_BWD, O.RC_KERNEL, _WGRAD_STREAM)
 
 
 class _TPlane(Plane):
@@ -319,8 +324,27 @@ class TrainEngine:
             x_f, x_p = o_f, o_p
         return x_f, x_p, saved
 
-    def _stack_bwd(self, ws, tag, blk, rs, G: F32Rows, saved, gap_ptr, final_mask_ptr, final_plane: Optional[Plane]):
-        """backward through n x (x + leaky(conv(x))); returns the gradient w.r.t. the stack input"""
+    @contextlib.contextmanager
+    def _forked(self, st):
+        """launches of the body go to stream `st`, ordered behind everything already enqueued on the current stream (None: no-op)"""
+        if st is None:
+            yield
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        st.wait_event(ev)
+        keep_tag = self._ws_tag
+        with O.on_stream(st):
+            self._ws_tag = "w"                  # (scratch of its own: the other streams run weight gradients at the same time)
+            try:
+                yield
+            finally:
+                self._ws_tag = keep_tag
+
+    def _stack_bwd(self, ws, tag, blk, rs, G: F32Rows, saved, gap_ptr, final_mask_ptr, final_plane: Optional[Plane], wgrad_stream=None):
+        """backward through n x (x + leaky(conv(x))); returns the gradient w.r.t. the stack input.
+        wgrad_stream: the stack's grouped weight gradients (and their reduction) are enqueued there, behind an event of the current stream
+        (their operands -- every layer's dZ plane and input plane -- are final then and not written again in this step); the caller joins"""
         m, C = self.m, self.m.n_channels
         layers = getattr(m, blk).layers
         group = []                                               # (grouped direct wgrads: every layer keeps its dZ plane and bias sums until the stack is through)
@@ -384,7 +408,8 @@ class TrainEngine:
                        out_plane=final_plane if last else None)
             G = Gn
         if group:
-            self._wgrad_group(ws, group, C, C, rs.rows, m.k_size, m.split)
+            with self._forked(wgrad_stream):
+                self._wgrad_group(ws, group, C, C, rs.rows, m.k_size, m.split)
         return G
 
     def forward_backward(self, text, text_lengths, speech, speech_lengths, gscale: Optional[torch.Tensor] = None,
@@ -629,17 +654,20 @@ class TrainEngine:
             # the unmasked loss sees (0 - speech) on padded frames; mel_pred = masked_fill(head output) blocks that gradient (:199-200)
             dmel_m = ws.f32("Bdmel_m", rs2, odim)
             self._act_bwd(dmel_f.ptr, None, None, len2.data_ptr(), 0, dmel_m, dmel_p, g["mel_output_layer.bias"], rs2.rows, odim)
-        if not self._wgrad_narrow(ws, "head", dmel_p, d_p, odim, C, rs2.rows, g["mel_output_layer.weight"]):
-            self._wgrad(ws, dmel_m.ptr, odim, d_f.ptr, C, C, 1, rs2.rows, None, None, g["mel_output_layer.weight"], None)
+        wst = m._aux_stream(dev) if (_WGRAD_STREAM and m.side_stream) else None
+        wst2 = wst if (_WGRAD_STREAM & 2) else None
+        with self._forked(wst2):
+            if not self._wgrad_narrow(ws, "head", dmel_p, d_p, odim, C, rs2.rows, g["mel_output_layer.weight"]):
+                self._wgrad(ws, dmel_m.ptr, odim, d_f.ptr, C, C, 1, rs2.rows, None, None, g["mel_output_layer.weight"], None)
         G = ws.f32("Bdec_Gh", rs2, C)
         wt = self.wt["head"]
         O.gemm(a=dmel_p, b_ptr=wt.ptr, ldb=wt.ld, m=rs2.rows, n=C, rowmask_ptr=gap2.data_ptr(), out_f32_ptr=G.ptr, ldo=C)
         # decoder; its input gradient dH is masked like H (efficient_tts.py:193-194) and also emitted as a split-2 plane
         dH_p = ws.plane("BdH_p", rs2, C, 2)
-        dH = self._stack_bwd(ws, "dec", "decoder", rs2, G, dec_saved, gap2.data_ptr(), len2.data_ptr(), dH_p)
+        dH = self._stack_bwd(ws, "dec", "decoder", rs2, G, dec_saved, gap2.data_ptr(), len2.data_ptr(), dH_p, wgrad_stream=wst if (_WGRAD_STREAM & 1) else None)
         if self.mark is not None:
             self.mark("bwd_decoder_done")
-        if self.bucket_hook:
+        if self.bucket_hook and wst is None:
             self.bucket_hook(0)
 
         # ---- expand bmm backward: d alpha' [B,T1,T2] and dV
@@ -700,6 +728,11 @@ class TrainEngine:
         if self.mark is not None:
             self.mark("bwd_alignment_done")
         side.wait_event(ev_gk)                                      # dK, dV are ready
+        if wst is not None and self.bucket_hook:
+            # data parallel: bucket 0 (mel head + decoder) is final once the decoder's weight gradients are through; its exchange then
+            # overlaps the encoders' backward instead of the alignment block's as well
+            main.wait_stream(wst)
+            self.bucket_hook(0)
 
         def kv_param_grads():                                        # bias + weight gradients of the value / key Linears
             sc = ws.f32("Bscratch1" + self._ws_tag, rs1, C)
@@ -741,7 +774,7 @@ class TrainEngine:
             G_me = ws.f32("BG_mh", rs2, C)
             wtq = self.wt["qfc"]
             O.gemm(a=GQ_p, b_ptr=wtq.ptr, ldb=wtq.ld, m=rs2.rows, n=C, rowmask_ptr=gap2.data_ptr(), out_f32_ptr=G_me.ptr, ldo=C)
-        Gm = self._stack_bwd(ws, "me", "mel_encoder", rs2, G_me, me_saved, gap2.data_ptr(), gap2.data_ptr(), None)
+        Gm = self._stack_bwd(ws, "me", "mel_encoder", rs2, G_me, me_saved, gap2.data_ptr(), gap2.data_ptr(), None, wgrad_stream=wst2)
         if self.mark is not None:
             self.mark("bwd_mel_encoder_done")
         narrow = self._narrow_ok(split, mel_in.split, C, odim, max(C, 128) * 2, mel_in.ld)        # (the dZ plane allocated below is C wide)
@@ -751,13 +784,18 @@ class TrainEngine:
             O.act_grad(m.act_general, Gm.ptr, pre_z.ptr, gap2.data_ptr(), dzp_f, dzp_p, g["mel_prenet.0.bias"], rs2.rows, C, pre_dp, pre_seed)
         else:
             self._act_bwd(Gm.ptr, pre_f.ptr, None, gap2.data_ptr(), 3, dzp_f, dzp_p, g["mel_prenet.0.bias"], rs2.rows, C, pre_dp, pre_seed)
-        if not (narrow and self._wgrad_narrow(ws, "pre", dzp_p, mel_in, C, odim, rs2.rows, g["mel_prenet.0.weight"])):
-            assert dzp_f is not None
-            self._wgrad(ws, dzp_f.ptr, C, mel_in_f.ptr, odim, odim, 1, rs2.rows, None, None, g["mel_prenet.0.weight"], None)
+        with self._forked(wst2):
+            if not (narrow and self._wgrad_narrow(ws, "pre", dzp_p, mel_in, C, odim, rs2.rows, g["mel_prenet.0.weight"])):
+                assert dzp_f is not None
+                self._wgrad(ws, dzp_f.ptr, C, mel_in_f.ptr, odim, odim, 1, rs2.rows, None, None, g["mel_prenet.0.weight"], None)
         if self.bucket_hook:
+            if wst is not None:
+                main.wait_stream(wst)
             self.bucket_hook(1)
 
         main.wait_stream(side)                                      # text-side gradients (bucket 2) and everything else enqueued there
+        if wst is not None and not self.bucket_hook:
+            main.wait_stream(wst)                                   # the weight gradients of the mel-length layers
         if self.bucket_hook:
             self.bucket_hook(2)
 
