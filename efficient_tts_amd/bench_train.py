@@ -138,6 +138,19 @@ def measure_train(a, world, rank, dev, wl, steps, warmup, precision=None):
     rows = P.Rows(B, T2).rows
     want_graph = bool(getattr(a, "train_graph", 1))
 
+    def bracketed(run, n=3):
+        """durations of the mel-length k5 launches (HIP events on their launch stream) over n eager steps of their own, NOT inside a timed
+        loop: creating the timing events can stall the host for tens of milliseconds when the runtime grows its event pool (seen as one
+        77 ms step in ten, i.e. a 10 ms "eager step", when the bracketing ran inside the timed eager loop)"""
+        P.PROFILE, P.PROFILE_TAG = [], (5, rows, 512)
+        try:
+            for _ in range(n):
+                run()
+            torch.cuda.synchronize()
+            return [s.elapsed_time(e) * 1e-3 for (tag, s, e) in (P.PROFILE or []) if tag == (5, rows, 512)]
+        finally:
+            P.PROFILE, P.PROFILE_TAG = None, None
+
     def finish(dt, issue, lv, durs, eager_dt, graph_dt, graph_note, poisoned):
         """the record from what has been measured (rank 0; None elsewhere)"""
         assert lv == lv, "NaN loss"
@@ -199,11 +212,9 @@ def measure_train(a, world, rank, dev, wl, steps, warmup, precision=None):
         # ---- (2) the eager loop (what the reference's trainer issues), conv launches bracketed by events for the roofline
         for _ in range(max(warmup, 2)):
             step()
-        P.PROFILE, P.PROFILE_TAG = [], (5, rows, 512)
         eager_dt, loss = timed(step, steps)
-        durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in (P.PROFILE or []) if tag == (5, rows, 512)]
-        P.PROFILE, P.PROFILE_TAG = None, None
         dp_stats = ddp.reducer.stats()
+        durs = bracketed(step)
         lv_eager = float(loss)
         # ---- (2b) the same K steps with the exchange switched off (the engine's bucket hooks detached): what the step costs this rank
         # without its collectives, under the same clock -- so that the line states its own scaling efficiency.  Replicas diverge in this
@@ -289,8 +300,6 @@ def measure_train(a, world, rank, dev, wl, steps, warmup, precision=None):
         run = gstep if graphed is not None else step
         for _ in range(max(warmup, 2)):
             loss = run()
-        if graphed is None:
-            P.PROFILE, P.PROFILE_TAG = [], (5, rows, 512)
         dt, loss = timed(run, steps)
         if graphed is not None and os.environ.get("EFTS_BENCH_TRAIN_NO_EAGER") == "1":
             graph_dt = dt                          # (profiling a replay's timeline: nothing issued behind the timed replays)
@@ -298,11 +307,12 @@ def measure_train(a, world, rank, dev, wl, steps, warmup, precision=None):
             # the same step issued eagerly (what the reference's loop does), with the conv launches bracketed by events for the roofline
             assert graphed.replays >= steps, "the timed steps were not graph replays"
             graph_dt = dt
-            P.PROFILE, P.PROFILE_TAG = [], (5, rows, 512)
             eager_dt, _ = timed(step, max(3, min(steps, 10)))
             eager_dt = eager_dt / max(3, min(steps, 10)) * steps
-        durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in (P.PROFILE or []) if tag == (5, rows, 512)]
-        P.PROFILE, P.PROFILE_TAG = None, None
+        if os.environ.get("EFTS_BENCH_TRAIN_NO_EAGER") == "1" and graphed is not None:
+            durs = []
+        else:
+            durs = bracketed(step)
         issue = ("one hipGraph replay per step (step_graph.GraphedStep), the batch resident in the buffers the captured launches read "
                  "(GraphedStep.inputs: where the trainer's loader copies it, trainer._stage)") if graphed is not None else "eager launches"
     lv = lv_eager if world > 1 else float(loss)
