@@ -35,7 +35,10 @@ if con:
 for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_l2"):
     con = db(sub)
     if not con:
-        print(f"\n## {sub}: no database (pass failed, see {sub}.log)")
+        if os.path.exists(os.path.join(out, sub + ".log")):
+            print(f"\n## {sub}: no database (pass failed, see {sub}.log)")
+        else:
+            print(f"\n## {sub}: not collected (trace-only run: NOPMC=1)")
         continue
     print(f"\n## {sub}: average counter value per dispatch (efts kernels only)")
     q = ("select kernel_name, counter_name, avg(value), count(*), grid_size from counters_collection "
