@@ -22,7 +22,7 @@ int efts_check_launch(const char* what) {
 }
 
 extern "C" const char* efts_last_error(void) { return g_err; }
-extern "C" int efts_version(void) { return 100; }
+extern "C" int efts_version(void) { return EFTS_ABI_VERSION; }
 
 extern "C" int efts_device_check(void) {
     int dev = 0;

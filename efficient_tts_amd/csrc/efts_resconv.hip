@@ -157,6 +157,7 @@ extern "C" int efts_resconv5_multi(const efts_resconv5_args* a, int32_t count, v
         if (rc) return rc;
         if (q->split != a->split || q->n != a->n || q->nchunk != a->nchunk || q->ldw != a->ldw)
             return efts_fail(EFTS_ESHAPE, "efts_resconv5_multi: the layers of a launch must agree in split, n, nchunk and ldw");
+        if (q->kernel != a->kernel) return efts_fail(EFTS_EINVAL, "efts_resconv5_multi: the layers of a launch must name the same kernel");
         RcProb& r = k.pr[i];
         r.a = (const char*)q->x; r.a_lo = (const char*)q->x_lo; r.resid = q->x_f32; r.w = (const char*)q->w;
         r.bias = q->bias; r.rowmask = q->rowmask; r.out_f32 = q->y_f32; r.ob = (char*)q->y; r.ob_lo = (char*)q->y_lo;
@@ -209,7 +210,7 @@ extern "C" int efts_resconv5_multi(const efts_resconv5_args* a, int32_t count, v
     // (efts_resconv5_args.kernel = 2): its main loop needs 8 % fewer cycles than the ping-pong kernel's (2 210 vs ~2 400 per full step), but on
     // MI355X both run at the clock the power budget leaves (1.4-1.5 GHz with every CU issuing MFMAs on random operands) and take the same
     // time -- measured in one process: forward 1.596 vs 1.561 ms, training step 3.80 vs 3.70 ms, the 8-wave kernel ahead (DESIGN.md 4a').
-    if (!(a->kernel == 0 || a->kernel == 1 || a->kernel == 2)) return efts_fail(EFTS_EINVAL, "efts_resconv5: kernel must be 0 (the 8-wave kernel) or 2");
+    if (!(a->kernel == 0 || a->kernel == 2)) return efts_fail(EFTS_EINVAL, "efts_resconv5: kernel must be 0 (the 8-wave kernel) or 2");
     bool w4 = a->kernel == 2 && a->split == 1 && k.nchunk >= 2;
     for (int i = 0; i < count; ++i) w4 = w4 && k.pr[i].taps == 5;
     if (w4) {

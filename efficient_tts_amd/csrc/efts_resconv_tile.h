@@ -563,7 +563,16 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
     };
     int pi, m0, h, rows_out;
     locate(0, vrow, pi, m0, h, rows_out);
-    if (h == 0) return;
+    auto zero_bias_rows = [&](int t_from) {
+        // rows of `bias_part` this workgroup's group owns but runs no tile for (a class with fewer tiles than bp_tiles, a group beyond the end of
+        // the row space): zeroed here, so that the table needs no caller-side clearing whatever m / plan it was last used with
+        if constexpr (MODE == 1) {
+            if (p.pr[0].bias_part)
+                for (int tt = t_from; tt < p.bp_tiles; ++tt)
+                    p.pr[0].bias_part[(long)(((g * p.bp_tiles) + tt) * 2 + (tid >> 8)) * (p.ntn * RC_BN) + c.n0 + (tid & 255)] = 0.f;
+        }
+    };
+    if (h == 0) { zero_bias_rows(0); return; }
 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -596,7 +605,8 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
             for (int q = 0; q < 4; ++q)
                 dma16(c.lds0 + RC_RING + s * RC_W_BYTES + c.wave * 1024 + q * 8192, c.vow[q], c.w_base + (long)s * c.wts);
     }
-    for (int t = 0; h > 0; ++t) {
+    int t = 0;
+    for (; h > 0; ++t) {
         const int vnext = vrow + rows_out;
         int pi1, m1, h1, rows1;
         locate(t + 1, vnext, pi1, m1, h1, rows1);
@@ -659,6 +669,7 @@ __global__ __launch_bounds__(512, 2) void resconv5_kernel(RcArgs p) {
         c.w_base = c.w_next; c.wts = c.wts_next;
         vrow = vnext; pi = pi1; m0 = m1; h = h1; rows_out = rows1;
     }
+    zero_bias_rows(t);
     // the last tile's wrapped weight requests may still be landing: LDS must not be handed to another workgroup under them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (RC_STAMP == 1 && p.stamp && tid == 0) p.stamp[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();

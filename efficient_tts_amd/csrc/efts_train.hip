@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
                 float t = 0.f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) t += colsum[k][threadIdx.x];
-                // bias_parts: dbias is a [row blocks][c] workspace of per-block sums (plain stores, summed by efts_wgrad_reduce_bias):
+                // bias_parts: dbias is a [row blocks][c] workspace of per-block sums (plain stores, summed by efts_wgrad_reduce_grouped):
                 // at mel length the 400 same-address atomics per column cost ~8 us of a 22 us launch
                 if (bias_parts) dbias[(long)blockIdx.x * c + cbase + threadIdx.x] = t;
                 else atomicAdd(dbias + cbase + threadIdx.x, t);
@@ -904,6 +904,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_sk_kernel(WrSkArgs p) {
 extern "C" int efts_wgrad_reduce_grouped(const efts_wgrad_item* items, int32_t count, const float* part, int32_t rows, int32_t cout, int32_t cin,
                                          int32_t taps, int32_t split, int32_t workgroups, void* stream) {
     if (!items || !part) return efts_fail(EFTS_EINVAL, "efts_wgrad_reduce_grouped: null pointer");
+    if (!(taps == 1 || taps == 3 || taps == 5)) return efts_fail(EFTS_EINVAL, "efts_wgrad_reduce_grouped: implemented for taps 1, 3, 5 (as efts_wgrad_tn_grouped)");
     if ((size_t)cin * taps * 4 > 60000) return efts_fail(EFTS_ESHAPE, "efts_wgrad_reduce_grouped: cin*taps too large for LDS");
     efts_wgrad_sk_geom gm;
     const int rc = efts_wgrad_sk_geometry(count, rows, cout, cin, split, workgroups, &gm);

@@ -12,6 +12,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EFTS_LIB", os.path.join(HERE, "libefts_hip.so"))   # EFTS_LIB: kernel experiments only
 
+ABI_VERSION = 600         # EFTS_ABI_VERSION of the include/efts_abi.h this binding mirrors; load() refuses any other library
 RC_PLAN_INTS = 42
 GAP = 2
 GUARD_LO = 8
@@ -188,6 +189,10 @@ def load() -> C.CDLL:
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
+    have = lib.efts_version()
+    if have != ABI_VERSION:
+        raise EftsError(f"{LIB_PATH} reports ABI revision {have}, this binding mirrors revision {ABI_VERSION} of include/efts_abi.h: "
+                        "argument blocks would be misread.  Rebuild with `python -m efficient_tts_amd.build --force`.")
     _lib = lib
     return lib
 

@@ -56,6 +56,14 @@ extern "C" {
 #define EFTS_ACT_RELU 2
 #define EFTS_ACT_TANH 3 /* the vocoder's output layer */
 
+/* ABI revision of THIS header.  Bumped whenever an argument block changes size / meaning or an export is removed, so that a consumer built
+ * against another revision can tell: efts_version() returns the revision the library was built from, and a binding must refuse to run unless
+ * it equals the EFTS_ABI_VERSION it was written against (efficient_tts_amd/lib.py does, tests/test_abi_cpu.py pins all three).
+ *   100  rounds 1-4
+ *   500  round 5: efts_resconv5_args grew by act_bwd_sign / act_bwd_bias_part / act_bwd_bias_rows / act_bwd_slope / kernel;
+ *        efts_wgrad_tn, efts_wgrad_reduce_bias, efts_resconv5_kernel removed (efts_wgrad_tn_grouped / efts_wgrad_reduce_grouped instead)
+ *   600  round 6 (this header) */
+#define EFTS_ABI_VERSION 600
 int efts_version(void);
 const char* efts_last_error(void);
 /* 0 when the current HIP device is gfx950. */
@@ -197,13 +205,14 @@ typedef struct efts_resconv5_args {
      * x_f32 = G, y_f32 = G' = d loss / d x_l, slope 1, no bias -- and its epilogue also runs the activation backward of layer l - 1
      * (efts_act_bwd mode 5 | EFTS_ACT_BWD_BIAS_PARTS) on the values it holds: y receives dZ_{l-1} = G' * (bit ? 1 : act_bwd_slope) as an
      * operand plane of format y_split = split, act_bwd_bias_part one row of column sums of dZ_{l-1} per tile and wave row
-     * (efts_resconv5_bias_rows(m, n) rows of n floats, zero-filled by the caller once: rows of tiles the schedule does not have are never
-     * written; NULL: no sums).  act_bwd_sign = the sign_bits layer l - 1's forward launch wrote.  NULL: a plain layer. */
+     * (efts_resconv5_bias_rows(m, n) rows of n floats; every row is written by every launch -- rows of tiles the schedule does not have
+     * receive zeros -- so the table needs no clearing and may be re-used across shapes; NULL: no sums).  act_bwd_sign = the sign_bits layer l - 1's forward launch wrote.  NULL: a plain layer. */
     const void* act_bwd_sign;
     float* act_bwd_bias_part;
     int32_t act_bwd_bias_rows;
     float act_bwd_slope;
-    int32_t kernel;      /* which kernel runs the launch (layers[0].kernel decides for a grouped launch).  0: the 8-wave ping-pong kernel -- the
+    int32_t kernel;      /* which kernel runs the launch (every layer of a grouped launch must name the same one; other values: EFTS_EINVAL).
+                          * 0: the 8-wave ping-pong kernel -- the
                           * product path.  2: the one-wave-per-SIMD kernel with the generated main loop wherever it applies (bf16 planes, 5 taps,
                           * >= 2 K chunks, no fused activation backward; the 8-wave kernel elsewhere): same results bit for bit, same time on
                           * MI355X (DESIGN.md 4a'), kept for the bit-equality tests between the two and for A/B measurements */

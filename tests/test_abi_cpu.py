@@ -27,7 +27,10 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_version_and_argument_errors(lib):
-    assert lib.efts_version() >= 100
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "efts_abi.h")).read()
+    declared = int(re.search(r"#define EFTS_ABI_VERSION (\d+)", hdr).group(1))
+    assert lib.efts_version() == declared == L.ABI_VERSION      # library, header and ctypes mirror are one revision (load() refuses any other)
     g = L.GemmArgs()
     g.split, g.taps = 7, 5
     assert lib.efts_gemm(g, None) == -1            # EFTS_EINVAL before any launch

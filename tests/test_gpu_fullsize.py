@@ -13,6 +13,9 @@ from oracle import efts_oracle as O
 
 pytestmark = pytest.mark.gpu
 MEL_TOL = 1e-3
+PLAIN_FILL_REL_TOL = 2e-4   # (200, 1500) with the plain fill: 1e-3 on LJSpeech-sized outputs (<= 5) as a fraction of the output range
+PLAIN_FILL_ABS_TOL = 4e-3   # ... and its absolute error as measured (see the test's print), with 1.5 x headroom
+BF16_MODE_TOL = 0.15       # the bf16 mode's OWN bound (config 2's stated dtype; measured 0.092-0.12 on these inputs, rounds 3-5): a 1.5 x regression fails
 
 
 def _dev():
@@ -34,7 +37,7 @@ def _full(golden_dir, reps):
     return g, [torch.cat([a] * reps, 0) for a in args]
 
 
-@pytest.mark.parametrize("precision,tol", [("bf16x3", MEL_TOL), ("bf16", 0.5)])
+@pytest.mark.parametrize("precision,tol", [("bf16x3", MEL_TOL), ("bf16", BF16_MODE_TOL)])
 def test_forward_b64_natural_dispatch_vs_reference_golden(golden_dir, precision, tol):
     """config 2 at full size: 32 copies of the reference's ragged golden pair.  Every copy must reproduce the golden
     (bf16x3: within the north_star 1e-3; bf16: its own, reported, error) and equal every other copy BITWISE -- tiles straddle
@@ -149,7 +152,38 @@ def test_long_sequence_b16_vs_oracle_and_equivariance(T1, T2):
     assert abs(float(loss) - float(lossp)) <= 1e-5 * float(loss)
 
 
-@pytest.mark.parametrize("precision,tol", [("bf16x3", MEL_TOL), ("bf16", 0.5)])
+def test_long_sequence_plain_fill_reports_its_error():
+    """config 5's second shape, (200, 1500), with the PLAIN deterministic fill (the test above rescales the mel head for this shape so
+    that the absolute 1e-3 applies to LJSpeech-sized outputs).  Here |mel_pred| reaches ~15, three times the range of LJSpeech log-mels,
+    and the honest form of north_star's bound is relative: 1e-3 on outputs of size <= 5 = 2e-4 of the output range.  The measured absolute
+    and relative errors of the bf16x3 mode are printed and bounded at what they are today -- no hidden failure."""
+    from efficient_tts_amd import EfficientTTSCNN
+    dev = _dev()
+    T1, T2, B = 200, 1500, 16
+    gen = torch.Generator().manual_seed(T1 * 10000 + T2)
+    text = torch.randint(0, 76, (B, T1), generator=gen)
+    mel = torch.randn(B, T2, 80, generator=gen)
+    tl = torch.randint(T1 // 2, T1 + 1, (B,), generator=gen); tl[0] = T1
+    sl = torch.randint(T2 // 2, T2 + 1, (B,), generator=gen); sl[0] = T2
+    P = O.fill_params()
+    m = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, use_weighted_masking=False, sigma=0.01, precision="bf16x3")
+    m.load_state_dict(P)
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        mp = m(*[t.to(dev) for t in (text, tl, mel, sl)])[4]
+        ref = O.forward(P, text[:2], tl[:2], mel[:2], sl[:2])["mel_pred"]            # the oracle as the checker (2 items)
+    scale = float(ref.abs().max())
+    worst = 0.0
+    for b in range(2):
+        t2 = int(sl[b])
+        worst = max(worst, float((mp[b, :t2].cpu() - ref[b, :t2]).abs().max()))
+    print(f"(200, 1500) plain fill, bf16x3: mel max-abs {worst:.3e}, max |mel| {scale:.2f}, relative {worst / scale:.3e}")
+    assert scale > 5.0                                    # (the point of the case: outputs beyond the LJSpeech range)
+    assert worst / scale <= PLAIN_FILL_REL_TOL
+    assert worst <= PLAIN_FILL_ABS_TOL
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", MEL_TOL), ("bf16", BF16_MODE_TOL)])
 def test_forward_b64_distinct_ragged_items_vs_oracle(precision, tol):
     """config 2 at full size with 64 DISTINCT ragged items (every item its own text, mel and lengths): item 0 (full length,
     so that the oracle's padded shape is the batch's) and 3 random others against the oracle run on exactly those 4 items;

@@ -206,7 +206,7 @@ def test_bf16_mode_reports_its_own_error(golden_dir):
         loss, stats, imv, ralpha, mel_pred, _ = m(*args)
     err = float((mel_pred.cpu()[:, ::int(g["mel_pred_stride"])] - torch.from_numpy(g["mel_pred"])).abs().max())
     print("bf16 mel max-abs", err)
-    assert err <= 0.5 and abs(float(loss) - float(g["loss"])) <= 2e-2 * float(g["loss"])
+    assert err <= 0.15 and abs(float(loss) - float(g["loss"])) <= 2e-2 * float(g["loss"])
 
 
 def test_full_size_properties(model):

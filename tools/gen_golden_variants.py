@@ -64,10 +64,16 @@ def main():
         ref["loss"].backward()
         Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
         O.forward(Pg, text, tl, mel, sl, hp)["loss"].backward()
-        worst = 0.0
+        worst, zero_like = 0.0, []
+        gmax_all = max(float(p.grad.abs().max()) for _, p in m.named_parameters())
         for k, p in m.named_parameters():
             g = p.grad
-            worst = max(worst, G.maxabs(g, Pg[k].grad) / (float(g.abs().max()) + 1e-12))
+            # a gradient that is identically zero in exact arithmetic (text_encoder_key.bias: softmax over the keys is shift-invariant) is fp noise
+            # on both sides: comparing noise with noise relative to its own size says nothing, so such tensors are reported apart
+            if float(g.abs().max()) <= 1e-5 * gmax_all:
+                zero_like.append((k, float(g.abs().max()), float(Pg[k].grad.abs().max())))
+            else:
+                worst = max(worst, G.maxabs(g, Pg[k].grad) / float(g.abs().max()))
             flat = G.npy(g).reshape(-1)
             if flat.size > 1024:
                 step = flat.size // 512
@@ -75,7 +81,8 @@ def main():
                 flat = flat[::step]
             d["grad:" + k] = flat
             d["gradnorm:" + k] = np.float64(g.double().norm())
-        print(f"  [{name}] oracle vs reference param-grad worst rel-to-max {worst:.3e}")
+        print(f"  [{name}] oracle vs reference param-grad worst rel-to-max {worst:.3e}"
+              + "".join(f"; {k}: zero in exact arithmetic (|grad| max: reference {a:.1e}, oracle {b:.1e}), not in the figure" for k, a, b in zero_like))
         if name in ("sharekv", "delta2", "k3", "k7", "k11", "gelu", "elu"):                # free-running path: value = key (:252-253) / positions from 0 (:261-265) / k3 stacks
             ids = torch.randint(1, 76, (1, 23), generator=torch.Generator().manual_seed(5))
             m.remove_weight_norm()

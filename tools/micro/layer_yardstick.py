@@ -14,9 +14,10 @@ Arms (random bf16 / fp32 data, N(0, 1) activations, 0.02 * N(0, 1) weights):
 Two passes:
   (1) timing: ROUNDS rounds, arms interleaved inside a round, LAUNCHES (200) launches per arm and round between two events after 20 warm-up launches;
       median / min over the rounds.
-  (2) sustained + power: each arm alone in a loop of ~SUSTAIN seconds; socket power sampled beside it (hwmon power1_average / power1_input when the
-      node exposes it, else `rocm-smi --showpower` as tools/gpu_power_trace.sh does), samples of the first second dropped; us per launch of the whole
-      loop, W, mJ per launch.
+  (2) sustained + power: each arm alone in a loop of ~SUSTAIN seconds; socket power sampled beside it (`rocm-smi --showpower` as
+      tools/gpu_power_trace.sh does, and the card's hwmon file as a second, faster signal), samples of the first second dropped; us per launch of
+      the whole loop, W, mJ per launch.
+Kernel names of the library arms: `YROUNDS=1 YLAUNCHES=20 YSUSTAIN=0.05 rocprofv3 --kernel-trace --stats ... -- python tools/micro/layer_yardstick.py`.
 FLOP figure of every conv / layer arm: 2 * 51200 * 2560 * 512 = 134.2 GFLOP (matmul_big: 2 * 8192^3).
 """
 import glob
@@ -40,7 +41,9 @@ FLOP = 2.0 * B * T * C * C * K
 
 
 class Power:
-    """socket power of GPU 0 in W: sysfs hwmon when there (micro-watts), else rocm-smi (one fork per sample)"""
+    """socket power of GPU 0 in W, from TWO sources side by side: `rocm-smi --showpower` (one fork per sample, ~3 per second: the figure
+    tools/gpu_power_trace.sh and DESIGN.md 4a' quote) and, when the node exposes it, the hwmon file of the card (20 samples per second; on
+    this pool's boxes it reads about HALF of rocm-smi's figure under load and does not drop at idle -- kept as a relative signal only)"""
 
     def __init__(self):
         self.path = None
@@ -49,14 +52,16 @@ class Power:
             if got:
                 self.path = got[0]
                 break
-        self.source = self.path or "rocm-smi --showpower"
+        self.source = f"rocm-smi --showpower; hwmon = {self.path}"
 
-    def read(self):
-        if self.path:
-            try:
-                return float(open(self.path).read()) * 1e-6
-            except Exception:                              # noqa: BLE001
-                return None
+    def read_hwmon(self):
+        try:
+            return float(open(self.path).read()) * 1e-6 if self.path else None
+        except Exception:                                  # noqa: BLE001
+            return None
+
+    @staticmethod
+    def read_smi():
         try:
             out = subprocess.run(["rocm-smi", "--showpower"], capture_output=True, text=True, timeout=10).stdout
             m = re.search(r"Power \(W\): ([0-9.]+)", out)
@@ -65,21 +70,25 @@ class Power:
             return None
 
     def sample_while(self, fn):
-        """run fn() (blocking) while sampling; -> (fn's result, [(t, W)])"""
-        stop, got, t0 = threading.Event(), [], time.perf_counter()
+        """run fn() (blocking) while sampling; -> (fn's result, [(t, W)] of rocm-smi, [(t, W)] of hwmon)"""
+        stop, smi, hw, t0 = threading.Event(), [], [], time.perf_counter()
 
-        def loop():
+        def loop(read, got, pause):
             while not stop.is_set():
-                w = self.read()
+                w = read()
                 if w is not None:
                     got.append((time.perf_counter() - t0, w))
-                time.sleep(0.05 if self.path else 0.0)
-        th = threading.Thread(target=loop, daemon=True)
-        th.start()
+                time.sleep(pause)
+        ths = [threading.Thread(target=loop, args=(self.read_smi, smi, 0.0), daemon=True)]
+        if self.path:
+            ths.append(threading.Thread(target=loop, args=(self.read_hwmon, hw, 0.05), daemon=True))
+        for th in ths:
+            th.start()
         res = fn()
         stop.set()
-        th.join()
-        return res, got
+        for th in ths:
+            th.join()
+        return res, smi, hw
 
 
 def arms():
@@ -174,16 +183,12 @@ def main():
         print(f"{n:13s} median {med:8.1f} us  min {ts[0]:8.1f} us  {tf:7.0f} TFLOP/s  {tf / 2500.0:5.3f} of peak   rounds: " + " ".join(f"{t:.1f}" for t in per[n]), flush=True)
     # ---- pass 2: sustained loops with power
     pw = Power()
-    idle = []
     torch.cuda.synchronize()
-    time.sleep(1.0)
-    for _ in range(10):
-        w = pw.read()
-        if w is not None:
-            idle.append(w)
-        time.sleep(0.1)
-    pidle = sum(idle) / max(len(idle), 1)
-    print(f"\n## pass 2: each arm alone for ~{SUSTAIN:.0f} s, power from {pw.source} (idle {pidle:.0f} W); samples of the first second dropped")
+    time.sleep(5.0)
+    _, idle_smi, idle_hw = pw.sample_while(lambda: time.sleep(2.0))
+    mean = lambda xs: sum(w for _, w in xs) / len(xs) if xs else float("nan")   # noqa: E731
+    print(f"\n## pass 2: each arm alone for ~{SUSTAIN:.0f} s, power from {pw.source}; idle (5 s after pass 1): rocm-smi {mean(idle_smi):.0f} W, hwmon {mean(idle_hw):.0f} W; "
+          "samples of the first second of a loop dropped; mJ / pJ from the rocm-smi figure")
     try:
         cap = subprocess.run(["rocm-smi", "--showmaxpower"], capture_output=True, text=True, timeout=10).stdout
         for ln in cap.splitlines():
@@ -198,14 +203,15 @@ def main():
 
         def loop(fn=fn, count=count):
             return events_us(fn, count)
-        us, samples = pw.sample_while(loop)
-        ws = [w for (t, w) in samples if t > 1.0]
+        us, smi, hw = pw.sample_while(loop)
+        ws = [w for (t, w) in smi if t > 1.0]
+        hs = [w for (t, w) in hw if t > 1.0]
         wavg = sum(ws) / len(ws) if ws else float("nan")
-        wmax = max(ws) if ws else float("nan")
+        havg = sum(hs) / len(hs) if hs else float("nan")
         tf = A[n][1] / us * 1e-6
-        print(f"{n:13s} {count:6d} launches  {us:8.1f} us per launch  {tf:7.0f} TFLOP/s  {tf / 2500.0:5.3f} of peak   {wavg:6.0f} W mean ({wmax:.0f} max, {len(ws)} samples)  "
-              f"{wavg * us * 1e-3:7.1f} mJ per launch  {wavg * us * 1e-6 / A[n][1] * 1e12:5.2f} pJ per FLOP", flush=True)
-        time.sleep(0.5)
+        print(f"{n:13s} {count:6d} launches  {us:8.1f} us per launch  {tf:7.0f} TFLOP/s  {tf / 2500.0:5.3f} of peak   rocm-smi {wavg:6.0f} W ({len(ws)} samples, max {max(ws) if ws else float('nan'):.0f})  "
+              f"hwmon {havg:5.0f} W ({len(hs)})  {wavg * us * 1e-3:7.1f} mJ per launch  {wavg * us * 1e-6 / A[n][1] * 1e12:5.2f} pJ per FLOP", flush=True)
+        time.sleep(1.0)
 
 
 if __name__ == "__main__":
