@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--stock-gpu", type=int, default=1, help="fwd64, N=1: also time the oracle's plain torch ops on this GPU (MIOpen / hipBLASLt, fp32 and bf16 autocast) -> `stock_gpu_baseline`")
     ap.add_argument("--stock-find", type=int, default=0, help="stock_gpu_baseline: 1 = torch.backends.cudnn.benchmark = True (MIOpen's exhaustive solver search, as nntts/bin/train.py:60 sets it; tens of seconds per new shape)")
     ap.add_argument("--measure-traffic", type=int, default=1, help="forward workloads, N=1: roofline.traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) over a 2-step child run, when rocprofv3 is on the box; 0: the committed profiles/traffic.json")
+    ap.add_argument("--test-shape", default="", metavar="B,T1,T2", help="PLUMBING TESTS ONLY (tests/test_dist_gpu.py: eight ranks sharing one GPU over gloo): fwd64 / train32 at this shape "
+                    "instead of BASELINE's, the training record at --steps / --warmup; the line says so in config.workload")
     ap.add_argument("--rc-kernel", type=int, default=0, help="A/B: efts_resconv5_args.kernel of every launch: 0 the 8-wave ping-pong kernel (default), 2 the one-wave-per-SIMD kernel where it applies")
     return ap.parse_args()
 
@@ -702,6 +704,10 @@ def run_rendezvous(a, world, rank):
 
 def main():
     a = parse()
+    if a.test_shape:
+        tb, t1, t2 = (int(v) for v in a.test_shape.split(","))
+        for k in ("fwd64", "train32"):
+            WORKLOADS[k].update(B=tb, T1=t1, T2=t2, desc=WORKLOADS[k]["desc"] + f" [TEST SHAPE {tb} x ({t1}, {t2}): a plumbing run, not a measurement]")
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         raise SystemExit(_self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -773,6 +779,8 @@ def conv_roofline(P, model, step, B, T2, precision, workload, a=None, traffic_ok
     durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in P.PROFILE if tag == (5, rows, 512)]
     P.PROFILE, P.PROFILE_TAG = None, None
     model.graphs = keep
+    if not durs:                                                 # (--test-shape: no launch of the dominant kernel at all)
+        return dict(bound="mfma", kernel="no efts_resconv5 launch at mel length in this shape", achieved=None, peak=PEAK_MFMA_BF16_TFLOPS, unit="TFLOP/s", frac=None, traffic=None)
     avg = sum(durs) / max(len(durs), 1)
     flop = 2.0 * B * T2 * 512 * 512 * 5
     # algorithmic bytes per launch: per element of the [rows, 512] stream 2 B hi + 2 B lo read, 4 B hi + lo
@@ -991,7 +999,8 @@ def run_forward(a, world, rank, dev, wl, sub=None):
         dog = _watchdog(int(os.environ.get("EFTS_BENCH_DP_TIMEOUT", "240")), rank, res, "train32", partial=lambda: getattr(a, "partial_train", None)) if world > 1 else None
         failed = False
         try:
-            tr = measure_train(a, world, rank, dev, WORKLOADS["train32"], steps=40, warmup=10)      # (None on ranks other than 0)
+            tsteps, twarm = (40, 10) if not a.test_shape else (a.steps, a.warmup)
+            tr = measure_train(a, world, rank, dev, WORKLOADS["train32"], steps=tsteps, warmup=twarm)      # (None on ranks other than 0)
         except Exception as exc:                                       # noqa: BLE001 -- the line must still be printed
             if world == 1:
                 raise
@@ -1001,7 +1010,7 @@ def run_forward(a, world, rank, dev, wl, sub=None):
         trp = None
         if not failed and a.precision == "bf16" and a.parity_mode and not (rank == 0 and tr and tr["config"].get("device_state")):
             try:
-                trp = measure_train(a, world, rank, dev, WORKLOADS["train32"], steps=40, warmup=10, precision="bf16x3")
+                trp = measure_train(a, world, rank, dev, WORKLOADS["train32"], steps=tsteps, warmup=twarm, precision="bf16x3")
             except Exception as exc:                                   # noqa: BLE001 -- the line must still be printed
                 trp = None
                 if rank == 0:

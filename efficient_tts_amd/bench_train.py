@@ -207,8 +207,14 @@ def measure_train(a, world, rank, dev, wl, steps, warmup, precision=None):
         torch.cuda.synchronize()
         same, every = fingerprints()
         assert same, "data-parallel replicas diverged after 2 steps: " + str([e.tolist() for e in every])
+        # every rank draws its OWN minibatch (seed 1234 + rank): gather the seeds and a checksum of each rank's batch
+        mine = torch.tensor([1234 + rank, int(text.to(torch.int64).sum()) * 1000003 + int((mel.double() * 1e3).round().to(torch.int64).sum().item() % 1000003)],
+                            dtype=torch.int64, device=dev)
+        allb = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allb, mine)
         selfcheck = dict(backend=backend, world_seen_by_rccl=dist.get_world_size(), steps=2, replicas_bit_identical=same,
-                         fingerprint=[int(v) for v in every[0].tolist()])
+                         fingerprint=[int(v) for v in every[0].tolist()], seeds=[int(t[0]) for t in allb],
+                         batches_distinct=len({int(t[1]) for t in allb}) == world)
         # ---- (2) the eager loop (what the reference's trainer issues), conv launches bracketed by events for the roofline
         for _ in range(max(warmup, 2)):
             step()

@@ -279,7 +279,7 @@ class EfficientTTSCNN(torch.nn.Module):
     _TEXT_SIDE = ("text_encoder.", "dur.", "key", "value")            # weights only the text-length launches read
 
     def _weights(self, folded: Optional[Dict[str, torch.Tensor]] = None,
-                 wt: Optional[Dict[str, PackedWeight]] = None, params=None, text_stream=None) -> Dict[str, PackedWeight]:
+                 wt: Optional[Dict[str, PackedWeight]] = None, params=None, text_stream=None, main_first: bool = False) -> Dict[str, PackedWeight]:
         """B operand planes of every Conv1d/Linear; repacked (weight-norm fold fused) whenever
         a parameter changed (optimizer step, load_state_dict, .to()).  Training engine extras, produced by the same
         launches: `folded[name]` (fp32 [cout][cin][taps]) receives the folded weight g * v / ||v|| of a weight-normed
@@ -351,6 +351,11 @@ class EfficientTTSCNN(torch.nn.Module):
         table, scale = tables[key]
         base = table.data_ptr()
         half = scale.numel() // 2 * 4
+        if main_first:
+            # the training step's order of issue (round 6): the planes of the stream the caller runs on first -- and among those the small groups (the prenet's
+            # and the mel head's Linears) in front of the stacks' -- then the text stream's: the mel side is the step's critical path
+            # (the text stream's own order: the text encoder's planes, its first consumer, in front of the duration predictor's and key / value's)
+            launches.sort(key=lambda t: (t[8], (-1 if t[8] else 1) * t[1] * t[4] * t[5] * t[6]))
         for first, n, ld, ld_t, cout, cin, taps, with_t, on_text in launches:
             if on_text:
                 with O.on_stream(text_stream):

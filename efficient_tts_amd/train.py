@@ -59,10 +59,20 @@ _WGRAD_GROUP_WGS = 384       # workgroups of a grouped launch (0: two per CU).  
                              # 3.28-3.34 at 256 (per-layer launches: 3.48-3.50); the launch is bound by the chip, not by its busiest CU
 
 
+_WGRAD_EARLY = 2            # round 6: stacks whose direct weight gradients are launched LAYER BY LAYER on the third stream as soon as a layer's dZ plane is final,
+                             # beside the rest of the stack's dgrad chain, instead of one grouped launch behind it (bit 0 decoder, bit 1 mel encoder).  Only where
+                             # the dgrad chain is NOT on the persistent kernel (whose workgroups own every CU's LDS: nothing co-resides): the mel encoder in bf16
+_WGRAD_EARLY_WGS = 128       # ... with this many workgroups per single-layer launch (32 tiles: 4 slabs per tile at 128)
+_TEXT_RIDERS = 1             # round 6: the last text-encoder layers ride in the mel encoder's persistent launches in the training forward too (0: every text layer a
+                             # launch of its own on the text stream; tests compare)
+_HEAD_ORDER = 1              # round 6: 1 = the mel side's launches (prenet plane, prenet, the stacks' planes) are issued FIRST and the prenet does not wait for the
+                             # stacks' planes; the gradient buffer's clear and the speech-frame pack (backward operands only) move to the text stream's idle time
+
+
 def switch_tag() -> tuple:
     """every hook above, by value: part of the tag of a captured training step"""
     return (_WGRAD_TN_SPLITS, _SIGN_MIN_ROWS, _BIAS_PARTS, _RESCONV_FWD, _RESCONV_DGRAD, _WGRAD_WGS, _PACK_SPLIT, _NARROW_TN, _EARLY_PACKS,
-            _WGRAD_GROUP_WGS, _FUSE_ACT_BWD, O.RC_KERNEL, _WGRAD_STREAM)
+            _WGRAD_GROUP_WGS, _FUSE_ACT_BWD, O.RC_KERNEL, _WGRAD_STREAM, _WGRAD_EARLY, _WGRAD_EARLY_WGS, _HEAD_ORDER, _TEXT_RIDERS)
 
 
 class _TPlane(Plane):
@@ -171,10 +181,10 @@ class TrainEngine:
         for name, lin in lins:
             if name not in self.wt:
                 self.wt[name] = PackedWeight(lin.in_features, lin.out_features, 1, m.split, dev)
-        pk = m._weights(self.folded, self.wt, self.step_params, text_stream=text_stream)
+        pk = m._weights(self.folded, self.wt, self.step_params, text_stream=text_stream, main_first=bool(_HEAD_ORDER))
         if m._folded_gen != m._packed_gen:
             m._packed_sig = None                # the last repack (an eval forward) did not write the copies kept here
-            pk = m._weights(self.folded, self.wt, self.step_params, text_stream=text_stream)
+            pk = m._weights(self.folded, self.wt, self.step_params, text_stream=text_stream, main_first=bool(_HEAD_ORDER))
         return pk
 
     # ------------------------------------------------------------------ small wrappers
@@ -234,27 +244,28 @@ class TrainEngine:
         L.check(_lib().efts_wgrad_reduce(part.data_ptr(), S, _ptr(v), _ptr(g), out_dw.data_ptr(), _ptr(out_dg), cout, cin, taps,
                                          O._stream()), "efts_wgrad_reduce")
 
-    def _wgrad_group(self, ws, items, cout, cin, rows, taps: int, split: int):
+    def _wgrad_group(self, ws, items, cout, cin, rows, taps: int, split: int, wgs: Optional[int] = None):
         """the direct weight gradients of several layers of one stack (same shape, same row space) as ONE stream-K launch and ONE
         reduction (csrc/efts_wgrad.hip `wgrad_sk_kernel`, csrc/efts_train.hip `wgrad_reduce_sk_kernel`).
         items: (dz_p, x_p, v, g, out_dw, out_dg, bias_part, dbias) per layer (more than the library takes per launch: several launches)"""
         if len(items) > L.WGRAD_MAX_ITEMS:
             for i in range(0, len(items), L.WGRAD_MAX_ITEMS):
-                self._wgrad_group(ws, items[i:i + L.WGRAD_MAX_ITEMS], cout, cin, rows, taps, split)
+                self._wgrad_group(ws, items[i:i + L.WGRAD_MAX_ITEMS], cout, cin, rows, taps, split, wgs)
             return
         lib = _lib()
         n = len(items)
+        wgs = _WGRAD_GROUP_WGS if wgs is None else wgs
         arr = (L.WgradItem * n)()
         for a, (dz_p, x_p, v, g, dw, dg, bp, db) in zip(arr, items):
             a.dz_plane, a.ldz, a.x_plane, a.ldx = dz_p.ptr, dz_p.ld, x_p.ptr, x_p.ld
             a.v, a.g, a.dw_or_dv, a.dg = _ptr(v), _ptr(g), dw.data_ptr(), _ptr(dg)
             a.bias_part, a.dbias, a.nparts = _ptr(bp), _ptr(db), 0 if bp is None else bp.shape[0]
-        nbytes = lib.efts_wgrad_grouped_part_bytes(n, rows, cout, cin, taps, split, _WGRAD_GROUP_WGS)
+        nbytes = lib.efts_wgrad_grouped_part_bytes(n, rows, cout, cin, taps, split, wgs)
         if nbytes < 0:
             L.check(-1, "efts_wgrad_grouped_part_bytes")
-        part = ws.get(("gpart", self._ws_tag, n, rows, cout, cin, taps, split, _WGRAD_GROUP_WGS), lambda: torch.empty(nbytes // 4, device=self.dev))
-        L.check(lib.efts_wgrad_tn_grouped(arr, n, part.data_ptr(), rows, cout, cin, taps, split, _WGRAD_GROUP_WGS, O._stream()), "efts_wgrad_tn_grouped")
-        L.check(lib.efts_wgrad_reduce_grouped(arr, n, part.data_ptr(), rows, cout, cin, taps, split, _WGRAD_GROUP_WGS, O._stream()),
+        part = ws.get(("gpart", self._ws_tag, n, rows, cout, cin, taps, split, wgs), lambda: torch.empty(nbytes // 4, device=self.dev))
+        L.check(lib.efts_wgrad_tn_grouped(arr, n, part.data_ptr(), rows, cout, cin, taps, split, wgs, O._stream()), "efts_wgrad_tn_grouped")
+        L.check(lib.efts_wgrad_reduce_grouped(arr, n, part.data_ptr(), rows, cout, cin, taps, split, wgs, O._stream()),
                 "efts_wgrad_reduce_grouped")
 
     @staticmethod
@@ -277,30 +288,52 @@ class TrainEngine:
         return True
 
     # ------------------------------------------------------------------ forward with saved activations
-    def _stack_fwd(self, ws, tag, blk, pk, rs, x_f, x_p, gap_ptr, last_split):
+    def _rc_layer(self, ws, tag, blk, pk, rs, i, x_f, x_p, x_lo, gap_ptr, last_split):
+        """layer i of a stack on efts_resconv5 in the training forward: (keyword set of the launch, what the backward keeps, fp32 output or None,
+        output plane, output remainder plane).  The stream between the layers is hi + lo bf16 planes (every hi plane is kept: it is the layer's
+        operand in the wgrad), the activation's sign leaves the epilogue as bit rows (efts_act_bwd mode 5); fp32 only into the first such layer
+        (x_f: the producer's stream) and out of the last one"""
+        m, C = self.m, self.m.n_channels
+        layers = getattr(m, blk).layers
+        last = i == len(layers) - 1
+        o_split = last_split if last else m.split
+        o_p = ws.plane(f"T{tag}_p{i}", rs, C, o_split)
+        o_l = ws.plane(f"T{tag}_l{i & 1}", rs, C, 1) if (o_split == 1 and not last) else None
+        o_f = ws.f32(f"T{tag}_f{len(layers) - 1}", rs, C) if last else None
+        sg = ws.tensor(f"T{tag}_sb{i}", (rs.rows, C // 8), torch.uint8)
+        kw = dict(x=x_p, x_lo=x_lo, x_f32_ptr=None if x_f is None else x_f.ptr, ldr=C, w=pk[f"{blk}.{i}"], taps=m.k_size, m=rs.rows, n=C,
+                  bias=layers[i].conv[0].bias, slope=m.slope, rowmask_ptr=gap_ptr, y_f32_ptr=None if o_f is None else o_f.ptr, ldo=C,
+                  y=o_p, y_lo=o_l, sign_bits_ptr=sg.data_ptr())
+        return kw, (None, None, x_p, (sg, 5), 0.0, 0), o_f, o_p, o_l
+
+    def _rc_forward_ok(self, tag, rs) -> bool:
+        m = self.m
+        return bool((_RESCONV_FWD & dict(dec=1, me=2, te=0)[tag]) and m._on_resconv(rs) and self._conv_drop(0)[0] == 0.0 and _WGRAD_TN_SPLITS > 0
+                    and m.n_channels % 128 == 0)
+
+    def _stack_fwd(self, ws, tag, blk, pk, rs, x_f, x_p, gap_ptr, last_split, stop: Optional[int] = None, rider=None):
+        """stop: only layers [0, stop) (on efts_gemm: the first text-encoder layers, whose successors ride in the mel encoder's launches);
+        rider(i): keyword set of an independent layer that shares layer i's persistent launch (efts_resconv5_multi), or None"""
         m, C = self.m, self.m.n_channels
         saved = []
         layers = getattr(m, blk).layers
-        if (_RESCONV_FWD & dict(dec=1, me=2, te=0)[tag]) and m._on_resconv(rs) and self._conv_drop(0)[0] == 0.0 and _WGRAD_TN_SPLITS > 0 and C % 128 == 0:
-            # mel-length stack on efts_resconv5 (the inference kernel): the stream between the layers is hi + lo bf16 planes (every
-            # hi plane is kept: it is the layer's operand in the wgrad), the activation's sign leaves the epilogue as bit rows
-            # (efts_act_bwd mode 5); fp32 only into the first layer (the producer's stream) and out of the last one
-            n = len(layers)
-            x_lo = None
-            for i, layer in enumerate(layers):
-                last = i == n - 1
-                o_split = last_split if last else m.split
-                o_p = ws.plane(f"T{tag}_p{i}", rs, C, o_split)
-                o_l = ws.plane(f"T{tag}_l{i & 1}", rs, C, 1) if (o_split == 1 and not last) else None
-                o_f = ws.f32(f"T{tag}_f{n - 1}", rs, C) if last else None
-                sg = ws.tensor(f"T{tag}_sb{i}", (rs.rows, C // 8), torch.uint8)
-                O.resconv5(x=x_p, x_lo=x_lo, x_f32_ptr=x_f.ptr if i == 0 else None, ldr=C, w=pk[f"{blk}.{i}"], taps=m.k_size, m=rs.rows, n=C,
-                           bias=layer.conv[0].bias, slope=m.slope, rowmask_ptr=gap_ptr, y_f32_ptr=None if o_f is None else o_f.ptr, ldo=C,
-                           y=o_p, y_lo=o_l, sign_bits_ptr=sg.data_ptr())
-                saved.append((None, None, x_p, (sg, 5), 0.0, 0))
+        if stop is None and self._rc_forward_ok(tag, rs):
+            # mel-length stack on efts_resconv5 (the inference kernel)
+            x_lo, o_f = None, None
+            for i in range(len(layers)):
+                kw, keep, o_f, o_p, o_l = self._rc_layer(ws, tag, blk, pk, rs, i, x_f if i == 0 else None, x_p, x_lo, gap_ptr, last_split)
+                extra = rider(i) if rider is not None else None
+                if extra is not None:
+                    O.resconv5_multi([kw, extra])
+                else:
+                    O.resconv5(**kw)
+                saved.append(keep)
                 x_p, x_lo = o_p, o_l
             return o_f, x_p, saved
+        assert rider is None
         for i, layer in enumerate(layers):
+            if stop is not None and i >= stop:
+                break
             last = i == len(layers) - 1
             w = pk[f"{blk}.{i}"]
             o_f = ws.f32(f"T{tag}_f{i}", rs, C)
@@ -350,6 +383,10 @@ class TrainEngine:
         group = []                                               # (grouped direct wgrads: every layer keeps its dZ plane and bias sums until the stack is through)
         on_rc = bool((_RESCONV_DGRAD if _RESCONV_DGRAD >= 0 else (1 if m.split == 1 else 3)) & dict(dec=1, me=2, te=0)[tag]) and m._on_resconv(rs)
         fused = None                                             # (dZ plane, bias sums) of layer i the dgrad launch of layer i + 1 has already written
+        # layer-by-layer weight gradients beside the dgrad chain (round 6): a layer's operands -- its dZ plane, its input plane, its bias sums -- are
+        # final as soon as its activation backward has run, i.e. BEFORE its own dgrad launch; where the dgrad kernel leaves half a CU's LDS free
+        # (conv5_kernel / gemm_kernel: 80 KiB) a weight-gradient workgroup co-resides and the two kinds of launch share the matrix pipes
+        early = wgrad_stream is not None and bool(_WGRAD_EARLY & dict(dec=1, me=2, te=0)[tag]) and not on_rc
         for i in reversed(range(len(layers))):
             x_f, y_f, x_pl, sg, dp, dseed = saved[i]
             conv = layers[i].conv[0]
@@ -378,7 +415,10 @@ class TrainEngine:
             wn = hasattr(conv, "weight_g")
             v_, g_ = (conv.weight_v.detach(), conv.weight_g.detach()) if wn else (None, None)
             dw_, dg_ = (self.g[pre + "weight_v"], self.g[pre + "weight_g"]) if wn else (self.g[pre + "weight"], None)
-            if direct:
+            if direct and early:
+                with self._forked(wgrad_stream):
+                    self._wgrad_group(ws, [(dz_p, x_pl, v_, g_, dw_, dg_, bp, self.g[pre + "bias"])], C, C, rs.rows, m.k_size, m.split, _WGRAD_EARLY_WGS)
+            elif direct:
                 group.append((dz_p, x_pl, v_, g_, dw_, dg_, bp, self.g[pre + "bias"]))
             else:
                 self._wgrad(ws, dz_f.ptr, C, x_f.ptr, C, C, m.k_size, rs.rows, v_, g_, dw_, dg_)
@@ -444,7 +484,8 @@ class TrainEngine:
         if side0 is not None:
             side0.wait_stream(torch.cuda.current_stream(dev))
         pk = self._prepare_weights(text_stream=side0)
-        self.flat.zero_()
+        if not _HEAD_ORDER:
+            self.flat.zero_()
 
         # Two HIP streams.  The text-length work (embedding, text encoder, K/V, duration predictor and all of their
         # backward) runs on ~B*T1 = 4k rows: launches of 70-270 workgroups that leave most of the chip idle.  None of it
@@ -477,11 +518,97 @@ class TrainEngine:
             seed0, seed1 = (self.seed_base + 2 * self.drop_calls) & 0xFFFFFFFF, (self.seed_base + 2 * self.drop_calls + 1) & 0xFFFFFFFF
 
         # ============================ forward (efficient_tts.py:144-227), activations kept
+        mel_in_f, mel_in = ws.f32("Tmel_in_f", rs2, odim), ws.plane("Tmel_in", rs2, odim, split)
+        pre_dp, pre_seed = self._conv_drop(40)                       # mel_prenet's Dropout (efficient_tts.py:76-80)
+        prenet_from_frames = m.act_general is None and pre_dp == 0.0 and m.fuse_prenet and odim % 8 == 0 and odim <= 128 and C % 128 == 0
+        late_head = bool(_HEAD_ORDER) and prenet_from_frames
+        # text-encoder layers as RIDERS of the mel encoder's persistent launches (round 6; the inference pass has done this since round 3,
+        # model._forward_body): the last min(nt, nm) text layers share the launches of the mel-encoder layers (efts_resconv5_multi: +22 us per
+        # launch instead of a 33 us launch of their own that must not run beside a persistent launch), the first nt - nr run by themselves on
+        # the text stream while the prenet runs on this one.  Their stream between the layers is then hi + lo bf16 planes like the mel stacks'.
+        nt, nm = len(m.text_encoder.layers), len(m.mel_encoder.layers)
+        nr = min(nt, nm) if (_TEXT_RIDERS and m.act_general is None and self._rc_forward_ok("me", rs2) and nt >= 1) else 0
+        ns = nt - nr
+        ev_te_head, ev_te_done = torch.cuda.Event(), torch.cuda.Event()
+        tstate = {}
+
+        def prenet():
+            """mel_prenet (efficient_tts.py:161) on the main stream"""
+            if not late_head:
+                O.pack_rows(speech, mel_in_f, mel_in, rs2)          # (the backward's wgrad of the prenet reads both)
+            pre_f, pre_p = ws.f32("Tpre_f", rs2, C), ws.plane("Tpre_p", rs2, C, split)
+            wp = pk["prenet"]
+            pre_z = None
+            if m.act_general is not None:
+                pre_z = ws.f32("Tpre_z", rs2, C)
+                O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, bias=m.mel_prenet[0].bias, out_f32_ptr=pre_z.ptr, ldo=C)
+                O.act_apply(m.act_general, pre_z.ptr, None, gap2.data_ptr(), pre_f, pre_p, rs2.rows, C, pre_dp, pre_seed)
+            elif prenet_from_frames:
+                # no Dropout on the prenet (the shipped recipe): straight from the caller's frames, whole-line stores (efts_frame_linear;
+                # bit-identical to the launch below)
+                O.frame_linear(x=speech, w=wp, bias=m.mel_prenet[0].bias, act=L.ACT_LEAKY, slope=m.slope, rs=rs2, y=pre_p, y_f32=pre_f)
+            else:
+                O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, act=L.ACT_LEAKY, slope=m.slope, bias=m.mel_prenet[0].bias,
+                       rowmask_ptr=gap2.data_ptr(), out_f32_ptr=pre_f.ptr, ldo=C, out_plane=pre_p, drop_p=pre_dp, drop_seed=pre_seed)
+            return pre_f, pre_p, pre_z
+
+        def text_rider(i):
+            """keyword set of the text-encoder layer that rides in mel-encoder layer i's launch (layer ns + i - (nm - nr)), or None"""
+            if i < nm - nr:
+                return None
+            j = ns + i - (nm - nr)
+            kw, keep, o_f, o_p, o_l = self._rc_layer(ws, "te", "text_encoder", pk, rs1, j, tstate["x_f"], tstate["x_p"], tstate["x_lo"], gap1.data_ptr(), split)
+            tstate["saved"].append(keep)
+            tstate.update(x_f=None, x_p=o_p, x_lo=o_l, o_f=o_f)
+            return kw
+
+        def mel_stack(pre_f, pre_p):
+            """mel encoder (+ mel_query_fc) (efficient_tts.py:162-164) on the main stream"""
+            if nr:
+                main.wait_event(ev_te_head)                          # the riders' input: the text stream's first layers (or the embedding)
+            rider = text_rider if nr else None
+            mh_f = mh_p = None
+            if m.mel_query_fc is None:
+                q_f, q_p, me_saved = self._stack_fwd(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2, rider=rider)
+            else:                                                   # efficient_tts.py:163-164: Linear(C, C) in front of the attention
+                mh_f, mh_p, me_saved = self._stack_fwd(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), split, rider=rider)
+                q_f, q_p = ws.f32("Tq_f", rs2, C), ws.plane("Tq_p", rs2, C, 2)
+                wq = pk["qfc"]
+                O.gemm(a=mh_p, b_ptr=wq.ptr, ldb=wq.ld, m=rs2.rows, n=C, bias=m.mel_query_fc.bias, rowmask_ptr=gap2.data_ptr(),
+                       out_f32_ptr=q_f.ptr, ldo=C, out_plane=q_p)
+            if nr:
+                ev_te_done.record(main)
+            if self.mark is not None:
+                self.mark("fwd_mel_encoder_done")
+            return q_f, q_p, me_saved, mh_f, mh_p
+
+        def text_head():
+            """embedding + the text-encoder layers that run by themselves (all of them without riders), on the text stream"""
+            with O.on_stream(side):
+                self._ws_tag = "s"
+                emb_f, emb_p = ws.f32("Temb_f", rs1, C), ws.plane("Temb_p", rs1, C, split)
+                O.embed(text, m.text_embedding_table.weight.detach(), emb_f, emb_p, rs1)
+                x_f, x_p, saved = self._stack_fwd(ws, "te", "text_encoder", pk, rs1, emb_f, emb_p, gap1.data_ptr(), split, stop=ns if nr else None)
+                if nr:
+                    tstate.update(x_f=x_f, x_p=x_p, x_lo=None, saved=saved, o_f=None)
+                    ev_te_head.record(side)
+                self._ws_tag = ""
+            return x_f, x_p, saved
+
+        if _HEAD_ORDER or nr:
+            # the mel side is issued in FRONT of the text side's launches: it is the longer of the two chains between the optimizer and the attention
+            pre_f, pre_p, pre_z = prenet()
+            te_f, te_p, te_saved = text_head()
+            q_f, q_p, me_saved, mh_f, mh_p = mel_stack(pre_f, pre_p)
+        else:
+            te_f, te_p, te_saved = text_head()
+            pre_f, pre_p, pre_z = prenet()
+            q_f, q_p, me_saved, mh_f, mh_p = mel_stack(pre_f, pre_p)
+        if nr:
+            te_f, te_p, te_saved = tstate["o_f"], tstate["x_p"], tstate["saved"]
+            side.wait_event(ev_te_done)
         with O.on_stream(side):
             self._ws_tag = "s"
-            emb_f, emb_p = ws.f32("Temb_f", rs1, C), ws.plane("Temb_p", rs1, C, split)
-            O.embed(text, m.text_embedding_table.weight.detach(), emb_f, emb_p, rs1)
-            te_f, te_p, te_saved = self._stack_fwd(ws, "te", "text_encoder", pk, rs1, emb_f, emb_p, gap1.data_ptr(), split)
             key_f, key_p = ws.f32("Tkey_f", rs1, C), ws.plane("Tkey_p", rs1, C, 2)
             val_f, val_p = ws.f32("Tval_f", rs1, C), ws.plane("Tval_p", rs1, C, split)
             shared = m.share_text_encoder_key_value                 # efficient_tts.py:150-153: the value is the key projection
@@ -489,6 +616,8 @@ class TrainEngine:
             wv = wk if shared else pk["value"]
             O.gemm(a=te_p, b_ptr=wk.ptr, ldb=wk.ld, m=rs1.rows, n=C, bias=m.text_encoder_key.bias, rowmask_ptr=len1.data_ptr(),
                    out_f32_ptr=key_f.ptr, ldo=C, out_plane=key_p)
+            ev_k = torch.cuda.Event()
+            ev_k.record(side)
             O.gemm(a=te_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=(m.text_encoder_key if shared else m.text_encoder_value).bias,
                    rowmask_ptr=len1.data_ptr(), out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p)
             ev_kv = torch.cuda.Event()
@@ -506,39 +635,19 @@ class TrainEngine:
                    bias=dp.conv[1][0].bias, out_f32_ptr=h2_f.ptr, ldo=C)
             O.layernorm_dot(h2_f.ptr, ln1.weight.detach(), ln1.bias.detach(), ln1.eps, dp.linear.weight.detach(),
                             dp.linear.bias.detach(), len1.data_ptr(), 0, float(dp.offset), dur, rs1.rows, C, drop_p, seed1, sadd)
+            if _HEAD_ORDER:
+                # the gradient buffer's clear: first written by the backward, which the main stream starts behind `ev_dur` (and every other
+                # stream forks from the main stream after that)
+                self.flat.zero_()
+            if late_head:
+                # the prenet reads the caller's frames itself (efts_frame_linear): the packed copy of the frames is an operand of the BACKWARD only
+                # (the prenet's weight gradient), so it is made here, in the text stream's idle time, instead of in front of the mel encoder
+                O.pack_rows(speech, mel_in_f, mel_in, rs2)
             ev_dur = torch.cuda.Event()
             ev_dur.record(side)
             self._ws_tag = ""
 
-        mel_in_f, mel_in = ws.f32("Tmel_in_f", rs2, odim), ws.plane("Tmel_in", rs2, odim, split)
-        O.pack_rows(speech, mel_in_f, mel_in, rs2)                  # (the backward's wgrad of the prenet reads both)
-        pre_f, pre_p = ws.f32("Tpre_f", rs2, C), ws.plane("Tpre_p", rs2, C, split)
-        wp = pk["prenet"]
-        pre_dp, pre_seed = self._conv_drop(40)                       # mel_prenet's Dropout (efficient_tts.py:76-80)
-        pre_z = None
-        if m.act_general is not None:
-            pre_z = ws.f32("Tpre_z", rs2, C)
-            O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, bias=m.mel_prenet[0].bias, out_f32_ptr=pre_z.ptr, ldo=C)
-            O.act_apply(m.act_general, pre_z.ptr, None, gap2.data_ptr(), pre_f, pre_p, rs2.rows, C, pre_dp, pre_seed)
-        elif pre_dp == 0.0 and m.fuse_prenet and odim % 8 == 0 and odim <= 128 and C % 128 == 0:
-            # no Dropout on the prenet (the shipped recipe): straight from the caller's frames, whole-line stores (efts_frame_linear;
-            # bit-identical to the launch below)
-            O.frame_linear(x=speech, w=wp, bias=m.mel_prenet[0].bias, act=L.ACT_LEAKY, slope=m.slope, rs=rs2, y=pre_p, y_f32=pre_f)
-        else:
-            O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, act=L.ACT_LEAKY, slope=m.slope, bias=m.mel_prenet[0].bias,
-                   rowmask_ptr=gap2.data_ptr(), out_f32_ptr=pre_f.ptr, ldo=C, out_plane=pre_p, drop_p=pre_dp, drop_seed=pre_seed)
-        if m.mel_query_fc is None:
-            q_f, q_p, me_saved = self._stack_fwd(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2)
-        else:                                                       # efficient_tts.py:163-164: Linear(C, C) in front of the attention
-            mh_f, mh_p, me_saved = self._stack_fwd(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), split)
-            q_f, q_p = ws.f32("Tq_f", rs2, C), ws.plane("Tq_p", rs2, C, 2)
-            wq = pk["qfc"]
-            O.gemm(a=mh_p, b_ptr=wq.ptr, ldb=wq.ld, m=rs2.rows, n=C, bias=m.mel_query_fc.bias, rowmask_ptr=gap2.data_ptr(),
-                   out_f32_ptr=q_f.ptr, ldo=C, out_plane=q_p)
-        if self.mark is not None:
-            self.mark("fwd_mel_encoder_done")
-
-        main.wait_event(ev_kv)                                      # K, V from the side stream
+        main.wait_event(ev_k)                                       # K from the text stream (V: in front of the expand launch)
         scale = O.INV_SQRT(C)
         scores = ws.tensor("Tscores", (B, T2, T1))
         O.gemm(a=q_p, b_ptr=key_p.ptr, ldb=key_p.ld, m=T2, n=T1, batch=B, a_batch_stride=rs2.Tp * q_p.ld,
@@ -555,6 +664,7 @@ class TrainEngine:
                 O.duration_target(e, tl, ml, float(m.duration_offset), False, lde, B, T1)
         ralpha = ws.tensor("Tralpha", (B, T1, T2))
         h_f, h_p = ws.f32("Texp_f", rs2, C), ws.plane("Texp_p", rs2, C, split)
+        main.wait_event(ev_kv)                                      # V from the text stream
         if m._fused_expand(T1):
             # alpha' produced in registers inside the expand contraction (efts_expand); the backward packs its own operands from
             # the fp32 alpha' kept here

@@ -80,6 +80,62 @@ def test_bucketed_allreduce_two_ranks_gloo(golden_dir, tmp_path):
     assert open(out).read() == "ok"
 
 
+def _worker8(rank, world, port, ends, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from efficient_tts_amd.dist import BucketReducer
+    numel = ends[-1]
+    # integer-valued "gradients" (exact in fp32 under any summation order): element i of rank r = (i mod 251) - 125 + 3 r
+    base = (torch.arange(numel, dtype=torch.int64) % 251 - 125).float()
+    want = base * world + 3.0 * sum(range(world))
+    ok, notes = True, []
+    for algo in ("allreduce", "rs_ag"):
+        flat = base + 3.0 * rank
+        red = BucketReducer(flat, ends, algo=algo)
+        if algo == "rs_ag":      # every bucket is padded to a multiple of the world size; none of the real buckets is one
+            notes.append([int(p.numel()) for p in red.pad])
+            ok &= all(p.numel() % world == 0 and p.numel() - (e - s) < world for p, s, e in zip(red.pad, red.starts, red.ends))
+        for i in reversed(range(len(ends))):          # any hand-over order: buckets are independent slices
+            red.reduce(i)
+        red.finish()
+        ok &= bool(torch.equal(flat, want))
+    if rank == 0:
+        open(out, "w").write("ok" if ok else f"mismatch {notes}")
+    dist.destroy_process_group()
+
+
+def test_bucketed_exchange_eight_ranks_gloo(tmp_path):
+    """world 8 (the node BASELINE config 4 names) over gloo: both exchange algorithms on the model's REAL bucket boundaries -- 20 587 601
+    gradients, an odd number, in three buckets of which the middle one is odd, and then a layout whose three buckets leave remainders 1, 3
+    and 7 modulo 8, so `rs_ag` runs on its padded staging buffers with ragged tails -- must produce the exact sum on every element (integer-valued inputs: exact under any order)."""
+    from efficient_tts_amd import EfficientTTSCNN
+    from efficient_tts_amd.train import grad_layout
+    m = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, sigma=0.01)
+    layout = grad_layout(m)
+    last_dec = [k for k, _ in layout if k.startswith("decoder.layers.0.")][-1]
+    last_pre = [k for k, _ in layout if k.startswith("mel_prenet.")][-1]
+    ends, acc = [], 0
+    for n, p in layout:                      # the three stages of TrainEngine.bucket_ends
+        acc += p.numel()
+        if n in (last_dec, last_pre):
+            ends.append(acc)
+    ends.append(acc)
+    assert ends[-1] == 20587601 and len(ends) == 3
+    sizes = [e - s for s, e in zip([0] + ends[:-1], ends)]
+    assert any(sz % 8 for sz in sizes), sizes             # the premise: the real layout has a bucket (the middle one, 5 553 153) with a ragged tail
+    out = str(tmp_path / "res8.txt")
+    mp.spawn(_worker8, args=(8, _free_port(), ends, out), nprocs=8, join=True)
+    assert open(out).read() == "ok"
+    # and a layout in which EVERY bucket leaves a different remainder modulo 8 (1, 3, 7 elements short of / over a multiple)
+    ragged = [1000001, 1000001 + 2000003, 1000001 + 2000003 + 1500007]
+    assert [(e - s) % 8 for s, e in zip([0] + ragged[:-1], ragged)] == [1, 3, 7]
+    mp.spawn(_worker8, args=(8, _free_port(), ragged, out), nprocs=8, join=True)
+    assert open(out).read() == "ok"
+
+
 def test_grad_layout_is_backward_completion_order():
     from efficient_tts_amd import EfficientTTSCNN
     from efficient_tts_amd.train import grad_layout

@@ -191,6 +191,53 @@ def test_bench_dp_record_two_ranks():
         assert dp["selfcheck"]["replicas_bit_identical_after_graph_replays"]
 
 
+def _bench_worker8(rank, port, out):
+    import sys
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=8)
+    from efficient_tts_amd.bench_train import measure_train
+    for algo in ("allreduce", "rs_ag"):
+        a = types.SimpleNamespace(precision="bf16", train_set=[], dp_algo=algo, train_graph=0, allow_gloo=True)
+        rec = measure_train(a, 8, rank, dev, dict(B=2, T1=24, T2=70, desc="test shape"), steps=2, warmup=2)
+        if rank == 0:
+            with open(out + "." + algo, "w") as f:
+                json.dump(rec, f)
+        else:
+            assert rec is None
+    dist.destroy_process_group()
+
+
+def test_bench_dp_record_eight_ranks():
+    """world 8 -- the node BASELINE config 4 names -- through the data-parallel measurement, eight ranks sharing the test GPU over gloo at
+    a reduced batch, both exchange algorithms (20 587 601 gradients: `rs_ag` pads its odd middle bucket to a multiple of 8): eight distinct
+    seeds and batches, replicas bit-identical after the optimisation steps, the record's own efficiency and exposed-exchange figures."""
+    import tempfile
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "rec.json")
+        mp.spawn(_bench_worker8, args=(port, out), nprocs=8, join=True)
+        recs = {algo: json.load(open(out + "." + algo)) for algo in ("allreduce", "rs_ag")}
+    for algo, rec in recs.items():
+        dp = rec["dp"]
+        assert rec["n_gpus"] == 8 and rec["config"]["parallelism"] == "dp8" and dp["ranks"] == 8 and dp["algo"] == algo
+        sc = dp["selfcheck"]
+        assert sc["replicas_bit_identical"] and sc["seeds"] == [1234 + r for r in range(8)] and sc["batches_distinct"]
+        assert len(dp["bucket_ms"]) == 3 and abs(sum(dp["bucket_mb"]) - 82.35) < 0.01
+        assert dp["step_ms_no_exchange"] > 0 and 0.0 < dp["efficiency"] < 1.5 and dp["exposed_ms"] >= 0
+        assert abs(dp["efficiency"] - dp["step_ms_no_exchange"] / dp["step_ms_with_exchange"]) < 1e-9
+        # 2 (N - 1) / N = 1.75 at N = 8 in the bus-bandwidth figures
+        assert all(abs(b - 1.75 * m / t) < 1e-6 for b, m, t in zip(dp["bucket_busbw_gbps"], dp["bucket_mb"], dp["bucket_ms"]))
+    # the two algorithms average the same gradients: same parameters after the same steps (sums of 8 fp32 values in different orders: equal
+    # up to rounding, so the fingerprints may differ; the losses of the last step agree)
+    assert abs(recs["allreduce"]["loss"] - recs["rs_ag"]["loss"]) <= 1e-4 * abs(recs["allreduce"]["loss"])
+
+
 def test_bench_two_ranks_end_to_end():
     """`python bench.py --gpus 2` as the driver's multi-GPU runs execute it -- self-launched ranks, replica forward in both precisions,
     then the data-parallel training record on every rank -- on the ONE GPU of the test box: EFTS_BENCH_BACKEND=gloo lets the two ranks share
@@ -214,3 +261,27 @@ def test_bench_two_ranks_end_to_end():
     # the collective path lifted to the top level of the N > 1 line
     assert rec["dp_value"] == tr["value"] and rec["dp_ms_per_step"] == tr["ms_per_step"] and rec["dp_efficiency"] == tr["dp"]["efficiency"] > 0
     assert rec["dp_exposed_ms"] == tr["dp"]["exposed_ms"] and "exchange" in rec["dp_note"]
+
+
+def test_bench_eight_ranks_end_to_end():
+    """`python bench.py --gpus 8` -- the driver's widest multi-GPU run -- with the eight self-launched ranks sharing the ONE test GPU over gloo
+    (EFTS_BENCH_BACKEND=gloo; RCCL needs a GPU per rank) at a reduced shape (--test-shape): one JSON line, n_gpus 8, eight replicas of the
+    forward, and the data-parallel record lifted to the top level: dp_efficiency, dp_exposed_ms, eight distinct seeds / batches, replicas
+    bit-identical after the optimisation steps."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["EFTS_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--parity-mode", "0",
+                          "--test-shape", "2,24,70"], env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["config"]["parallelism"] == "replicas x8" and "TEST SHAPE" in rec["config"]["workload"]
+    tr = rec["train32"]
+    dp = tr["dp"]
+    assert tr["n_gpus"] == 8 and tr["config"]["parallelism"] == "dp8" and dp["ranks"] == 8 and tr["steps"] == 2
+    assert dp["selfcheck"]["replicas_bit_identical"] and dp["selfcheck"]["seeds"] == [1234 + r for r in range(8)] and dp["selfcheck"]["batches_distinct"]
+    assert rec["dp_efficiency"] == dp["efficiency"] > 0 and rec["dp_exposed_ms"] == dp["exposed_ms"] >= 0 and rec["dp_value"] == tr["value"] > 0
