@@ -20,6 +20,12 @@ RCCL's own topology lines, bit-exact replica check).  `--workload train32` times
 protected from that record: an exception in it costs the record (`train32.error`), a hang is cut after EFTS_BENCH_DP_TIMEOUT
 (240) seconds by a watchdog that prints the line with what there is and ends every rank.
 
+The default line (N = 1, fwd64) carries every BASELINE config under the one invocation the driver times (round 6): `parity_mode` (bf16x3, the 1e-3 grade,
+same K / W), `long16` (config 5: B=16 x (128, 1200), both precisions), `infer64` (config 2-ii: batched free-running inference), `infer_lj` (config 1: ten
+LJSpeech utterances one by one, + end-to-end with the vocoder), `train32` (config 3, + its parity mode), each with ms_per_step, roofline, the oracle as
+checker (hip_vs_oracle_mel_max_abs) and a bounded CPU leg; and `stock_gpu_baseline`: the oracle's plain torch ops on THIS GPU (MIOpen / hipBLASLt, fp32 and
+bf16 autocast; forward B=64 and training step B=32) -- a second baseline leg beside `cpu_baseline`, never the product.
+
 Prints ONE JSON line on rank 0, with `roofline` for the dominant kernel (the k5 Conv1d contraction at mel length, measured with HIP
 events on the launch stream inside the timed region; `traffic` from two rocprofv3 PMC child passes) and `cpu_baseline` (the
 oracle's CPU restatement timed on this box's host cores on a bounded sample).
@@ -217,8 +223,8 @@ def stock_gpu_baseline(dev, find=False, budget_s=45.0, T1=128, T2=800):
         return (time.perf_counter() - t0) / n
 
     try:
+        P = {k: v.to(dev) for k, v in O.fill_params().items()}     # (filled on the host: the fill's generators are CPU generators)
         with torch.device(dev):                  # the oracle's torch.arange / zeros land on the GPU
-            P = {k: v.to(dev) for k, v in O.fill_params().items()}
             tl, sl = lens(64)
             for name, ac in (("fwd64_fp32", False), ("fwd64_bf16_autocast", True)):
                 if time.perf_counter() - t_start > budget_s:
@@ -419,6 +425,25 @@ def run_infer64(a, world, rank, dev, sub=None):
         if check is not None:
             res["hip_vs_oracle_mel_max_abs"] = check
             res["hip_vs_oracle_note"] = f"items 0 and 1 of the batch against the oracle's B = 1 inference() with the same weights and forced durations; precision {a.precision} (1e-3 applies to bf16x3)"
+        if a.precision == "bf16" and a.parity_mode and world == 1:
+            # the parity-grade mode under the same clock: bf16x3, same weights, same K / W
+            mp = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, sigma=0.01, precision="bf16x3")
+            mp = mp.to(dev).eval()
+            mp.remove_weight_norm()
+            mp.load_state_dict({k: v.detach() for k, v in model.state_dict().items()})
+            for _ in range(max(a.warmup, 1)):
+                mp.inference_batch(text, tl, force_delta=T2 / T1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                mp.inference_batch(text, tl, force_delta=T2 / T1)
+            torch.cuda.synchronize()
+            dtp = (time.perf_counter() - t0) / a.steps
+            res["parity_mode"] = dict(precision="bf16x3", ms_per_step=dtp * 1e3, value=B * T2 / dtp, tolerance=1e-3)
+            if check is not None:
+                gotp = mp.inference_batch(text, tl, force_delta=T2 / T1)[0][:2].detach().cpu()
+                res["parity_mode"]["hip_vs_oracle_mel_max_abs"] = float(max((gotp[0] - ref0[0]).abs().max(), (gotp[1] - ref1[0]).abs().max()))
+            del mp
         if sub is not None:
             return res
         print(json.dumps(res), flush=True)
@@ -519,13 +544,59 @@ def run_vocoder(a, world, rank, dev):
         ch, length = ch // 2, length * u
         fl += sum(2 * ch * ch * kk * 6 for kk in cfg["resblock_kernel_sizes"]) * length
     fl += 2 * ch * 7 * length
+    # roofline (round 6): every efts_gemm launch of two eager passes bracketed by HIP events, grouped by (taps, rows, cout): per group the share of
+    # the call, TFLOP/s against the bf16 MFMA peak and algorithmic GB/s (operand plane in, fp32 stream + operand plane out, weights) against HBM;
+    # `roofline` = the group with the largest share, bound by whichever of its two fractions is the larger
+    from efficient_tts_amd import ops as Pops
+    keep_g, model.graphs = model.graphs, False
+    model(mel)
+    torch.cuda.synchronize()
+    Pops.PROFILE, Pops.PROFILE_TAG = [], None
+    Pops.PROFILE_INFO.clear()
+    for _ in range(2):
+        model(mel)
+    torch.cuda.synchronize()
+    groups = {}
+    for tag, s0, s1 in Pops.PROFILE:
+        groups.setdefault(tag, []).append(s0.elapsed_time(s1) * 1e-3)
+    info = dict(Pops.PROFILE_INFO)
+    Pops.PROFILE, Pops.PROFILE_TAG = None, None
+    model.graphs = keep_g
+    sp = model.split
+    rows_out = []
+    total_gemm = sum(sum(v) for v in groups.values()) / 2
+    for (taps, m_, n_), ds in groups.items():
+        k_, _, _ = info[(taps, m_, n_)]
+        per = sum(ds) / len(ds)
+        flop_l = 2.0 * m_ * n_ * k_ * taps
+        bytes_l = m_ * k_ * 2 * sp + m_ * n_ * (4 + 2 * sp) + taps * n_ * k_ * 2 * sp
+        rows_out.append(dict(taps=taps, rows=m_, cout=n_, cin=k_, launches_per_call=len(ds) // 2, avg_launch_us=per * 1e6, share_of_gemm_time=sum(ds) / 2 / total_gemm,
+                             tflops=flop_l / per / 1e12, mfma_frac=(3 if sp == 2 else 1) * flop_l / per / 1e12 / PEAK_MFMA_BF16_TFLOPS,
+                             algorithmic_gbs=bytes_l / per / 1e9, hbm_frac=bytes_l / per / 1e9 / PEAK_HBM_GBS))
+    rows_out.sort(key=lambda r: -r["share_of_gemm_time"])
+    top = rows_out[0] if rows_out else None
+    roof = None
+    if top is not None:
+        mf = top["tflops"] / PEAK_MFMA_BF16_TFLOPS
+        bound = "hbm" if top["hbm_frac"] > mf else "mfma"
+        roof = dict(bound=bound, kernel=f"gemm_kernel (efts_gemm): the generator's Conv1d launches of {top['taps']} taps, {top['cin']} -> {top['cout']} channels over {top['rows']} rows "
+                                       f"({top['launches_per_call']} per call, {100 * top['share_of_gemm_time']:.0f} % of the contraction time)",
+                    achieved=top["algorithmic_gbs"] if bound == "hbm" else top["tflops"], peak=PEAK_HBM_GBS if bound == "hbm" else PEAK_MFMA_BF16_TFLOPS,
+                    unit="GB/s" if bound == "hbm" else "TFLOP/s", frac=top["hbm_frac"] if bound == "hbm" else mf, traffic=None,
+                    avg_launch_us=top["avg_launch_us"], launches_measured=2 * top["launches_per_call"], groups=rows_out[:6],
+                    contraction_ms_per_call=total_gemm * 1e3,
+                    note="algorithmic bytes per launch = operand plane in + fp32 stream and operand plane out + weights; traffic (PMC) not collected for this row")
     if rank == 0:
         res = dict(metric=f"mel-frames/sec (HiFi-GAN V1 generator, {NB} x 800-frame utterance per step)", value=world * NB * T2 / dt,
                    unit="mel-frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt * 1e3, higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype=a.precision if a.precision == "bf16" else "bf16x3 (split-bf16 MFMA, fp32-class)",
                    data="synthetic", config={"workload": f"HiFi-GAN V1 generator, mel [{NB}, 80, 800] -> {NB} x 204800 samples", "mel_len": T2,
                                               "precision": a.precision, "parallelism": f"replicas x{world}"},
-                   rtf=dt / (NB * T2 * 256 / 22050.0), tflops=fl * NB * T2 / dt / 1e12, roofline=None)
+                   rtf=dt / (NB * T2 * 256 / 22050.0), tflops=fl * NB * T2 / dt / 1e12, roofline=roof,
+                   call_issue="one hipGraph replay per call (the generator's per-shape graph cache decides from its first calls)" if model.graphs else "eager launches")
+        pol = [e.policy for e in model._graph_cache.entries.values() if e.policy is not None]
+        if pol:
+            res["config"]["call_policy"] = dict(chosen=pol[-1][0], host_ms_to_issue=pol[-1][1] * 1e3, device_ms=pol[-1][2] * 1e3)
         if world == 1 and not a.no_cpu_baseline:
             from oracle import hifigan_oracle as HO                  # cpu_baseline leg: the oracle as the thing timed
             P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
@@ -656,10 +727,32 @@ def run_infer_lj(a, world, rank, dev, sub=None):
             gots = [model.inference(x)[0].detach().cpu() for x in dids]
         res["cpu_baseline"] = dict(value=frames / dc, unit="mel-frames/s", cores=torch.get_num_threads(), kind="port", rtf=dc / audio,
                                    sample="oracle inference() fp32 on the same 10 utterances, one pass")
-        same = [g.shape == r.shape for g, r in zip(gots, refs)]
-        res["t2_equal_to_oracle"] = f"{sum(same)} of {len(same)} utterances"
-        res["hip_vs_oracle_mel_max_abs"] = max([float((g - r).abs().max()) for g, r, ok in zip(gots, refs, same) if ok] or [float("nan")])
-        res["hip_vs_oracle_note"] = f"mel of every utterance whose frame count T2 equals the oracle's, same weights; precision {a.precision} (1e-3 applies to bf16x3)"
+        def against_oracle(gs):
+            same = [g.shape == r.shape for g, r in zip(gs, refs)]
+            return dict(t2_equal_to_oracle=f"{sum(same)} of {len(same)} utterances",
+                        hip_vs_oracle_mel_max_abs=max([float((g - r).abs().max()) for g, r, ok in zip(gs, refs, same) if ok] or [float("nan")]))
+        res.update(against_oracle(gots))
+        res["hip_vs_oracle_note"] = (f"mel of every utterance whose frame count T2 = round(sum of the predicted durations) equals the oracle's, same weights; precision {a.precision}: "
+                                     "a bf16-operand duration predictor moves a sum of ~70 durations across a rounding boundary for some utterances (random-init weights); "
+                                     "the 1e-3 grade is parity_mode (bf16x3)")
+        if a.precision == "bf16" and a.parity_mode:
+            mp = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, sigma=0.01, precision="bf16x3")
+            mp.load_state_dict(P)
+            mp = mp.to(dev).eval()
+            mp.remove_weight_norm()
+            with torch.no_grad():
+                for x in dids[:2]:
+                    mp.inference(x)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    for x in dids:
+                        mp.inference(x)
+                torch.cuda.synchronize()
+                dtp = (time.perf_counter() - t0) / a.steps
+                res["parity_mode"] = dict(precision="bf16x3", ms_per_step=dtp * 1e3, value=frames / dtp, tolerance=1e-3,
+                                          **against_oracle([mp.inference(x)[0].detach().cpu() for x in dids]))
+            del mp
     if sub is not None:
         return res
     print(json.dumps(res), flush=True)

@@ -276,10 +276,9 @@ class EfficientTTSCNN(torch.nn.Module):
             out.append((f"dur.{i}", seq[0]))
         return out
 
-    _TEXT_SIDE = ("text_encoder.", "dur.", "key", "value")            # weights only the text-length launches read
 
     def _weights(self, folded: Optional[Dict[str, torch.Tensor]] = None,
-                 wt: Optional[Dict[str, PackedWeight]] = None, params=None, text_stream=None, main_first: bool = False) -> Dict[str, PackedWeight]:
+                 wt: Optional[Dict[str, PackedWeight]] = None, params=None, phase_of=None) -> Dict[str, PackedWeight]:
         """B operand planes of every Conv1d/Linear; repacked (weight-norm fold fused) whenever
         a parameter changed (optimizer step, load_state_dict, .to()).  Training engine extras, produced by the same
         launches: `folded[name]` (fp32 [cout][cin][taps]) receives the folded weight g * v / ||v|| of a weight-normed
@@ -287,9 +286,12 @@ class EfficientTTSCNN(torch.nn.Module):
         call (`efts_pack_weights_grouped`, a device-side item table) instead of a launch each.
         `_packed_sig` cannot see in-place updates made by the fused optimizer kernel (no version bump), which is
         why EftsAdam resets it and why consumers of derived data compare `_packed_gen`, never the signature.
-        `text_stream`: the planes only the text-length launches read (text encoder, duration predictor, key / value) are packed on that
-        stream -- the training pass runs its text side there, so the two halves of the repack overlap each other and the other stream's
-        first launches instead of standing in front of both (the caller orders `text_stream` behind the parameters' last writer)."""
+        `phase_of(name, has_dgrad_plane) -> [(phase, with_dgrad_plane, with_forward_plane), ...]` (round 6, the training pass): the repack in PHASES.  Nothing is
+        launched here then; `_issue_packs(phase)` enqueues a phase's grouped launches on the CURRENT stream, and the caller places the phases
+        where their first consumer needs them -- the forward planes of the text encoder / of the mel encoder and prenet in front of the two
+        chains of the step, everything else (decoder, mel head, key / value, duration predictor, and every transposed dgrad plane) beside or
+        behind them.  The whole repack stood in front of both chains with 110 us of launches; skipping it altogether returned 0.38 ms
+        (profiles/train_skip_bounds_r05.txt).  Every phase of a repack must be issued before the next one is scheduled."""
         sig = tuple((p.data_ptr(), p._version) for p in (params if params is not None else self.parameters()))
         if sig == self._packed_sig:
             return self._packed
@@ -310,11 +312,11 @@ class EfficientTTSCNN(torch.nn.Module):
             cout, cin = mod.weight_v.shape[:2] if hasattr(mod, "weight_g") else mod.weight.shape[:2]
             if name not in pk or pk[name].buf.device != dev:
                 pk[name] = PackedWeight(cout, cin, taps, self.split, dev)
-            on_text = text_stream is not None and name.startswith(self._TEXT_SIDE)
-            groups.setdefault((cout, cin, taps, name in wt, on_text), []).append((name, mod))
+            for phase, with_t, with_f in ([(None, name in wt, True)] if phase_of is None else phase_of(name, name in wt)):
+                groups.setdefault((cout, cin, taps, bool(with_t), phase, bool(with_f)), []).append((name, mod))
         lib = L.load()
         table_rows, launches = [], []
-        for (cout, cin, taps, with_t, on_text), members in groups.items():
+        for (cout, cin, taps, with_t, phase, with_f), members in groups.items():
             first = len(table_rows)
             tiled = cout % 64 == 0 and cin % 64 == 0 and taps <= 5     # the library's one-pass path: no folded copy needed
             for name, mod in members:
@@ -326,10 +328,11 @@ class EfficientTTSCNN(torch.nn.Module):
                 else:
                     w, g, fo = mod.weight.detach(), None, None
                 assert w.is_contiguous()
+                # (a NULL forward plane: the item only writes its dgrad plane -- the forward plane was packed by an earlier phase)
                 table_rows.append((w.data_ptr(), 0 if g is None else g.data_ptr(), 0 if fo is None else fo.data_ptr(),
-                                   pk[name].ptr, wt[name].ptr if with_t else 0))
+                                   pk[name].ptr if with_f else 0, wt[name].ptr if with_t else 0))
             ref = pk[members[0][0]]
-            launches.append((first, len(members), ref.ld, wt[members[0][0]].ld if with_t else 0, cout, cin, taps, int(with_t), on_text))
+            launches.append((first, len(members), ref.ld, wt[members[0][0]].ld if with_t else 0, cout, cin, taps, int(with_t), phase))
         key = tuple(table_rows)
         tables = getattr(self, "_pack_tables", None)
         if tables is None:
@@ -343,32 +346,32 @@ class EfficientTTSCNN(torch.nn.Module):
             # parameters), which a captured step can no longer be replayed with either (its tag holds the storage signature)
             while len(tables) >= 8:
                 tables.pop(next(iter(tables)))
-            # (scale workspace: one region per stream, the launches of a stream run in order)
-            tables[key] = (torch.tensor(table_rows, dtype=torch.int64, device=dev),
-                           torch.empty(2 * max(n * co for _, n, _, _, co, _, _, _, _ in launches), device=dev))
+            # (scale workspace: one region per phase -- the launches of a phase run in order on one stream, different phases may overlap)
+            phases = sorted({t[8] for t in launches}, key=str)
+            region = max(n * co for _, n, _, _, co, _, _, _, _ in launches)
+            tables[key] = (torch.tensor(table_rows, dtype=torch.int64, device=dev), torch.empty(len(phases) * region, device=dev),
+                           {ph: i * region * 4 for i, ph in enumerate(phases)})
         else:
             tables[key] = tables.pop(key)                                # most recently used last
-        table, scale = tables[key]
+        table, scale, region_of = tables[key]
         base = table.data_ptr()
-        half = scale.numel() // 2 * 4
-        if main_first:
-            # the training step's order of issue (round 6): the planes of the stream the caller runs on first -- and among those the small groups (the prenet's
-            # and the mel head's Linears) in front of the stacks' -- then the text stream's: the mel side is the step's critical path
-            # (the text stream's own order: the text encoder's planes, its first consumer, in front of the duration predictor's and key / value's)
-            launches.sort(key=lambda t: (t[8], (-1 if t[8] else 1) * t[1] * t[4] * t[5] * t[6]))
-        for first, n, ld, ld_t, cout, cin, taps, with_t, on_text in launches:
-            if on_text:
-                with O.on_stream(text_stream):
-                    L.check(lib.efts_pack_weights_grouped(base + first * 40, n, scale.data_ptr() + half, ld, ld_t, cout, cin, taps,
-                                                          self.split, with_t, O._stream()), "efts_pack_weights_grouped")
-            else:
-                L.check(lib.efts_pack_weights_grouped(base + first * 40, n, scale.data_ptr(), ld, ld_t, cout, cin, taps,
-                                                      self.split, with_t, O._stream()), "efts_pack_weights_grouped")
+        pending: Dict = {}
+        for first, n, ld, ld_t, cout, cin, taps, with_t, phase in launches:
+            pending.setdefault(phase, []).append((base + first * 40, n, scale.data_ptr() + region_of[phase], ld, ld_t, cout, cin, taps, self.split, with_t))
+        object.__setattr__(self, "_pack_pending", pending)
+        if phase_of is None:
+            self._issue_packs(None)
         self._packed_sig = sig
         self._packed_gen += 1
         if wt:
             self._folded_gen = self._packed_gen      # this repack also wrote the training engine's derived copies
         return pk
+
+    def _issue_packs(self, phase) -> None:
+        """enqueue the grouped repack launches of `phase` (scheduled by the last `_weights` call) on the current stream"""
+        lib = L.load()
+        for args in self._pack_pending.pop(phase, []):
+            L.check(lib.efts_pack_weights_grouped(*args, O._stream()), "efts_pack_weights_grouped")
 
     def _te0_table(self, pk) -> Optional[torch.Tensor]:
         """tap_table [k_size][num_symbols][C] of text-encoder layer 0: tap k's weights applied to every symbol's embedding, in the

@@ -23,6 +23,7 @@ RC_KERNEL = 0
 PROFILE = None
 # optional filter: only launches whose tag equals PROFILE_TAG are bracketed (keeps the host light)
 PROFILE_TAG = None
+PROFILE_INFO = {}          # tag -> (K = input channels, split, batch) of the bracketed efts_gemm launches (bench.py: FLOPs / bytes of a tag)
 
 _cached_stream = None
 
@@ -159,6 +160,7 @@ def gemm(*, a: Plane, a_ptr: Optional[int] = None, b_ptr: int, ldb: int, b_tap_s
         L.check(L.load().efts_gemm(C.byref(g), _stream()), "efts_gemm")
         s1.record()
         PROFILE.append(((taps, m, n), s0, s1))
+        PROFILE_INFO[(taps, m, n)] = (a.k, a.split, batch)
         return
     L.check(L.load().efts_gemm(C.byref(g), _stream()), "efts_gemm")
 

@@ -38,17 +38,6 @@ _RESCONV_FWD = 3             # residual stacks whose FORWARD runs on efts_rescon
 _RESCONV_DGRAD = -1          # ... and whose DGRAD does (same bits as efts_gemm's); -1: decoder (bf16) / decoder + mel encoder (bf16x3), measured best:
                              # 3.72 -> 3.58-3.61 ms per B = 32 step with both switches (bf16), 6.96 -> 6.62-6.64 (bf16x3), tools/train_ab.sh
 _WGRAD_WGS = 480             # split-K target: 480 workgroups per wgrad launch measured best (6.30 vs 6.60 ms/step at 640)
-
-
-_PACK_SPLIT = 1              # the text-side operand planes are repacked on the side stream (A/B)
-
-
-_NARROW_TN = 1               # the 80-channel Linears' weight gradients on the direct kernel over the 128-wide planes (A/B; bf16 planes only)
-
-
-_EARLY_PACKS = 1             # alignment backward: the operand copies that depend on forward tensors only go to the side stream, early (A/B)
-
-
 _WGRAD_STREAM = 3            # the mel-length weight gradients (mel head, decoder group, mel-encoder group, prenet) + their reductions on a third stream: nothing
                              # on the dgrad chain waits for them, and they fill what that chain leaves idle -- above all the backward of the alignment block,
                              # 0.25 ms of small latency-bound launches that use neither the matrix pipes nor the power budget.  Joined in front of a gradient
@@ -59,20 +48,16 @@ _WGRAD_GROUP_WGS = 384       # workgroups of a grouped launch (0: two per CU).  
                              # 3.28-3.34 at 256 (per-layer launches: 3.48-3.50); the launch is bound by the chip, not by its busiest CU
 
 
-_WGRAD_EARLY = 2            # round 6: stacks whose direct weight gradients are launched LAYER BY LAYER on the third stream as soon as a layer's dZ plane is final,
-                             # beside the rest of the stack's dgrad chain, instead of one grouped launch behind it (bit 0 decoder, bit 1 mel encoder).  Only where
-                             # the dgrad chain is NOT on the persistent kernel (whose workgroups own every CU's LDS: nothing co-resides): the mel encoder in bf16
-_WGRAD_EARLY_WGS = 128       # ... with this many workgroups per single-layer launch (32 tiles: 4 slabs per tile at 128)
-_TEXT_RIDERS = 1             # round 6: the last text-encoder layers ride in the mel encoder's persistent launches in the training forward too (0: every text layer a
-                             # launch of its own on the text stream; tests compare)
-_HEAD_ORDER = 1              # round 6: 1 = the mel side's launches (prenet plane, prenet, the stacks' planes) are issued FIRST and the prenet does not wait for the
-                             # stacks' planes; the gradient buffer's clear and the speech-frame pack (backward operands only) move to the text stream's idle time
+_WGRAD_GROUP_WGS_ME = 0      # workgroups of the mel encoder's grouped launch (3 layers = 96 tiles); 0: _WGRAD_GROUP_WGS (A/B)
+_PACK_LATE = -1              # round 6: the weight repack in phases (TrainEngine._pack_phase) -- what the step's first launches read in front of them, everything
+                             # else beside or behind the head of the step; 0: the whole repack in front of both chains; -1: where it measured faster -- bf16x3, whose
+                             # planes are twice the size (graphed B = 32 step 6.10 -> 5.90-5.95 ms; bf16: 3.23 -> 3.25-3.27, profiles/train_ab_r06.txt)
 
 
 def switch_tag() -> tuple:
     """every hook above, by value: part of the tag of a captured training step"""
-    return (_WGRAD_TN_SPLITS, _SIGN_MIN_ROWS, _BIAS_PARTS, _RESCONV_FWD, _RESCONV_DGRAD, _WGRAD_WGS, _PACK_SPLIT, _NARROW_TN, _EARLY_PACKS,
-            _WGRAD_GROUP_WGS, _FUSE_ACT_BWD, O.RC_KERNEL, _WGRAD_STREAM, _WGRAD_EARLY, _WGRAD_EARLY_WGS, _HEAD_ORDER, _TEXT_RIDERS)
+    return (_WGRAD_TN_SPLITS, _SIGN_MIN_ROWS, _BIAS_PARTS, _RESCONV_FWD, _RESCONV_DGRAD, _WGRAD_WGS,
+            _WGRAD_GROUP_WGS, _FUSE_ACT_BWD, O.RC_KERNEL, _WGRAD_STREAM, _PACK_LATE, _WGRAD_GROUP_WGS_ME)
 
 
 class _TPlane(Plane):
@@ -160,7 +145,26 @@ class TrainEngine:
         return set(cur) != set(self.g) or any(cur[n].shape != self.g[n].shape or cur[n].device != self.dev for n in cur)
 
     # ------------------------------------------------------------------ weights for the backward
-    def _prepare_weights(self, text_stream=None):
+    def _pack_late(self) -> bool:
+        return bool(_PACK_LATE) if _PACK_LATE >= 0 else self.m.split == 2
+
+    def _pack_phase(self, name: str, has_t: bool):
+        """where a weight's planes are repacked in the training step (model._weights(phase_of=...)):
+        "te" / "me": the forward planes of the text encoder / of the mel encoder and the prenet, in front of the two chains of the step;
+        "kv": key, value and duration-predictor planes (forward + dgrad), on the text stream behind the text encoder's launches;
+        "tet": the text encoder's dgrad planes, on the text stream behind the duration predictor;
+        "late": decoder, mel head, mel_query_fc (forward + dgrad) and the mel encoder's dgrad planes, on the third stream beside the head"""
+        if not self._pack_late():
+            return [("te" if name.startswith(("text_encoder.", "dur.", "key", "value")) else "me", has_t, True)]
+        if name.startswith("text_encoder."):
+            return [("te", False, True)] + ([("tet", True, False)] if has_t else [])
+        if name.startswith(("mel_encoder.", "prenet")):
+            return [("me", False, True)] + ([("late", True, False)] if has_t else [])
+        if name.startswith(("dur.", "key", "value")):
+            return [("kv", has_t, True)]
+        return [("late", has_t, True)]
+
+    def _prepare_weights(self):
         """forward planes, folded fp32 weights and transposed/flipped dgrad planes, all from `model._weights` (a handful
         of grouped launches).  The derived copies follow `model._packed_gen` / `_folded_gen`, the repack counters: the
         fused optimizer updates parameters in place without a version bump, so the signature of the parameters cannot
@@ -181,10 +185,10 @@ class TrainEngine:
         for name, lin in lins:
             if name not in self.wt:
                 self.wt[name] = PackedWeight(lin.in_features, lin.out_features, 1, m.split, dev)
-        pk = m._weights(self.folded, self.wt, self.step_params, text_stream=text_stream, main_first=bool(_HEAD_ORDER))
+        pk = m._weights(self.folded, self.wt, self.step_params, phase_of=self._pack_phase)
         if m._folded_gen != m._packed_gen:
             m._packed_sig = None                # the last repack (an eval forward) did not write the copies kept here
-            pk = m._weights(self.folded, self.wt, self.step_params, text_stream=text_stream, main_first=bool(_HEAD_ORDER))
+            pk = m._weights(self.folded, self.wt, self.step_params, phase_of=self._pack_phase)
         return pk
 
     # ------------------------------------------------------------------ small wrappers
@@ -254,7 +258,7 @@ class TrainEngine:
             return
         lib = _lib()
         n = len(items)
-        wgs = _WGRAD_GROUP_WGS if wgs is None else wgs
+        wgs = _WGRAD_GROUP_WGS if not wgs else wgs
         arr = (L.WgradItem * n)()
         for a, (dz_p, x_p, v, g, dw, dg, bp, db) in zip(arr, items):
             a.dz_plane, a.ldz, a.x_plane, a.ldx = dz_p.ptr, dz_p.ld, x_p.ptr, x_p.ld
@@ -271,7 +275,7 @@ class TrainEngine:
     @staticmethod
     def _narrow_ok(dz_split: int, x_split: int, cout: int, cin: int, ldz: int, ldx: int) -> bool:
         """THE applicability test of _wgrad_narrow (callers that allocate differently for the two paths ask this, not a copy of it)"""
-        return bool(_NARROW_TN and _WGRAD_TN_SPLITS > 0 and dz_split == 1 and x_split == 1 and max(cout, cin) % 128 == 0 and min(cout, cin) <= 128
+        return bool(_WGRAD_TN_SPLITS > 0 and dz_split == 1 and x_split == 1 and max(cout, cin) % 128 == 0 and min(cout, cin) <= 128
                     and ldz >= max(cout, 128) * 2 and ldx >= max(cin, 128) * 2)
 
     def _wgrad_narrow(self, ws, tag, dz_p: Plane, x_p: Plane, cout, cin, rows, out_dw) -> bool:
@@ -288,52 +292,30 @@ class TrainEngine:
         return True
 
     # ------------------------------------------------------------------ forward with saved activations
-    def _rc_layer(self, ws, tag, blk, pk, rs, i, x_f, x_p, x_lo, gap_ptr, last_split):
-        """layer i of a stack on efts_resconv5 in the training forward: (keyword set of the launch, what the backward keeps, fp32 output or None,
-        output plane, output remainder plane).  The stream between the layers is hi + lo bf16 planes (every hi plane is kept: it is the layer's
-        operand in the wgrad), the activation's sign leaves the epilogue as bit rows (efts_act_bwd mode 5); fp32 only into the first such layer
-        (x_f: the producer's stream) and out of the last one"""
-        m, C = self.m, self.m.n_channels
-        layers = getattr(m, blk).layers
-        last = i == len(layers) - 1
-        o_split = last_split if last else m.split
-        o_p = ws.plane(f"T{tag}_p{i}", rs, C, o_split)
-        o_l = ws.plane(f"T{tag}_l{i & 1}", rs, C, 1) if (o_split == 1 and not last) else None
-        o_f = ws.f32(f"T{tag}_f{len(layers) - 1}", rs, C) if last else None
-        sg = ws.tensor(f"T{tag}_sb{i}", (rs.rows, C // 8), torch.uint8)
-        kw = dict(x=x_p, x_lo=x_lo, x_f32_ptr=None if x_f is None else x_f.ptr, ldr=C, w=pk[f"{blk}.{i}"], taps=m.k_size, m=rs.rows, n=C,
-                  bias=layers[i].conv[0].bias, slope=m.slope, rowmask_ptr=gap_ptr, y_f32_ptr=None if o_f is None else o_f.ptr, ldo=C,
-                  y=o_p, y_lo=o_l, sign_bits_ptr=sg.data_ptr())
-        return kw, (None, None, x_p, (sg, 5), 0.0, 0), o_f, o_p, o_l
-
-    def _rc_forward_ok(self, tag, rs) -> bool:
-        m = self.m
-        return bool((_RESCONV_FWD & dict(dec=1, me=2, te=0)[tag]) and m._on_resconv(rs) and self._conv_drop(0)[0] == 0.0 and _WGRAD_TN_SPLITS > 0
-                    and m.n_channels % 128 == 0)
-
-    def _stack_fwd(self, ws, tag, blk, pk, rs, x_f, x_p, gap_ptr, last_split, stop: Optional[int] = None, rider=None):
-        """stop: only layers [0, stop) (on efts_gemm: the first text-encoder layers, whose successors ride in the mel encoder's launches);
-        rider(i): keyword set of an independent layer that shares layer i's persistent launch (efts_resconv5_multi), or None"""
+    def _stack_fwd(self, ws, tag, blk, pk, rs, x_f, x_p, gap_ptr, last_split):
         m, C = self.m, self.m.n_channels
         saved = []
         layers = getattr(m, blk).layers
-        if stop is None and self._rc_forward_ok(tag, rs):
-            # mel-length stack on efts_resconv5 (the inference kernel)
-            x_lo, o_f = None, None
-            for i in range(len(layers)):
-                kw, keep, o_f, o_p, o_l = self._rc_layer(ws, tag, blk, pk, rs, i, x_f if i == 0 else None, x_p, x_lo, gap_ptr, last_split)
-                extra = rider(i) if rider is not None else None
-                if extra is not None:
-                    O.resconv5_multi([kw, extra])
-                else:
-                    O.resconv5(**kw)
-                saved.append(keep)
+        if (_RESCONV_FWD & dict(dec=1, me=2, te=0)[tag]) and m._on_resconv(rs) and self._conv_drop(0)[0] == 0.0 and _WGRAD_TN_SPLITS > 0 and C % 128 == 0:
+            # mel-length stack on efts_resconv5 (the inference kernel): the stream between the layers is hi + lo bf16 planes (every
+            # hi plane is kept: it is the layer's operand in the wgrad), the activation's sign leaves the epilogue as bit rows
+            # (efts_act_bwd mode 5); fp32 only into the first layer (the producer's stream) and out of the last one
+            n = len(layers)
+            x_lo = None
+            for i, layer in enumerate(layers):
+                last = i == n - 1
+                o_split = last_split if last else m.split
+                o_p = ws.plane(f"T{tag}_p{i}", rs, C, o_split)
+                o_l = ws.plane(f"T{tag}_l{i & 1}", rs, C, 1) if (o_split == 1 and not last) else None
+                o_f = ws.f32(f"T{tag}_f{n - 1}", rs, C) if last else None
+                sg = ws.tensor(f"T{tag}_sb{i}", (rs.rows, C // 8), torch.uint8)
+                O.resconv5(x=x_p, x_lo=x_lo, x_f32_ptr=x_f.ptr if i == 0 else None, ldr=C, w=pk[f"{blk}.{i}"], taps=m.k_size, m=rs.rows, n=C,
+                           bias=layer.conv[0].bias, slope=m.slope, rowmask_ptr=gap_ptr, y_f32_ptr=None if o_f is None else o_f.ptr, ldo=C,
+                           y=o_p, y_lo=o_l, sign_bits_ptr=sg.data_ptr())
+                saved.append((None, None, x_p, (sg, 5), 0.0, 0))
                 x_p, x_lo = o_p, o_l
             return o_f, x_p, saved
-        assert rider is None
         for i, layer in enumerate(layers):
-            if stop is not None and i >= stop:
-                break
             last = i == len(layers) - 1
             w = pk[f"{blk}.{i}"]
             o_f = ws.f32(f"T{tag}_f{i}", rs, C)
@@ -383,10 +365,6 @@ class TrainEngine:
         group = []                                               # (grouped direct wgrads: every layer keeps its dZ plane and bias sums until the stack is through)
         on_rc = bool((_RESCONV_DGRAD if _RESCONV_DGRAD >= 0 else (1 if m.split == 1 else 3)) & dict(dec=1, me=2, te=0)[tag]) and m._on_resconv(rs)
         fused = None                                             # (dZ plane, bias sums) of layer i the dgrad launch of layer i + 1 has already written
-        # layer-by-layer weight gradients beside the dgrad chain (round 6): a layer's operands -- its dZ plane, its input plane, its bias sums -- are
-        # final as soon as its activation backward has run, i.e. BEFORE its own dgrad launch; where the dgrad kernel leaves half a CU's LDS free
-        # (conv5_kernel / gemm_kernel: 80 KiB) a weight-gradient workgroup co-resides and the two kinds of launch share the matrix pipes
-        early = wgrad_stream is not None and bool(_WGRAD_EARLY & dict(dec=1, me=2, te=0)[tag]) and not on_rc
         for i in reversed(range(len(layers))):
             x_f, y_f, x_pl, sg, dp, dseed = saved[i]
             conv = layers[i].conv[0]
@@ -415,10 +393,7 @@ class TrainEngine:
             wn = hasattr(conv, "weight_g")
             v_, g_ = (conv.weight_v.detach(), conv.weight_g.detach()) if wn else (None, None)
             dw_, dg_ = (self.g[pre + "weight_v"], self.g[pre + "weight_g"]) if wn else (self.g[pre + "weight"], None)
-            if direct and early:
-                with self._forked(wgrad_stream):
-                    self._wgrad_group(ws, [(dz_p, x_pl, v_, g_, dw_, dg_, bp, self.g[pre + "bias"])], C, C, rs.rows, m.k_size, m.split, _WGRAD_EARLY_WGS)
-            elif direct:
+            if direct:
                 group.append((dz_p, x_pl, v_, g_, dw_, dg_, bp, self.g[pre + "bias"]))
             else:
                 self._wgrad(ws, dz_f.ptr, C, x_f.ptr, C, C, m.k_size, rs.rows, v_, g_, dw_, dg_)
@@ -449,7 +424,7 @@ class TrainEngine:
             G = Gn
         if group:
             with self._forked(wgrad_stream):
-                self._wgrad_group(ws, group, C, C, rs.rows, m.k_size, m.split)
+                self._wgrad_group(ws, group, C, C, rs.rows, m.k_size, m.split, _WGRAD_GROUP_WGS_ME if tag == "me" else None)
         return G
 
     def forward_backward(self, text, text_lengths, speech, speech_lengths, gscale: Optional[torch.Tensor] = None,
@@ -480,12 +455,25 @@ class TrainEngine:
             O.row_masks(ml, rs2, gap2, len2)
         # the repack of the operand planes (weight-norm fold + bf16 planes + dgrad planes, ~110 us on one stream): the text-side planes on
         # the stream the text side runs on, the mel-side planes here -- both behind the masks and the previous step's optimizer
-        side0 = m._side_stream(dev) if _PACK_SPLIT else None
-        if side0 is not None:
-            side0.wait_stream(torch.cuda.current_stream(dev))
-        pk = self._prepare_weights(text_stream=side0)
-        if not _HEAD_ORDER:
-            self.flat.zero_()
+        # (round 6: in phases -- only what the step's first launches read stands in front of them, see _pack_phase)
+        side0 = m._side_stream(dev)
+        side0.wait_stream(torch.cuda.current_stream(dev))
+        late0 = m._aux_stream(dev) if (self._pack_late() and m.side_stream) else None
+        if late0 is not None:
+            late0.wait_stream(torch.cuda.current_stream(dev))
+        pk = self._prepare_weights()
+        m._issue_packs("me")
+        with O.on_stream(side0):
+            m._issue_packs("te")
+        ev_late = None
+        if late0 is not None:
+            with O.on_stream(late0):
+                m._issue_packs("late")
+            ev_late = torch.cuda.Event()
+            ev_late.record(late0)
+        else:
+            m._issue_packs("late")
+        self.flat.zero_()
 
         # Two HIP streams.  The text-length work (embedding, text encoder, K/V, duration predictor and all of their
         # backward) runs on ~B*T1 = 4k rows: launches of 70-270 workgroups that leave most of the chip idle.  None of it
@@ -493,8 +481,6 @@ class TrainEngine:
         # stream and fills the idle CUs / tail rounds of the mel-length kernels; events mark the few hand-over points.
         main = torch.cuda.current_stream(dev)
         side = m._side_stream(dev)
-        if side0 is None:
-            side.wait_stream(main)
         if self.mark is not None:
             self.mark("step_start")
         dp = m.duration_predictor
@@ -518,106 +504,19 @@ class TrainEngine:
             seed0, seed1 = (self.seed_base + 2 * self.drop_calls) & 0xFFFFFFFF, (self.seed_base + 2 * self.drop_calls + 1) & 0xFFFFFFFF
 
         # ============================ forward (efficient_tts.py:144-227), activations kept
-        mel_in_f, mel_in = ws.f32("Tmel_in_f", rs2, odim), ws.plane("Tmel_in", rs2, odim, split)
-        pre_dp, pre_seed = self._conv_drop(40)                       # mel_prenet's Dropout (efficient_tts.py:76-80)
-        prenet_from_frames = m.act_general is None and pre_dp == 0.0 and m.fuse_prenet and odim % 8 == 0 and odim <= 128 and C % 128 == 0
-        late_head = bool(_HEAD_ORDER) and prenet_from_frames
-        # text-encoder layers as RIDERS of the mel encoder's persistent launches (round 6; the inference pass has done this since round 3,
-        # model._forward_body): the last min(nt, nm) text layers share the launches of the mel-encoder layers (efts_resconv5_multi: +22 us per
-        # launch instead of a 33 us launch of their own that must not run beside a persistent launch), the first nt - nr run by themselves on
-        # the text stream while the prenet runs on this one.  Their stream between the layers is then hi + lo bf16 planes like the mel stacks'.
-        nt, nm = len(m.text_encoder.layers), len(m.mel_encoder.layers)
-        nr = min(nt, nm) if (_TEXT_RIDERS and m.act_general is None and self._rc_forward_ok("me", rs2) and nt >= 1) else 0
-        ns = nt - nr
-        ev_te_head, ev_te_done = torch.cuda.Event(), torch.cuda.Event()
-        tstate = {}
-
-        def prenet():
-            """mel_prenet (efficient_tts.py:161) on the main stream"""
-            if not late_head:
-                O.pack_rows(speech, mel_in_f, mel_in, rs2)          # (the backward's wgrad of the prenet reads both)
-            pre_f, pre_p = ws.f32("Tpre_f", rs2, C), ws.plane("Tpre_p", rs2, C, split)
-            wp = pk["prenet"]
-            pre_z = None
-            if m.act_general is not None:
-                pre_z = ws.f32("Tpre_z", rs2, C)
-                O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, bias=m.mel_prenet[0].bias, out_f32_ptr=pre_z.ptr, ldo=C)
-                O.act_apply(m.act_general, pre_z.ptr, None, gap2.data_ptr(), pre_f, pre_p, rs2.rows, C, pre_dp, pre_seed)
-            elif prenet_from_frames:
-                # no Dropout on the prenet (the shipped recipe): straight from the caller's frames, whole-line stores (efts_frame_linear;
-                # bit-identical to the launch below)
-                O.frame_linear(x=speech, w=wp, bias=m.mel_prenet[0].bias, act=L.ACT_LEAKY, slope=m.slope, rs=rs2, y=pre_p, y_f32=pre_f)
-            else:
-                O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, act=L.ACT_LEAKY, slope=m.slope, bias=m.mel_prenet[0].bias,
-                       rowmask_ptr=gap2.data_ptr(), out_f32_ptr=pre_f.ptr, ldo=C, out_plane=pre_p, drop_p=pre_dp, drop_seed=pre_seed)
-            return pre_f, pre_p, pre_z
-
-        def text_rider(i):
-            """keyword set of the text-encoder layer that rides in mel-encoder layer i's launch (layer ns + i - (nm - nr)), or None"""
-            if i < nm - nr:
-                return None
-            j = ns + i - (nm - nr)
-            kw, keep, o_f, o_p, o_l = self._rc_layer(ws, "te", "text_encoder", pk, rs1, j, tstate["x_f"], tstate["x_p"], tstate["x_lo"], gap1.data_ptr(), split)
-            tstate["saved"].append(keep)
-            tstate.update(x_f=None, x_p=o_p, x_lo=o_l, o_f=o_f)
-            return kw
-
-        def mel_stack(pre_f, pre_p):
-            """mel encoder (+ mel_query_fc) (efficient_tts.py:162-164) on the main stream"""
-            if nr:
-                main.wait_event(ev_te_head)                          # the riders' input: the text stream's first layers (or the embedding)
-            rider = text_rider if nr else None
-            mh_f = mh_p = None
-            if m.mel_query_fc is None:
-                q_f, q_p, me_saved = self._stack_fwd(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2, rider=rider)
-            else:                                                   # efficient_tts.py:163-164: Linear(C, C) in front of the attention
-                mh_f, mh_p, me_saved = self._stack_fwd(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), split, rider=rider)
-                q_f, q_p = ws.f32("Tq_f", rs2, C), ws.plane("Tq_p", rs2, C, 2)
-                wq = pk["qfc"]
-                O.gemm(a=mh_p, b_ptr=wq.ptr, ldb=wq.ld, m=rs2.rows, n=C, bias=m.mel_query_fc.bias, rowmask_ptr=gap2.data_ptr(),
-                       out_f32_ptr=q_f.ptr, ldo=C, out_plane=q_p)
-            if nr:
-                ev_te_done.record(main)
-            if self.mark is not None:
-                self.mark("fwd_mel_encoder_done")
-            return q_f, q_p, me_saved, mh_f, mh_p
-
-        def text_head():
-            """embedding + the text-encoder layers that run by themselves (all of them without riders), on the text stream"""
-            with O.on_stream(side):
-                self._ws_tag = "s"
-                emb_f, emb_p = ws.f32("Temb_f", rs1, C), ws.plane("Temb_p", rs1, C, split)
-                O.embed(text, m.text_embedding_table.weight.detach(), emb_f, emb_p, rs1)
-                x_f, x_p, saved = self._stack_fwd(ws, "te", "text_encoder", pk, rs1, emb_f, emb_p, gap1.data_ptr(), split, stop=ns if nr else None)
-                if nr:
-                    tstate.update(x_f=x_f, x_p=x_p, x_lo=None, saved=saved, o_f=None)
-                    ev_te_head.record(side)
-                self._ws_tag = ""
-            return x_f, x_p, saved
-
-        if _HEAD_ORDER or nr:
-            # the mel side is issued in FRONT of the text side's launches: it is the longer of the two chains between the optimizer and the attention
-            pre_f, pre_p, pre_z = prenet()
-            te_f, te_p, te_saved = text_head()
-            q_f, q_p, me_saved, mh_f, mh_p = mel_stack(pre_f, pre_p)
-        else:
-            te_f, te_p, te_saved = text_head()
-            pre_f, pre_p, pre_z = prenet()
-            q_f, q_p, me_saved, mh_f, mh_p = mel_stack(pre_f, pre_p)
-        if nr:
-            te_f, te_p, te_saved = tstate["o_f"], tstate["x_p"], tstate["saved"]
-            side.wait_event(ev_te_done)
         with O.on_stream(side):
             self._ws_tag = "s"
+            emb_f, emb_p = ws.f32("Temb_f", rs1, C), ws.plane("Temb_p", rs1, C, split)
+            O.embed(text, m.text_embedding_table.weight.detach(), emb_f, emb_p, rs1)
+            te_f, te_p, te_saved = self._stack_fwd(ws, "te", "text_encoder", pk, rs1, emb_f, emb_p, gap1.data_ptr(), split)
             key_f, key_p = ws.f32("Tkey_f", rs1, C), ws.plane("Tkey_p", rs1, C, 2)
             val_f, val_p = ws.f32("Tval_f", rs1, C), ws.plane("Tval_p", rs1, C, split)
             shared = m.share_text_encoder_key_value                 # efficient_tts.py:150-153: the value is the key projection
             wk = pk["key"]
             wv = wk if shared else pk["value"]
+            m._issue_packs("kv")                                    # key / value / duration-predictor planes: behind the text encoder's launches
             O.gemm(a=te_p, b_ptr=wk.ptr, ldb=wk.ld, m=rs1.rows, n=C, bias=m.text_encoder_key.bias, rowmask_ptr=len1.data_ptr(),
                    out_f32_ptr=key_f.ptr, ldo=C, out_plane=key_p)
-            ev_k = torch.cuda.Event()
-            ev_k.record(side)
             O.gemm(a=te_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=(m.text_encoder_key if shared else m.text_encoder_value).bias,
                    rowmask_ptr=len1.data_ptr(), out_f32_ptr=val_f.ptr, ldo=C, out_plane=val_p)
             ev_kv = torch.cuda.Event()
@@ -635,19 +534,40 @@ class TrainEngine:
                    bias=dp.conv[1][0].bias, out_f32_ptr=h2_f.ptr, ldo=C)
             O.layernorm_dot(h2_f.ptr, ln1.weight.detach(), ln1.bias.detach(), ln1.eps, dp.linear.weight.detach(),
                             dp.linear.bias.detach(), len1.data_ptr(), 0, float(dp.offset), dur, rs1.rows, C, drop_p, seed1, sadd)
-            if _HEAD_ORDER:
-                # the gradient buffer's clear: first written by the backward, which the main stream starts behind `ev_dur` (and every other
-                # stream forks from the main stream after that)
-                self.flat.zero_()
-            if late_head:
-                # the prenet reads the caller's frames itself (efts_frame_linear): the packed copy of the frames is an operand of the BACKWARD only
-                # (the prenet's weight gradient), so it is made here, in the text stream's idle time, instead of in front of the mel encoder
-                O.pack_rows(speech, mel_in_f, mel_in, rs2)
+            m._issue_packs("tet")                                   # the text encoder's dgrad planes: this stream's idle time
             ev_dur = torch.cuda.Event()
             ev_dur.record(side)
             self._ws_tag = ""
 
-        main.wait_event(ev_k)                                       # K from the text stream (V: in front of the expand launch)
+        mel_in_f, mel_in = ws.f32("Tmel_in_f", rs2, odim), ws.plane("Tmel_in", rs2, odim, split)
+        O.pack_rows(speech, mel_in_f, mel_in, rs2)                  # (the backward's wgrad of the prenet reads both)
+        pre_f, pre_p = ws.f32("Tpre_f", rs2, C), ws.plane("Tpre_p", rs2, C, split)
+        wp = pk["prenet"]
+        pre_dp, pre_seed = self._conv_drop(40)                       # mel_prenet's Dropout (efficient_tts.py:76-80)
+        pre_z = None
+        if m.act_general is not None:
+            pre_z = ws.f32("Tpre_z", rs2, C)
+            O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, bias=m.mel_prenet[0].bias, out_f32_ptr=pre_z.ptr, ldo=C)
+            O.act_apply(m.act_general, pre_z.ptr, None, gap2.data_ptr(), pre_f, pre_p, rs2.rows, C, pre_dp, pre_seed)
+        elif pre_dp == 0.0 and m.fuse_prenet and odim % 8 == 0 and odim <= 128 and C % 128 == 0:
+            # no Dropout on the prenet (the shipped recipe): straight from the caller's frames, whole-line stores (efts_frame_linear;
+            # bit-identical to the launch below)
+            O.frame_linear(x=speech, w=wp, bias=m.mel_prenet[0].bias, act=L.ACT_LEAKY, slope=m.slope, rs=rs2, y=pre_p, y_f32=pre_f)
+        else:
+            O.gemm(a=mel_in, b_ptr=wp.ptr, ldb=wp.ld, m=rs2.rows, n=C, act=L.ACT_LEAKY, slope=m.slope, bias=m.mel_prenet[0].bias,
+                   rowmask_ptr=gap2.data_ptr(), out_f32_ptr=pre_f.ptr, ldo=C, out_plane=pre_p, drop_p=pre_dp, drop_seed=pre_seed)
+        if m.mel_query_fc is None:
+            q_f, q_p, me_saved = self._stack_fwd(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), 2)
+        else:                                                       # efficient_tts.py:163-164: Linear(C, C) in front of the attention
+            mh_f, mh_p, me_saved = self._stack_fwd(ws, "me", "mel_encoder", pk, rs2, pre_f, pre_p, gap2.data_ptr(), split)
+            q_f, q_p = ws.f32("Tq_f", rs2, C), ws.plane("Tq_p", rs2, C, 2)
+            wq = pk["qfc"]
+            O.gemm(a=mh_p, b_ptr=wq.ptr, ldb=wq.ld, m=rs2.rows, n=C, bias=m.mel_query_fc.bias, rowmask_ptr=gap2.data_ptr(),
+                   out_f32_ptr=q_f.ptr, ldo=C, out_plane=q_p)
+        if self.mark is not None:
+            self.mark("fwd_mel_encoder_done")
+
+        main.wait_event(ev_kv)                                      # K, V from the side stream
         scale = O.INV_SQRT(C)
         scores = ws.tensor("Tscores", (B, T2, T1))
         O.gemm(a=q_p, b_ptr=key_p.ptr, ldb=key_p.ld, m=T2, n=T1, batch=B, a_batch_stride=rs2.Tp * q_p.ld,
@@ -664,7 +584,6 @@ class TrainEngine:
                 O.duration_target(e, tl, ml, float(m.duration_offset), False, lde, B, T1)
         ralpha = ws.tensor("Tralpha", (B, T1, T2))
         h_f, h_p = ws.f32("Texp_f", rs2, C), ws.plane("Texp_p", rs2, C, split)
-        main.wait_event(ev_kv)                                      # V from the text stream
         if m._fused_expand(T1):
             # alpha' produced in registers inside the expand contraction (efts_expand); the backward packs its own operands from
             # the fp32 alpha' kept here
@@ -681,6 +600,8 @@ class TrainEngine:
             O.gemm(a=ra_p, b_ptr=vt.ptr, ldb=vt.ld, m=T2, n=C, batch=B, a_batch_stride=rs2.Tp * ra_p.ld, b_batch_stride=C * vt.ld,
                    rowmask_ptr=len2.data_ptr(), rowmask_batch_stride=rs2.Tp, out_f32_ptr=h_f.ptr, ldo=C, out_batch_stride=rs2.Tp * C,
                    out_plane=h_p, outb_batch_stride=rs2.Tp * h_p.ld)
+        if ev_late is not None:
+            main.wait_event(ev_late)                                # decoder / head planes (and every dgrad plane this stream reads later)
         d_f, d_p, dec_saved = self._stack_fwd(ws, "dec", "decoder", pk, rs2, h_f, h_p, gap2.data_ptr(), split)
         if self.mark is not None:
             self.mark("fwd_decoder_done")
@@ -740,21 +661,19 @@ class TrainEngine:
             O.gemm(a=dz1_p, b_ptr=wt.ptr, ldb=wt.ld, b_tap_stride=wt.tap_stride, taps=3, m=rs1.rows, n=C, out_f32_ptr=dV_dur.ptr, ldo=C)
             ev_durb = torch.cuda.Event()
             ev_durb.record(side)
-            ev_packs = None
-            if _EARLY_PACKS:
-                # operand copies of the alignment backward that depend on forward tensors only (V as an A operand, alpha' as an A operand,
-                # K^T, Q^T): this stream idles through the decoder's backward, the main one would run them one after the other in front of
-                # their GEMMs
-                val_p2 = ws.plane("Bval_p2", rs1, C, 2)
-                L.check(_lib().efts_pack_rows(val_f.ptr, None, val_p2.ptr, val_p2.ld, B, rs1.Tp, rs1.Tp, C, C, 2, O._stream()), "efts_pack_rows")
-                ra1_p = ws.plane("Bra1_p", rs1, T2, 2)
-                O.pack_rows(ralpha, None, ra1_p, rs1)
-                kt = ws.raw_plane("Bkt", B * C + 136, T1, 2)
-                O.pack_vt(key_f, kt, B, T1, rs1.Tp, C)
-                qt = ws.raw_plane("Bqt", B * C + 136, T2, 2)
-                O.pack_vt(q_f, qt, B, T2, rs2.Tp, C)
-                ev_packs = torch.cuda.Event()
-                ev_packs.record(side)
+            # operand copies of the alignment backward that depend on forward tensors only (V as an A operand, alpha' as an A operand,
+            # K^T, Q^T): this stream idles through the decoder's backward, the main one would run them one after the other in front of
+            # their GEMMs
+            val_p2 = ws.plane("Bval_p2", rs1, C, 2)
+            L.check(_lib().efts_pack_rows(val_f.ptr, None, val_p2.ptr, val_p2.ld, B, rs1.Tp, rs1.Tp, C, C, 2, O._stream()), "efts_pack_rows")
+            ra1_p = ws.plane("Bra1_p", rs1, T2, 2)
+            O.pack_rows(ralpha, None, ra1_p, rs1)
+            kt = ws.raw_plane("Bkt", B * C + 136, T1, 2)
+            O.pack_vt(key_f, kt, B, T1, rs1.Tp, C)
+            qt = ws.raw_plane("Bqt", B * C + 136, T2, 2)
+            O.pack_vt(q_f, qt, B, T2, rs2.Tp, C)
+            ev_packs = torch.cuda.Event()
+            ev_packs.record(side)
             self._ws_tag = ""
         # mel head (Linear 512->80, masked): bias grad + operand plane, wgrad, dgrad
         if m.use_masking:
@@ -781,17 +700,10 @@ class TrainEngine:
             self.bucket_hook(0)
 
         # ---- expand bmm backward: d alpha' [B,T1,T2] and dV
-        if ev_packs is not None:
-            main.wait_event(ev_packs)
-        else:
-            val_p2 = ws.plane("Bval_p2", rs1, C, 2)
-            L.check(_lib().efts_pack_rows(val_f.ptr, None, val_p2.ptr, val_p2.ld, B, rs1.Tp, rs1.Tp, C, C, 2, O._stream()), "efts_pack_rows")
+        main.wait_event(ev_packs)
         dAp = ws.tensor("BdAp", (B, T1, T2))
         O.gemm(a=val_p2, b_ptr=dH_p.ptr, ldb=dH_p.ld, m=T1, n=T2, batch=B, a_batch_stride=rs1.Tp * val_p2.ld,
                b_batch_stride=rs2.Tp * dH_p.ld, out_f32_ptr=dAp.data_ptr(), ldo=T2, out_batch_stride=T1 * T2)
-        if ev_packs is None:
-            ra1_p = ws.plane("Bra1_p", rs1, T2, 2)                   # alpha' as an A operand: rows (b,i), K = j
-            O.pack_rows(ralpha, None, ra1_p, rs1)
         dHt = ws.raw_plane("BdHt", B * C + 136, T2, 2)              # dH^T per item: [B][C][K = j]
         O.pack_vt(dH, dHt, B, T2, rs2.Tp, C)
         GV = ws.f32("BGV", rs1, C)
@@ -814,17 +726,11 @@ class TrainEngine:
         L.check(_lib().efts_attn_bwd(scores.data_ptr(), T1, sidx.data_ptr(), dsx.data_ptr(), tl.data_ptr(), ml.data_ptr(), dS.data_ptr(),
                                      T1, dS_p.ptr, dS_p.ld, B, T1, T2, rs2.Tp, O._stream()), "efts_attn_bwd")
         # dQ = scale * dS K ; dK = scale * dS^T Q
-        if ev_packs is None:
-            kt = ws.raw_plane("Bkt", B * C + 136, T1, 2)
-            O.pack_vt(key_f, kt, B, T1, rs1.Tp, C)
         GQ = ws.f32("BGQ", rs2, C)
         O.gemm(a=dS_p, b_ptr=kt.ptr, ldb=kt.ld, m=T2, n=C, batch=B, a_batch_stride=rs2.Tp * dS_p.ld, b_batch_stride=C * kt.ld, alpha=scale,
                out_f32_ptr=GQ.ptr, ldo=C, out_batch_stride=rs2.Tp * C)
         dSt = ws.raw_plane("BdSt", B * T1 + 264, T2, 2)             # dS^T: rows (b,i), K = j
         L.check(_lib().efts_pack_vt(dS.data_ptr(), T1, dSt.ptr, dSt.ld, B, T2, T2, T1, O._stream()), "efts_pack_vt")
-        if ev_packs is None:
-            qt = ws.raw_plane("Bqt", B * C + 136, T2, 2)
-            O.pack_vt(q_f, qt, B, T2, rs2.Tp, C)
         GK = ws.f32("BGK", rs1, C)
         GK_p = ws.plane("BGK_p", rs1, C, split)
         shared = m.share_text_encoder_key_value                     # value = key projection: its gradient joins dK here (residual)

@@ -102,9 +102,15 @@ class HiFiGANGenerator(nn.Module):
         self._packed_dev = None
         self._bias: Dict[str, torch.Tensor] = {}
         self._bufs: Dict[int, dict] = {}
+        # per-shape hipGraph of the ~85 launches of a call (round 6; efficient_tts_amd/graphs.py, the acoustic model's cache): one utterance is
+        # 2 ms of device work issued by a host that needs about as long for the launches; `graphs = False`: every launch issued eagerly
+        self.graphs = True
+        from .graphs import GraphCache
+        object.__setattr__(self, "_graph_cache", GraphCache(capacity=4))
 
     # ------------------------------------------------------------------ reference API
     def remove_weight_norm(self):
+        self._graph_cache.clear()
         for m in [self.conv_pre, self.conv_post, *self.ups]:
             remove_weight_norm(m)
         for rb in self.resblocks:
@@ -114,6 +120,7 @@ class HiFiGANGenerator(nn.Module):
 
     def load_state_dict(self, *a, **k):
         self._packed = None
+        self._graph_cache.clear()
         return super().load_state_dict(*a, **k)
 
     # ------------------------------------------------------------------ weights -> operand planes (once)
@@ -204,13 +211,23 @@ class HiFiGANGenerator(nn.Module):
             lens = torch.full((B,), T, dtype=torch.int32, device=dev)
         else:
             lens = lengths.to(device=dev, dtype=torch.int32).clamp(0, T)
-        audio = torch.zeros(B, 1, T * hop, dtype=torch.float32, device=dev)
         mel = x.transpose(1, 2).float()
         if lengths is not None:                 # what the padding frames hold must not reach conv_pre's halo
             mel = mel * (torch.arange(T, device=dev)[None, :] < lens[:, None])[:, :, None]
-        with O.stream_scope():
-            self._run(pk, mel.contiguous(), lens, audio, B, T, hop, dev)
-        return audio
+        mel = mel.contiguous()
+
+        def body(mel_btc, lens_i32):
+            audio = torch.zeros(B, 1, T * hop, dtype=torch.float32, device=dev)
+            with O.stream_scope():
+                self._run(pk, mel_btc, lens_i32, audio, B, T, hop, dev)
+            return (audio,)
+
+        if not self.graphs or torch.cuda.is_current_stream_capturing():
+            return body(mel, lens)[0]
+        ws = self._workspace_for(B, T, dev)
+        # the graph is valid while the buffers its launches point at live: this workspace and the packed planes
+        tag = (id(ws), tuple(w.ptr for w in pk.values()), self.split)
+        return self._graph_cache.run(("voc", B, T), tag, (mel, lens), body, keepalive=(ws, pk), adaptive=True)[0]
 
     def _conv(self, pk, name, a: Plane, rows, taps, dil, *, mask=None, out_f=None, ldo=0, out_p=None, plane_slope=None, resid=None,
               ldr=0, act=L.ACT_NONE):
