@@ -475,19 +475,38 @@ def run_logmel64(a, world, rank, dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     dt /= a.steps
+    # roofline (round 6): the three launches of a call are timed with HIP events on the launch stream (frame pack / the batched DFT product / logmel);
+    # the pipeline's algorithmic bytes -- audio in, operand plane written and read, spectrum written and read, mel out -- against HBM, the product's
+    # FLOPs against the MFMA peak; `roofline` is the product's line (still the longest launch), `pipeline` the whole call's
     rows = B * (T2 + 2)
-    P.PROFILE, P.PROFILE_TAG = [], (1, rows, 1026)
+    P.PROFILE, P.PROFILE_TAG = [], None
+    evs = []
     for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         fe(audio, lengths)
+        e1.record()
+        evs.append((e0, e1))
     torch.cuda.synchronize()
-    durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in P.PROFILE]
+    durs = [s.elapsed_time(e) * 1e-3 for (tag, s, e) in P.PROFILE if tag[0] == 1 and tag[1] == rows]
+    call = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs) * 1e-3
     P.PROFILE, P.PROFILE_TAG = None, None
     avg = sum(durs) / max(len(durs), 1)
-    flop = 2.0 * B * T2 * 1024 * 1026
-    roof = dict(bound="mfma", kernel="gemm_kernel<taps=1,split=2> (real DFT 1024 -> 513 re + 513 im as an MFMA product)",
+    flop = 2.0 * B * T2 * (1024 * 1026 if fe.radix == 1 else fe.radix * fe.sub * fe.sub)
+    plane_bytes = rows * 1024 * 4                      # bf16x3 operand plane: hi + lo
+    spec_bytes = rows * fe.ld_spec * 4
+    gemm_bytes = plane_bytes + spec_bytes
+    pipe_bytes = B * T2 * 256 * 4 + 2 * plane_bytes + 2 * spec_bytes + B * T2 * 80 * 4
+    roof = dict(bound="mfma", kernel=(f"gemm_kernel<taps=1,split=2>: {fe.radix} real DFTs of {1024 // fe.radix} points per frame as one batched MFMA product (decimation in time, radix {fe.radix})"
+                                      if fe.radix > 1 else "gemm_kernel<taps=1,split=2> (real DFT 1024 -> 513 re + 513 im as an MFMA product)"),
                 achieved=flop / avg / 1e12, peak=PEAK_MFMA_BF16_TFLOPS, unit="TFLOP/s", frac=flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS,
                 traffic=None, avg_launch_us=avg * 1e6, launches_measured=len(durs), algorithmic_flop_per_launch=flop,
-                mfma_issue_frac=3 * flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS)
+                mfma_issue_frac=3 * flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS,
+                algorithmic_bytes_per_launch=gemm_bytes, hbm_frac_algorithmic=gemm_bytes / avg / 1e9 / PEAK_HBM_GBS,
+                dense_product_flop=2.0 * B * T2 * 1024 * 1026,
+                pipeline=dict(bound="hbm", call_us=call * 1e6, algorithmic_bytes=pipe_bytes, achieved_gbs=pipe_bytes / call / 1e9,
+                              frac=pipe_bytes / call / 1e9 / PEAK_HBM_GBS,
+                              note="frame pack + product + logmel of one call (events around the call); bytes: audio in, operand plane written + read, spectrum written + read, mel out"))
     if rank == 0:
         res = dict(metric="mel-frames/sec (on-device log-mel front-end, 64 x 800 frames, n_fft 1024 / hop 256 / 80 mel)",
                    value=world * B * T2 / dt, unit="mel-frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt * 1e3,

@@ -8,6 +8,13 @@
 //
 // The STFT is a dense MFMA product on the same contraction kernel as the model (no rocFFT, no host
 // round trip): 2.1 MFLOP per frame, less than one ResConv layer.  frame_pack and logmel are HBM-bound.
+//
+// Round 6: radix-R decimation in time (efts_frame_pack_dit / efts_logmel_dit).  The dense 1024-point product is 107.6 GFLOP per
+// 64 x 800 frames where an FFT needs ~3; splitting the frame into R interleaved sub-sequences x_p[j] = x[R j + p] turns it into R
+// real DFTs of N / R points -- ONE batched efts_gemm of R items against the same [N / R][N / R] plane: R times fewer FLOPs -- and
+//     X[f] = sum_p W_N^(p f) Y_p[f mod N/R],   Y_p[N/R - g] = conj(Y_p[g])  (real input)
+// is R complex multiply-adds per bin in front of the magnitude, in the logmel kernel.  A real M-point DFT has M independent real
+// outputs (re[0 .. M/2], im[1 .. M/2 - 1]), so the batched product has exactly N output columns.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -44,6 +51,38 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(const float* __restrict
     }
 }
 
+// the same frames with the samples of a frame de-interleaved: column (k mod R) * (N / R) + k / R holds sample k
+__global__ __launch_bounds__(256) void frame_pack_dit_kernel(const float* __restrict__ audio, long ld_audio, const int* __restrict__ lengths,
+                                                             const float* __restrict__ window, char* __restrict__ plane, long ld_plane,
+                                                             int T, int Tp, int n_fft, int hop, int split, int radix) {
+    const int row = blockIdx.x;
+    const int b = row / Tp, t = row - b * Tp;
+    const int L = lengths[b];
+    const int nfr = L / hop;
+    const int pad = (n_fft - hop) / 2;
+    const bool valid = t < T && t < nfr;
+    const float* a = audio + (long)b * ld_audio;
+    char* dst = plane + (long)row * ld_plane;
+    const int sub = n_fft / radix;
+    for (int c = threadIdx.x * 4; c < n_fft; c += 1024) {       // output column c .. c + 3: sub-sequence p, positions j .. j + 3
+        const int p = c / sub, j = c - p * sub;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float x = 0.f;
+            if (valid) {
+                const int k = radix * (j + u) + p;
+                int s = t * hop + k - pad;
+                s = s < 0 ? -s : s;
+                s = s >= L ? 2 * (L - 1) - s : s;
+                x = a[s] * window[k];
+            }
+            v[u] = x;
+        }
+        plane_store4(dst, c, v[0], v[1], v[2], v[3], split);
+    }
+}
+
 // one wave per row: magnitudes into LDS, then lane m (and m + 64) accumulates its triangular filter
 __global__ __launch_bounds__(64) void logmel_kernel(const float* __restrict__ spec, long ld_spec, const float* __restrict__ basis,
                                                     const int* __restrict__ ranges, const int* __restrict__ frames, float* __restrict__ out,
@@ -71,6 +110,48 @@ __global__ __launch_bounds__(64) void logmel_kernel(const float* __restrict__ sp
         float acc = 0.f;
         for (int k = lo; k < hi; ++k) acc += w[k] * mag[k];
         o[m] = logf(fmaxf(acc, 1e-5f));          // meldataset.py:27-28,78
+    }
+}
+
+// radix-R form: spec row = R blocks of M = N / R floats, block p = [re Y_p[0 .. M/2] | im Y_p[1 .. M/2 - 1]]; twiddle[p][f] = (cos, sin)(2 pi p f / N)
+__global__ __launch_bounds__(64) void logmel_dit_kernel(const float* __restrict__ spec, long ld_spec, const float* __restrict__ basis,
+                                                        const int* __restrict__ ranges, const int* __restrict__ frames,
+                                                        const float2* __restrict__ twiddle, float* __restrict__ out, int T, int Tp, int n_bins,
+                                                        int n_mels, int radix) {
+    extern __shared__ float mag[];
+    const int row = blockIdx.x;
+    const int b = row / Tp, t = row - b * Tp;
+    if (t >= T) return;
+    const int lane = threadIdx.x;
+    float* o = out + ((long)b * T + t) * n_mels;
+    if (t >= frames[b]) {
+        for (int m = lane; m < n_mels; m += 64) o[m] = 0.f;
+        return;
+    }
+    const int M = 2 * (n_bins - 1) / radix, half = M >> 1;
+    const float* y = spec + (long)row * ld_spec;
+    for (int f = lane; f < n_bins; f += 64) {
+        int g = f % M;
+        float sgn = 1.f;
+        if (g > half) { g = M - g; sgn = -1.f; }                 // Y[M - g] = conj(Y[g])
+        const bool real_only = g == 0 || g == half;
+        float xr = 0.f, xi = 0.f;
+        for (int p = 0; p < radix; ++p) {
+            const float* yp = y + p * M;
+            const float yr = yp[g], yi = real_only ? 0.f : sgn * yp[half + g];
+            const float2 w = twiddle[p * n_bins + f];            // W^(p f) = cos - i sin
+            xr += w.x * yr + w.y * yi;
+            xi += w.x * yi - w.y * yr;
+        }
+        mag[f] = sqrtf(xr * xr + xi * xi + 1e-9f);                // meldataset.py:75
+    }
+    __syncthreads();
+    for (int m = lane; m < n_mels; m += 64) {
+        const int lo = ranges[2 * m], hi = ranges[2 * m + 1];
+        const float* w = basis + (long)m * n_bins;
+        float acc = 0.f;
+        for (int k = lo; k < hi; ++k) acc += w[k] * mag[k];
+        o[m] = logf(fmaxf(acc, 1e-5f));                          // meldataset.py:27-28,78
     }
 }
 
@@ -102,4 +183,34 @@ extern "C" int efts_logmel(const float* spec, int64_t ld_spec, const float* basi
     hipLaunchKernelGGL(logmel_kernel, dim3(B * Tp), dim3(64), n_bins * sizeof(float), (hipStream_t)stream, spec, (long)ld_spec, basis,
                        ranges, frames, out, T, Tp, n_bins, n_mels);
     return efts_check_launch("efts_logmel");
+}
+
+extern "C" int efts_frame_pack_dit(const float* audio, int64_t ld_audio, const int32_t* lengths, const float* window, void* plane,
+                                   int64_t ld_plane, int32_t B, int32_t T, int32_t Tp, int32_t n_fft, int32_t hop, int32_t split,
+                                   int32_t radix, void* stream) {
+    if (!audio || !lengths || !window || !plane) return efts_fail(EFTS_EINVAL, "efts_frame_pack_dit: null pointer");
+    if (B <= 0 || T <= 0 || Tp < T) return efts_fail(EFTS_ESHAPE, "efts_frame_pack_dit: bad B / T / Tp");
+    if (n_fft <= 0 || hop <= 0 || hop > n_fft || ((n_fft - hop) & 1)) return efts_fail(EFTS_ESHAPE, "efts_frame_pack_dit: 0 < hop <= n_fft, n_fft - hop even");
+    if (radix < 1 || n_fft % radix || (n_fft / radix) % (split == 1 ? 64 : 32))
+        return efts_fail(EFTS_ESHAPE, "efts_frame_pack_dit: n_fft / radix must be a whole number of 128-byte operand chunks");
+    if (!(split == 1 || split == 2)) return efts_fail(EFTS_EINVAL, "efts_frame_pack_dit: split must be 1 or 2");
+    const int64_t need = (int64_t)((n_fft + (split == 1 ? 63 : 31)) / (split == 1 ? 64 : 32)) * 128;
+    if (ld_plane < need || (ld_plane & 15)) return efts_fail(EFTS_ESHAPE, "efts_frame_pack_dit: plane row stride too small / unaligned");
+    hipLaunchKernelGGL(frame_pack_dit_kernel, dim3(B * Tp), dim3(256), 0, (hipStream_t)stream, audio, (long)ld_audio, lengths, window,
+                       (char*)plane, (long)ld_plane, T, Tp, n_fft, hop, split, radix);
+    return efts_check_launch("efts_frame_pack_dit");
+}
+
+extern "C" int efts_logmel_dit(const float* spec, int64_t ld_spec, const float* basis, const int32_t* ranges, const int32_t* frames,
+                               const float* twiddle, float* out, int32_t B, int32_t T, int32_t Tp, int32_t n_bins, int32_t n_mels, int32_t radix,
+                               void* stream) {
+    if (!spec || !basis || !ranges || !frames || !out || !twiddle) return efts_fail(EFTS_EINVAL, "efts_logmel_dit: null pointer");
+    if (B <= 0 || T <= 0 || Tp < T || n_bins <= 1 || n_mels <= 0) return efts_fail(EFTS_ESHAPE, "efts_logmel_dit: bad shape");
+    const int n_fft = 2 * (n_bins - 1);
+    if (radix < 1 || n_fft % radix || ((n_fft / radix) & 1)) return efts_fail(EFTS_ESHAPE, "efts_logmel_dit: (n_bins - 1) * 2 / radix must be an even whole number");
+    if (ld_spec < (int64_t)n_fft) return efts_fail(EFTS_ESHAPE, "efts_logmel_dit: spectrum row stride smaller than n_fft");
+    if (n_bins * 4 > 64 * 1024) return efts_fail(EFTS_ESHAPE, "efts_logmel_dit: n_bins too large for the LDS tile");
+    hipLaunchKernelGGL(logmel_dit_kernel, dim3(B * Tp), dim3(64), n_bins * sizeof(float), (hipStream_t)stream, spec, (long)ld_spec, basis,
+                       ranges, frames, (const float2*)twiddle, out, T, Tp, n_bins, n_mels, radix);
+    return efts_check_launch("efts_logmel_dit");
 }

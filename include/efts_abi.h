@@ -62,7 +62,7 @@ extern "C" {
  *   100  rounds 1-4
  *   500  round 5: efts_resconv5_args grew by act_bwd_sign / act_bwd_bias_part / act_bwd_bias_rows / act_bwd_slope / kernel;
  *        efts_wgrad_tn, efts_wgrad_reduce_bias, efts_resconv5_kernel removed (efts_wgrad_tn_grouped / efts_wgrad_reduce_grouped instead)
- *   600  round 6 (this header) */
+ *   600  round 6 (this header): + efts_frame_pack_dit, efts_logmel_dit; efts_pack_item.plane may be NULL (dgrad plane only) */
 #define EFTS_ABI_VERSION 600
 int efts_version(void);
 const char* efts_last_error(void);
@@ -608,6 +608,21 @@ int efts_frame_pack(const float* audio, int64_t ld_audio, const int32_t* lengths
                     void* stream);
 int efts_logmel(const float* spec, int64_t ld_spec, const float* basis, const int32_t* ranges, const int32_t* frames,
                 float* out, int32_t B, int32_t T, int32_t Tp, int32_t n_bins, int32_t n_mels, void* stream);
+/* The same pipeline with the DFT split by decimation in time (round 6): `radix` interleaved sub-sequences x_p[j] = x[radix j + p] of
+ * M = n_fft / radix samples each.
+ *   efts_frame_pack_dit : as efts_frame_pack, but column p * M + j of a row holds sample radix * j + p of the frame, so that ONE batched
+ *                         efts_gemm (batch = radix, a_batch_stride = the bytes of M columns, nchunk = the chunks of M columns, n = M,
+ *                         out_batch_stride = M) against the B plane of the real M-point DFT -- rows 0 .. M/2: cos(2 pi g j / M), rows
+ *                         M/2 + g, g = 1 .. M/2 - 1: -sin(2 pi g j / M) -- leaves, per row, `radix` blocks [re Y_p[0 .. M/2] | im Y_p[1 .. M/2 - 1]]:
+ *                         radix times fewer FLOPs than the dense n_fft-point product.
+ *   efts_logmel_dit     : X[f] = sum_p W^(p f) Y_p[f mod M] (Y_p[M - g] = conj Y_p[g]) in front of the magnitude, then as efts_logmel.
+ *                         twiddle: fp32 [radix][n_bins][2] = (cos, sin)(2 pi p f / n_fft).  spec rows hold n_fft floats. */
+int efts_frame_pack_dit(const float* audio, int64_t ld_audio, const int32_t* lengths, const float* window, void* plane,
+                        int64_t ld_plane, int32_t B, int32_t T, int32_t Tp, int32_t n_fft, int32_t hop, int32_t split,
+                        int32_t radix, void* stream);
+int efts_logmel_dit(const float* spec, int64_t ld_spec, const float* basis, const int32_t* ranges, const int32_t* frames,
+                    const float* twiddle, float* out, int32_t B, int32_t T, int32_t Tp, int32_t n_bins, int32_t n_mels, int32_t radix,
+                    void* stream);
 
 /* ------------------------------------------------------------------------------------
  * HiFi-GAN generator (nntts/vocoders/hifigan_model.py:95-136): every Conv1d /

@@ -115,3 +115,30 @@ def test_frontend_edge_cases_and_model_handoff():
     with torch.no_grad():
         out = model(text, tl, mel, frames)
     assert torch.isfinite(out[0]).all() and out[4].shape == mel.shape
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("radix", [1, 2, 4, 8, 16])
+def test_frontend_radix_split_dft_equals_the_dense_product(radix):
+    """round 6: the DFT split by decimation in time (`radix` real DFTs of 1024 / radix points as one batched contraction, recombined in the
+    logmel kernel) against the oracle's torch.stft, for every radix incl. the dense 1024-point product (radix 1) -- same tolerance -- and
+    against the dense product's own output (summation order only: well inside the tolerance)."""
+    from efficient_tts_amd.frontend import LogMelFrontend
+    g = np.load(GOLD)
+    a16, lengths = torch.from_numpy(g["audio"]), torch.from_numpy(g["lengths"])
+    mel, frames = LogMelFrontend("cuda:0", radix=radix)(a16, lengths)
+    assert frames.tolist() == g["frames"].tolist()
+    err = np.abs(mel.cpu().numpy() - g["mel"]).max()
+    print(f"radix {radix}: log-mel max-abs vs the oracle fixture {err:.2e}")
+    assert err < LOGMEL_TOL, err
+    dense, _ = LogMelFrontend("cuda:0", radix=1)(a16, lengths)
+    assert float((mel - dense).abs().max()) < LOGMEL_TOL / 2
+    # ragged edge cases through the split path: shortest legal item, non-multiple of hop, garbage past the length
+    gen = torch.Generator().manual_seed(3)
+    lengths = torch.tensor([385 + 256, 256 * 7 + 255, 256 * 40, 1000])
+    audio = (torch.rand(4, int(lengths.max()), generator=gen) * 2 - 1) * 0.5
+    for b, l in enumerate(lengths):
+        audio[b, int(l):] = 123.0
+    mel, frames = LogMelFrontend("cuda:0", radix=radix)(audio, lengths)
+    ref, rfr = LO.batch_logmel(audio, lengths)
+    assert frames.tolist() == rfr.tolist() and float((mel.cpu() - ref).abs().max()) < LOGMEL_TOL
