@@ -459,7 +459,7 @@ def run_logmel64(a, world, rank, dev):
     g = torch.Generator().manual_seed(1234 + rank)
     audio = (torch.rand(B, T2 * 256, generator=g) * 2 - 1).mul_(0.3).to(dev)
     lengths = torch.full((B,), T2 * 256)
-    fe = LogMelFrontend(dev)
+    fe = LogMelFrontend(dev, radix=int(os.environ.get("EFTS_LOGMEL_RADIX", "4")))       # (EFTS_LOGMEL_RADIX: A/B of the DFT split, tools/r06_call7.sh)
     for _ in range(max(a.warmup, 1)):
         mel, frames = fe(audio, lengths)
     torch.cuda.synchronize()
