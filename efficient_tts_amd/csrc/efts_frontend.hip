@@ -51,10 +51,15 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(const float* __restrict
     }
 }
 
-// the same frames with the samples of a frame de-interleaved: column (k mod R) * (N / R) + k / R holds sample k
+// the same frames with the samples of a frame de-interleaved: column (k mod R) * (N / R) + k / R holds sample k.  The frame goes through LDS:
+// samples are read the way they lie in memory (4 consecutive ones per thread: whole cache lines per wave) and dropped at their de-interleaved
+// position (LDS index u * N/R + j for the thread's samples R j' + u: consecutive threads, consecutive words), then every thread takes the 4
+// consecutive COLUMNS of its plane store.  (Gathering the columns straight from memory used a quarter of every cache line per wave: 190 us per
+// 64 x 800 frames against 100 for the natural order.)
 __global__ __launch_bounds__(256) void frame_pack_dit_kernel(const float* __restrict__ audio, long ld_audio, const int* __restrict__ lengths,
                                                              const float* __restrict__ window, char* __restrict__ plane, long ld_plane,
                                                              int T, int Tp, int n_fft, int hop, int split, int radix) {
+    extern __shared__ float fr[];            // [n_fft], de-interleaved
     const int row = blockIdx.x;
     const int b = row / Tp, t = row - b * Tp;
     const int L = lengths[b];
@@ -64,22 +69,24 @@ __global__ __launch_bounds__(256) void frame_pack_dit_kernel(const float* __rest
     const float* a = audio + (long)b * ld_audio;
     char* dst = plane + (long)row * ld_plane;
     const int sub = n_fft / radix;
-    for (int c = threadIdx.x * 4; c < n_fft; c += 1024) {       // output column c .. c + 3: sub-sequence p, positions j .. j + 3
-        const int p = c / sub, j = c - p * sub;
-        float v[4];
+    for (int k = threadIdx.x * 4; k < n_fft; k += 1024) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             float x = 0.f;
             if (valid) {
-                const int k = radix * (j + u) + p;
-                int s = t * hop + k - pad;
+                int s = t * hop + k + u - pad;
                 s = s < 0 ? -s : s;
                 s = s >= L ? 2 * (L - 1) - s : s;
-                x = a[s] * window[k];
+                x = a[s] * window[k + u];
             }
-            v[u] = x;
+            const int kk = k + u;
+            fr[(kk % radix) * sub + kk / radix] = x;
         }
-        plane_store4(dst, c, v[0], v[1], v[2], v[3], split);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x * 4; c < n_fft; c += 1024) {
+        const float4 v = *(const float4*)(fr + c);
+        plane_store4(dst, c, v.x, v.y, v.z, v.w, split);
     }
 }
 
@@ -155,6 +162,108 @@ __global__ __launch_bounds__(64) void logmel_dit_kernel(const float* __restrict_
     }
 }
 
+// The same with the twiddles in REGISTERS and the spectrum row staged through LDS: lane l owns the bins f = l + 64 i (i < NB), loads its
+// (R - 1) * NB twiddles once and then works through LM_ROWS rows (the table version above re-read 16 KiB of twiddles per row from L2: 226 us per
+// 64 x 800 frames against 150 for the dense spectrum's kernel).  N = 1024 only (NB = 9 bins per lane).
+constexpr int LM_ROWS = 16, LM_NB = 9, LM_CB = 2048;
+template <int R>
+__global__ __launch_bounds__(64) void logmel_dit_fast_kernel(const float* __restrict__ spec, long ld_spec, const float* __restrict__ basis,
+                                                             const int* __restrict__ ranges, const int* __restrict__ frames,
+                                                             const float2* __restrict__ twiddle, float* __restrict__ out, int T, int Tp,
+                                                             int rows_total, int n_mels) {
+    constexpr int N = 1024, NBINS = 513, M = N / R, HALF = M / 2;
+    __shared__ __attribute__((aligned(16))) float y[N];
+    __shared__ float mag[NBINS + 3];
+    __shared__ float cb[LM_CB];              // the filterbank's non-zero spans, filter after filter (every bin lies in at most two triangles: ~1 030 weights)
+    __shared__ int offs[129];
+    const int lane = threadIdx.x;
+    float2 tw[R - 1][LM_NB];
+#pragma unroll
+    for (int p = 1; p < R; ++p)
+#pragma unroll
+        for (int i = 0; i < LM_NB; ++i) {
+            const int f = lane + 64 * i;
+            tw[p - 1][i] = f < NBINS ? twiddle[p * NBINS + f] : make_float2(0.f, 0.f);
+        }
+    // this lane's filters: m = lane and m = lane + 64; their weights go to LDS once per block (the mel sums were a chain of up to 40 dependent
+    // L2 reads per lane and row: the longest part of the kernel)
+    int flo[2], fhi[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int m = lane + 64 * h;
+        flo[h] = m < n_mels ? ranges[2 * m] : 0;
+        fhi[h] = m < n_mels ? ranges[2 * m + 1] : 0;
+    }
+    if (lane == 0) {
+        int acc = 0;
+        for (int m = 0; m < n_mels; ++m) { offs[m] = acc; acc += ranges[2 * m + 1] - ranges[2 * m]; }
+        offs[n_mels] = acc;
+    }
+    __syncthreads();
+    const bool in_lds = offs[n_mels] <= LM_CB;
+    if (in_lds) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = lane + 64 * h;
+            if (m < n_mels) {
+                const float* w = basis + (long)m * NBINS;
+                for (int k = flo[h]; k < fhi[h]; ++k) cb[offs[m] + k - flo[h]] = w[k];
+            }
+        }
+    }
+    for (int rr = 0; rr < LM_ROWS; ++rr) {
+        const int row = blockIdx.x * LM_ROWS + rr;
+        if (row >= rows_total) return;
+        const int b = row / Tp, t = row - b * Tp;
+        if (t >= T) continue;
+        float* o = out + ((long)b * T + t) * n_mels;
+        if (t >= frames[b]) {
+            for (int m = lane; m < n_mels; m += 64) o[m] = 0.f;
+            continue;
+        }
+        const float4* src = (const float4*)(spec + (long)row * ld_spec);
+        __syncthreads();                                         // (the previous row's readers are done with y / mag)
+#pragma unroll
+        for (int i = 0; i < N / 256; ++i) ((float4*)y)[lane + 64 * i] = src[lane + 64 * i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < LM_NB; ++i) {
+            const int f = lane + 64 * i;
+            if (f < NBINS) {
+                int g = f & (M - 1);
+                float sgn = 1.f;
+                if (g > HALF) { g = M - g; sgn = -1.f; }
+                const bool real_only = g == 0 || g == HALF;
+                float xr = y[g], xi = real_only ? 0.f : sgn * y[HALF + g];          // p = 0: W^0 = 1
+#pragma unroll
+                for (int p = 1; p < R; ++p) {
+                    const float yr = y[p * M + g], yi = real_only ? 0.f : sgn * y[p * M + HALF + g];
+                    const float2 w = tw[p - 1][i];
+                    xr += w.x * yr + w.y * yi;
+                    xi += w.x * yi - w.y * yr;
+                }
+                mag[f] = sqrtf(xr * xr + xi * xi + 1e-9f);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = lane + 64 * h;
+            if (m < n_mels) {
+                float acc = 0.f;
+                if (in_lds) {
+                    const float* w = cb + offs[m] - flo[h];
+                    for (int k = flo[h]; k < fhi[h]; ++k) acc += w[k] * mag[k];
+                } else {
+                    const float* w = basis + (long)m * NBINS;
+                    for (int k = flo[h]; k < fhi[h]; ++k) acc += w[k] * mag[k];
+                }
+                o[m] = logf(fmaxf(acc, 1e-5f));
+            }
+        }
+    }
+}
+
 }  // namespace efts
 
 using namespace efts;
@@ -196,7 +305,8 @@ extern "C" int efts_frame_pack_dit(const float* audio, int64_t ld_audio, const i
     if (!(split == 1 || split == 2)) return efts_fail(EFTS_EINVAL, "efts_frame_pack_dit: split must be 1 or 2");
     const int64_t need = (int64_t)((n_fft + (split == 1 ? 63 : 31)) / (split == 1 ? 64 : 32)) * 128;
     if (ld_plane < need || (ld_plane & 15)) return efts_fail(EFTS_ESHAPE, "efts_frame_pack_dit: plane row stride too small / unaligned");
-    hipLaunchKernelGGL(frame_pack_dit_kernel, dim3(B * Tp), dim3(256), 0, (hipStream_t)stream, audio, (long)ld_audio, lengths, window,
+    if ((n_fft & 3) || n_fft * 4 > 64 * 1024) return efts_fail(EFTS_ESHAPE, "efts_frame_pack_dit: n_fft must be a multiple of 4 and fit the LDS tile");
+    hipLaunchKernelGGL(frame_pack_dit_kernel, dim3(B * Tp), dim3(256), n_fft * sizeof(float), (hipStream_t)stream, audio, (long)ld_audio, lengths, window,
                        (char*)plane, (long)ld_plane, T, Tp, n_fft, hop, split, radix);
     return efts_check_launch("efts_frame_pack_dit");
 }
@@ -210,6 +320,15 @@ extern "C" int efts_logmel_dit(const float* spec, int64_t ld_spec, const float* 
     if (radix < 1 || n_fft % radix || ((n_fft / radix) & 1)) return efts_fail(EFTS_ESHAPE, "efts_logmel_dit: (n_bins - 1) * 2 / radix must be an even whole number");
     if (ld_spec < (int64_t)n_fft) return efts_fail(EFTS_ESHAPE, "efts_logmel_dit: spectrum row stride smaller than n_fft");
     if (n_bins * 4 > 64 * 1024) return efts_fail(EFTS_ESHAPE, "efts_logmel_dit: n_bins too large for the LDS tile");
+    if (n_fft == 1024 && n_mels <= 128 && (ld_spec & 3) == 0 && ((uintptr_t)spec & 15) == 0 && (radix == 2 || radix == 4 || radix == 8)) {
+        const int rows = B * Tp;
+        const dim3 grid((rows + LM_ROWS - 1) / LM_ROWS);
+#define EFTS_LMF(R) hipLaunchKernelGGL(logmel_dit_fast_kernel<R>, grid, dim3(64), 0, (hipStream_t)stream, spec, (long)ld_spec, basis, ranges, frames, \
+                                       (const float2*)twiddle, out, T, Tp, rows, n_mels)
+        if (radix == 2) EFTS_LMF(2); else if (radix == 4) EFTS_LMF(4); else EFTS_LMF(8);
+#undef EFTS_LMF
+        return efts_check_launch("efts_logmel_dit");
+    }
     hipLaunchKernelGGL(logmel_dit_kernel, dim3(B * Tp), dim3(64), n_bins * sizeof(float), (hipStream_t)stream, spec, (long)ld_spec, basis,
                        ranges, frames, (const float2*)twiddle, out, T, Tp, n_bins, n_mels, radix);
     return efts_check_launch("efts_logmel_dit");

@@ -16,6 +16,12 @@ int efts_num_cus(void);
 
 // geometry of a grouped (stream-K) wgrad launch, shared by efts_wgrad_tn_grouped and efts_wgrad_reduce_grouped (efts_wgrad.hip)
 struct efts_wgrad_sk_geom { int steps_tile, tiles_item, ntn, nx, q, total, workgroups, maxseg; };
+// the launch's geometry as efts_wgrad_tn_grouped leaves it behind the last slab of `part` (8 int32) and efts_wgrad_reduce_grouped expects to find it:
+// a reduction called with other arguments than the launch that filled `part` would sum slabs that were never written -- it writes NaN instead
+#define EFTS_WGRAD_STAMP_MAGIC 0x57475236
+static inline void efts_wgrad_stamp(int* st, int count, int rows, int cout, int cin, int taps, int split, const efts_wgrad_sk_geom& gm) {
+    st[0] = EFTS_WGRAD_STAMP_MAGIC; st[1] = count; st[2] = rows; st[3] = cout; st[4] = cin; st[5] = taps; st[6] = split; st[7] = gm.workgroups;
+}
 __attribute__((visibility("hidden"))) int efts_wgrad_sk_geometry(int count, int rows, int cout, int cin, int split, int workgroups, efts_wgrad_sk_geom* gm);
 
 namespace efts {

@@ -847,6 +847,8 @@ struct WrSkArgs {
     const float* part;
     int cout, cin, taps;
     int tiles_item, ntn, nx, steps_tile, q, maxseg;
+    int stamp[8];
+    const int* stamp_src;
 };
 
 __global__ __launch_bounds__(256) void wgrad_reduce_sk_kernel(WrSkArgs p) {
@@ -855,6 +857,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_sk_kernel(WrSkArgs p) {
     const int item = blockIdx.x / p.cout, co = blockIdx.x - item * p.cout;
     const WrItem& q = p.it[item];
     const int cin = p.cin, taps = p.taps, n = cin * taps;
+    bool stale = false;                                // `part` was filled by a launch of another geometry (or by none): NaN, loudly, instead of a wrong sum
+#pragma unroll
+    for (int i = 0; i < 8; ++i) stale |= p.stamp_src[i] != p.stamp[i];
+    if (stale) {
+        float* o = q.dw_or_dv + (long)co * n;
+        for (int idx = threadIdx.x; idx < n; idx += 256) o[idx] = __builtin_nanf("");
+        if (threadIdx.x == 0) { if (q.dg) q.dg[co] = __builtin_nanf(""); if (q.bias_part) q.dbias[co] = __builtin_nanf(""); }
+        return;
+    }
     if (q.bias_part) {
         float b = 0.f;
         for (int i = threadIdx.x; i < q.nparts; i += 256) b += q.bias_part[(long)i * p.cout + co];
@@ -918,6 +929,8 @@ extern "C" int efts_wgrad_reduce_grouped(const efts_wgrad_item* items, int32_t c
     }
     k.part = part; k.cout = cout; k.cin = cin; k.taps = taps;
     k.tiles_item = gm.tiles_item; k.ntn = gm.ntn; k.nx = gm.nx; k.steps_tile = gm.steps_tile; k.q = gm.q; k.maxseg = gm.maxseg;
+    efts_wgrad_stamp(k.stamp, count, rows, cout, cin, taps, split, gm);
+    k.stamp_src = (const int*)(part + (size_t)gm.workgroups * gm.maxseg * taps * 128 * 64);
     hipLaunchKernelGGL(wgrad_reduce_sk_kernel, dim3(count * cout), dim3(256), (size_t)cin * taps * sizeof(float), ST, k);
     return efts_check_launch("efts_wgrad_reduce_grouped");
 }

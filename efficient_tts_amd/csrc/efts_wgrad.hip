@@ -204,12 +204,15 @@ struct WgSkArgs {
     int nx;                       // 8: tile T belongs to XCD T % 8 (workgroup w runs on XCD w % 8); 1: one list
     int steps_tile, q, total;     // steps per tile; steps per workgroup; steps of one list
     int maxseg;
+    int stamp[8];                 // written behind the slabs by workgroup 0: what the reduction checks (efts_internal.h)
+    int* stamp_dst;
 };
 
 template <int SPLIT, int TAPS>
 __global__ __launch_bounds__(256, 2) void wgrad_sk_kernel(WgSkArgs p) {
     using C = WgCfg<SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (blockIdx.x == 0 && threadIdx.x < 8) p.stamp_dst[threadIdx.x] = p.stamp[threadIdx.x];
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -275,7 +278,7 @@ int efts_wgrad_sk_geometry(int count, int rows, int cout, int cin, int split, in
 extern "C" int64_t efts_wgrad_grouped_part_bytes(int32_t count, int32_t rows, int32_t cout, int32_t cin, int32_t taps, int32_t split, int32_t workgroups) {
     efts_wgrad_sk_geom gm;
     if (efts_wgrad_sk_geometry(count, rows, cout, cin, split, workgroups, &gm)) return -1;
-    return (int64_t)gm.workgroups * gm.maxseg * taps * 128 * 64 * 4;
+    return (int64_t)gm.workgroups * gm.maxseg * taps * 128 * 64 * 4 + 64;        // (+ the geometry stamp)
 }
 
 extern "C" int efts_wgrad_tn_grouped(const efts_wgrad_item* items, int32_t count, float* part, int32_t rows, int32_t cout, int32_t cin,
@@ -296,6 +299,8 @@ extern "C" int efts_wgrad_tn_grouped(const efts_wgrad_item* items, int32_t count
     }
     k.part = part; k.tiles_item = gm.tiles_item; k.ntn = gm.ntn; k.nx = gm.nx; k.steps_tile = gm.steps_tile; k.q = gm.q; k.total = gm.total;
     k.maxseg = gm.maxseg;
+    efts_wgrad_stamp(k.stamp, count, rows, cout, cin, taps, split, gm);
+    k.stamp_dst = (int*)(part + (size_t)gm.workgroups * gm.maxseg * taps * 128 * 64);
     const dim3 grid(gm.workgroups);
 #define EFTS_WGSK(S, T)                                                                                                                  \
     do {                                                                                                                                 \

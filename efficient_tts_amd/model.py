@@ -288,10 +288,8 @@ class EfficientTTSCNN(torch.nn.Module):
         why EftsAdam resets it and why consumers of derived data compare `_packed_gen`, never the signature.
         `phase_of(name, has_dgrad_plane) -> [(phase, with_dgrad_plane, with_forward_plane), ...]` (round 6, the training pass): the repack in PHASES.  Nothing is
         launched here then; `_issue_packs(phase)` enqueues a phase's grouped launches on the CURRENT stream, and the caller places the phases
-        where their first consumer needs them -- the forward planes of the text encoder / of the mel encoder and prenet in front of the two
-        chains of the step, everything else (decoder, mel head, key / value, duration predictor, and every transposed dgrad plane) beside or
-        behind them.  The whole repack stood in front of both chains with 110 us of launches; skipping it altogether returned 0.38 ms
-        (profiles/train_skip_bounds_r05.txt).  Every phase of a repack must be issued before the next one is scheduled."""
+        where their first consumer needs them (the training pass: the text side's planes on the text stream, the rest on the main one; a phase
+        entry with with_forward_plane = False writes the dgrad plane only).  Every phase of a repack must be issued before the next one is scheduled."""
         sig = tuple((p.data_ptr(), p._version) for p in (params if params is not None else self.parameters()))
         if sig == self._packed_sig:
             return self._packed

@@ -24,7 +24,9 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-# Test / A-B hooks of the training pass (module-level: bench.py --train-set NAME=INT, tests).  `switch_tag()` is what a captured step
+# Test hooks and tuning constants of the training pass (module-level: bench.py --train-set NAME=INT, tests).  Round 6 removed the decided A/Bs
+# (_PACK_SPLIT, _NARROW_TN, _EARLY_PACKS: always on) and did not keep its own (_WGRAD_EARLY, _TEXT_RIDERS, _HEAD_ORDER, _PACK_LATE,
+# _WGRAD_GROUP_WGS_ME: all measured slower or equal, profiles/train_ab_r06.txt).  `switch_tag()` is what a captured step
 # (step_graph.GraphedStep) is valid for.  Finished A/Bs of earlier rounds are no longer switches: the direct wgrad for taps 1 / 3
 # (was _WGRAD_TN_SMALL) and the prenet through efts_frame_linear (was _FRAME_PRENET) are simply the code.
 _WGRAD_TN_SPLITS = 8         # > 0: weight gradients on the direct (row-major, stream-K) kernel wherever its tiles fit; 0 = everything through the transposed
@@ -48,16 +50,10 @@ _WGRAD_GROUP_WGS = 384       # workgroups of a grouped launch (0: two per CU).  
                              # 3.28-3.34 at 256 (per-layer launches: 3.48-3.50); the launch is bound by the chip, not by its busiest CU
 
 
-_WGRAD_GROUP_WGS_ME = 0      # workgroups of the mel encoder's grouped launch (3 layers = 96 tiles); 0: _WGRAD_GROUP_WGS (A/B)
-_PACK_LATE = -1              # round 6: the weight repack in phases (TrainEngine._pack_phase) -- what the step's first launches read in front of them, everything
-                             # else beside or behind the head of the step; 0: the whole repack in front of both chains; -1: where it measured faster -- bf16x3, whose
-                             # planes are twice the size (graphed B = 32 step 6.10 -> 5.90-5.95 ms; bf16: 3.23 -> 3.25-3.27, profiles/train_ab_r06.txt)
-
-
 def switch_tag() -> tuple:
     """every hook above, by value: part of the tag of a captured training step"""
     return (_WGRAD_TN_SPLITS, _SIGN_MIN_ROWS, _BIAS_PARTS, _RESCONV_FWD, _RESCONV_DGRAD, _WGRAD_WGS,
-            _WGRAD_GROUP_WGS, _FUSE_ACT_BWD, O.RC_KERNEL, _WGRAD_STREAM, _PACK_LATE, _WGRAD_GROUP_WGS_ME)
+            _WGRAD_GROUP_WGS, _FUSE_ACT_BWD, O.RC_KERNEL, _WGRAD_STREAM)
 
 
 class _TPlane(Plane):
@@ -145,24 +141,13 @@ class TrainEngine:
         return set(cur) != set(self.g) or any(cur[n].shape != self.g[n].shape or cur[n].device != self.dev for n in cur)
 
     # ------------------------------------------------------------------ weights for the backward
-    def _pack_late(self) -> bool:
-        return bool(_PACK_LATE) if _PACK_LATE >= 0 else self.m.split == 2
-
-    def _pack_phase(self, name: str, has_t: bool):
-        """where a weight's planes are repacked in the training step (model._weights(phase_of=...)):
-        "te" / "me": the forward planes of the text encoder / of the mel encoder and the prenet, in front of the two chains of the step;
-        "kv": key, value and duration-predictor planes (forward + dgrad), on the text stream behind the text encoder's launches;
-        "tet": the text encoder's dgrad planes, on the text stream behind the duration predictor;
-        "late": decoder, mel head, mel_query_fc (forward + dgrad) and the mel encoder's dgrad planes, on the third stream beside the head"""
-        if not self._pack_late():
-            return [("te" if name.startswith(("text_encoder.", "dur.", "key", "value")) else "me", has_t, True)]
-        if name.startswith("text_encoder."):
-            return [("te", False, True)] + ([("tet", True, False)] if has_t else [])
-        if name.startswith(("mel_encoder.", "prenet")):
-            return [("me", False, True)] + ([("late", True, False)] if has_t else [])
-        if name.startswith(("dur.", "key", "value")):
-            return [("kv", has_t, True)]
-        return [("late", has_t, True)]
+    @staticmethod
+    def _pack_phase(name: str, has_t: bool):
+        """where a weight's planes are repacked in the training step (model._weights(phase_of=...)): "te" = on the text stream (text encoder,
+        duration predictor, key / value), "me" = on the main stream (everything else); forward and dgrad plane in one pass.  Round 6 measured a finer
+        split -- only the planes the step's first launches read in front of them, the rest beside / behind the head of the step on the third stream:
+        3.23 -> 3.25-3.27 ms (bf16), 5.93-5.97 -> 6.02-6.05 (bf16x3) under bench.py's clock (profiles/train_ab_r06.txt): not kept."""
+        return [("te" if name.startswith(("text_encoder.", "dur.", "key", "value")) else "me", has_t, True)]
 
     def _prepare_weights(self):
         """forward planes, folded fp32 weights and transposed/flipped dgrad planes, all from `model._weights` (a handful
@@ -424,7 +409,7 @@ class TrainEngine:
             G = Gn
         if group:
             with self._forked(wgrad_stream):
-                self._wgrad_group(ws, group, C, C, rs.rows, m.k_size, m.split, _WGRAD_GROUP_WGS_ME if tag == "me" else None)
+                self._wgrad_group(ws, group, C, C, rs.rows, m.k_size, m.split)
         return G
 
     def forward_backward(self, text, text_lengths, speech, speech_lengths, gscale: Optional[torch.Tensor] = None,
@@ -455,24 +440,12 @@ class TrainEngine:
             O.row_masks(ml, rs2, gap2, len2)
         # the repack of the operand planes (weight-norm fold + bf16 planes + dgrad planes, ~110 us on one stream): the text-side planes on
         # the stream the text side runs on, the mel-side planes here -- both behind the masks and the previous step's optimizer
-        # (round 6: in phases -- only what the step's first launches read stands in front of them, see _pack_phase)
         side0 = m._side_stream(dev)
         side0.wait_stream(torch.cuda.current_stream(dev))
-        late0 = m._aux_stream(dev) if (self._pack_late() and m.side_stream) else None
-        if late0 is not None:
-            late0.wait_stream(torch.cuda.current_stream(dev))
         pk = self._prepare_weights()
         m._issue_packs("me")
         with O.on_stream(side0):
             m._issue_packs("te")
-        ev_late = None
-        if late0 is not None:
-            with O.on_stream(late0):
-                m._issue_packs("late")
-            ev_late = torch.cuda.Event()
-            ev_late.record(late0)
-        else:
-            m._issue_packs("late")
         self.flat.zero_()
 
         # Two HIP streams.  The text-length work (embedding, text encoder, K/V, duration predictor and all of their
@@ -514,7 +487,6 @@ class TrainEngine:
             shared = m.share_text_encoder_key_value                 # efficient_tts.py:150-153: the value is the key projection
             wk = pk["key"]
             wv = wk if shared else pk["value"]
-            m._issue_packs("kv")                                    # key / value / duration-predictor planes: behind the text encoder's launches
             O.gemm(a=te_p, b_ptr=wk.ptr, ldb=wk.ld, m=rs1.rows, n=C, bias=m.text_encoder_key.bias, rowmask_ptr=len1.data_ptr(),
                    out_f32_ptr=key_f.ptr, ldo=C, out_plane=key_p)
             O.gemm(a=te_p, b_ptr=wv.ptr, ldb=wv.ld, m=rs1.rows, n=C, bias=(m.text_encoder_key if shared else m.text_encoder_value).bias,
@@ -534,7 +506,6 @@ class TrainEngine:
                    bias=dp.conv[1][0].bias, out_f32_ptr=h2_f.ptr, ldo=C)
             O.layernorm_dot(h2_f.ptr, ln1.weight.detach(), ln1.bias.detach(), ln1.eps, dp.linear.weight.detach(),
                             dp.linear.bias.detach(), len1.data_ptr(), 0, float(dp.offset), dur, rs1.rows, C, drop_p, seed1, sadd)
-            m._issue_packs("tet")                                   # the text encoder's dgrad planes: this stream's idle time
             ev_dur = torch.cuda.Event()
             ev_dur.record(side)
             self._ws_tag = ""
@@ -600,8 +571,6 @@ class TrainEngine:
             O.gemm(a=ra_p, b_ptr=vt.ptr, ldb=vt.ld, m=T2, n=C, batch=B, a_batch_stride=rs2.Tp * ra_p.ld, b_batch_stride=C * vt.ld,
                    rowmask_ptr=len2.data_ptr(), rowmask_batch_stride=rs2.Tp, out_f32_ptr=h_f.ptr, ldo=C, out_batch_stride=rs2.Tp * C,
                    out_plane=h_p, outb_batch_stride=rs2.Tp * h_p.ld)
-        if ev_late is not None:
-            main.wait_event(ev_late)                                # decoder / head planes (and every dgrad plane this stream reads later)
         d_f, d_p, dec_saved = self._stack_fwd(ws, "dec", "decoder", pk, rs2, h_f, h_p, gap2.data_ptr(), split)
         if self.mark is not None:
             self.mark("fwd_decoder_done")

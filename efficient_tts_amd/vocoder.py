@@ -25,6 +25,7 @@ There is no CPU path.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Dict, List, Optional
 
 import torch
@@ -105,6 +106,7 @@ class HiFiGANGenerator(nn.Module):
         # per-shape hipGraph of the ~85 launches of a call (round 6; efficient_tts_amd/graphs.py, the acoustic model's cache): one utterance is
         # 2 ms of device work issued by a host that needs about as long for the launches; `graphs = False`: every launch issued eagerly
         self.graphs = True
+        self.branch_streams = True          # the residual blocks of a stage on streams of their own (False: one after the other, A/B)
         from .graphs import GraphCache
         object.__setattr__(self, "_graph_cache", GraphCache(capacity=4))
 
@@ -180,7 +182,7 @@ class HiFiGANGenerator(nn.Module):
             n_i = rows * u
             b[f"up{i}"] = _Rows((rows + 1) * u, cout, sp, dev, plane=False)  # the [rows + 1][u * cout] GEMM result, seen as rows of cout
             b[f"x{i}"] = _Rows(n_i, cout, sp, dev, f32=False)                # plane of leaky(x_i)
-            b[f"t{i}"] = _Rows(n_i, cout, sp, dev, f32=False)                # plane of leaky(xt)
+            b[f"t{i}"] = [_Rows(n_i, cout, sp, dev, f32=False) for _ in self.res_kernels]   # plane of leaky(xt), one per residual block (they run side by side)
             b[f"r{i}"] = [[_Rows(n_i, cout, sp, dev) for _ in range(2)] for _ in self.res_kernels]   # ping-pong per residual block
             b[f"s{i}"] = _Rows(n_i, cout, sp, dev, f32=False)                # plane of leaky(mean)
             b["mask"].append(torch.zeros(n_i + 1, dtype=torch.float32, device=dev))
@@ -189,6 +191,13 @@ class HiFiGANGenerator(nn.Module):
         b["out"] = torch.zeros(rows + 256, 1, dtype=torch.float32, device=dev)
         self._bufs[key] = b
         return b
+
+    def _branch_streams(self, dev, count: int):
+        st = getattr(self, "_bstreams", None)
+        if st is None or len(st) != count or (count and st[0].device != dev):
+            st = [torch.cuda.Stream(device=dev) for _ in range(count)]
+            object.__setattr__(self, "_bstreams", st)
+        return st
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -269,19 +278,39 @@ class HiFiGANGenerator(nn.Module):
             # the transposed convolution's cropped border samples, which land in the zero rows between items
             L.check(lib.efts_act_bwd(x_f, x_f, None, mask.data_ptr(), LRELU_SLOPE, 3, None, x_p.ptr, x_p.ld, sp, None, n_i, cout, st),
                     "efts_act_bwd")
-            finals: List[int] = []
-            for j, k in enumerate(self.res_kernels):
-                rb = self.resblocks[n]
-                r_f, r_p, pp = x_f, x_p, b[f"r{i}"][j]
-                for d_i, d in enumerate(rb.dilation):
-                    tp = b[f"t{i}"].p
-                    self._conv(pk, f"rb{n}.c1.{d_i}", r_p, n_i, k, d, mask=mask, out_p=tp, plane_slope=LRELU_SLOPE)  # :47-48 (+ :49)
-                    nxt = pp[d_i & 1]
-                    self._conv(pk, f"rb{n}.c2.{d_i}", tp, n_i, k, 1, mask=mask, out_f=nxt.fptr, ldo=cout, out_p=nxt.p,
-                               plane_slope=LRELU_SLOPE, resid=r_f, ldr=cout)                                        # :50-51
-                    r_f, r_p = nxt.fptr, nxt.p
-                finals.append(r_f)
-                n += 1
+            # The residual blocks of a stage (kernel sizes 3 / 7 / 11) are independent until their mean (:123-128): each runs as a chain of its own
+            # on its own stream (round 6).  At one utterance a launch is 50-200 workgroups for 15-30 us: eighteen of them in a row per stage were
+            # latency, not work (profiles/rocprofv3_r06_vocoder_summary.txt); two chains' workgroups fit a CU's LDS side by side.
+            finals: List[int] = [0] * len(self.res_kernels)
+            main = torch.cuda.current_stream(dev)
+            side = self._branch_streams(dev, len(self.res_kernels) - 1) if self.branch_streams else []
+            ev_x = torch.cuda.Event()
+            ev_x.record(main)
+            joins = []
+            order = sorted(range(len(self.res_kernels)), key=lambda j: -self.res_kernels[j])       # the longest chain is issued first
+            for slot, j in enumerate(order):
+                k = self.res_kernels[j]
+                rb = self.resblocks[n + j]
+                own = side[slot] if slot < len(side) else None                                   # the last (shortest) chain stays on the main stream
+                if own is not None:
+                    own.wait_event(ev_x)
+                with (O.on_stream(own) if own is not None else contextlib.nullcontext()):
+                    r_f, r_p, pp = x_f, x_p, b[f"r{i}"][j]
+                    tp = b[f"t{i}"][j].p
+                    for d_i, d in enumerate(rb.dilation):
+                        self._conv(pk, f"rb{n + j}.c1.{d_i}", r_p, n_i, k, d, mask=mask, out_p=tp, plane_slope=LRELU_SLOPE)  # :47-48 (+ :49)
+                        nxt = pp[d_i & 1]
+                        self._conv(pk, f"rb{n + j}.c2.{d_i}", tp, n_i, k, 1, mask=mask, out_f=nxt.fptr, ldo=cout, out_p=nxt.p,
+                                   plane_slope=LRELU_SLOPE, resid=r_f, ldr=cout)                                        # :50-51
+                        r_f, r_p = nxt.fptr, nxt.p
+                    finals[j] = r_f
+                    if own is not None:
+                        ev = torch.cuda.Event()
+                        ev.record(own)
+                        joins.append(ev)
+            for ev in joins:
+                main.wait_event(ev)
+            n += len(self.res_kernels)
             last = i == len(self.upsample_rates) - 1
             s_p = b[f"s{i}"].p
             L.check(lib.efts_mean_act_rows(finals[0], finals[1] if len(finals) > 1 else None, finals[2] if len(finals) > 2 else None,

@@ -521,7 +521,8 @@ int efts_wgrad_reduce(const float* part, int32_t nsplit, const float* v, const f
  * in `part` (efts_wgrad_grouped_part_bytes() bytes; -1: bad arguments), and efts_wgrad_reduce_grouped -- called with the SAME count, rows, cout, cin,
  * taps, split and workgroups -- adds a tile's slabs in a fixed order, then per layer the weight-norm backward (g != NULL) and the bias
  * gradient dbias[co] += sum_i bias_part[i][co], i < nparts (the workspace efts_act_bwd fills in EFTS_ACT_BWD_BIAS_PARTS mode, or a dgrad
- * launch's act_bwd_bias_part), in a fixed order. */
+ * launch's act_bwd_bias_part), in a fixed order.  The launch leaves its geometry behind the slabs (the last 64 bytes of `part`); a reduction whose
+ * arguments do not match the launch that filled `part` writes NaN into every output instead of a sum over slabs that were never written. */
 #define EFTS_WGRAD_MAX_ITEMS 8
 typedef struct efts_wgrad_item {
     const void* dz_plane;   /* operand plane of dZ, row 0 */
