@@ -539,6 +539,7 @@ def run_vocoder(a, world, rank, dev):
     torch.manual_seed(0)
     model = HiFiGANGenerator(cfg, precision=a.precision).to(dev).eval()
     model.remove_weight_norm()
+    model.branch_streams = os.environ.get("EFTS_VOC_BRANCH", "1") == "1"       # (A/B: the residual blocks of a stage side by side / one after the other)
     mel = (torch.randn(NB, 80, T2, generator=torch.Generator().manual_seed(1234 + rank)) * 1.5 - 4.0).to(dev)
     for _ in range(max(a.warmup, 1)):
         y = model(mel)
