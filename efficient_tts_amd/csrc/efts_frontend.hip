@@ -165,18 +165,20 @@ __global__ __launch_bounds__(64) void logmel_dit_kernel(const float* __restrict_
 // The same with the twiddles in REGISTERS and the spectrum row staged through LDS: lane l owns the bins f = l + 64 i (i < NB), loads its
 // (R - 1) * NB twiddles once and then works through LM_ROWS rows (the table version above re-read 16 KiB of twiddles per row from L2: 226 us per
 // 64 x 800 frames against 150 for the dense spectrum's kernel).  N = 1024 only (NB = 9 bins per lane).
-constexpr int LM_ROWS = 16, LM_NB = 9, LM_CB = 2048;
+constexpr int LM_WAVES = 4, LM_RPW = 4, LM_ROWS = LM_WAVES * LM_RPW, LM_NB = 9, LM_CB = 2048;
 template <int R>
-__global__ __launch_bounds__(64) void logmel_dit_fast_kernel(const float* __restrict__ spec, long ld_spec, const float* __restrict__ basis,
-                                                             const int* __restrict__ ranges, const int* __restrict__ frames,
-                                                             const float2* __restrict__ twiddle, float* __restrict__ out, int T, int Tp,
-                                                             int rows_total, int n_mels) {
+__global__ __launch_bounds__(64 * LM_WAVES) void logmel_dit_fast_kernel(const float* __restrict__ spec, long ld_spec, const float* __restrict__ basis,
+                                                                        const int* __restrict__ ranges, const int* __restrict__ frames,
+                                                                        const float2* __restrict__ twiddle, float* __restrict__ out, int T, int Tp,
+                                                                        int rows_total, int n_mels) {
     constexpr int N = 1024, NBINS = 513, M = N / R, HALF = M / 2;
-    __shared__ __attribute__((aligned(16))) float y[N];
-    __shared__ float mag[NBINS + 3];
+    __shared__ __attribute__((aligned(16))) float ys[LM_WAVES][N];
+    __shared__ float mags[LM_WAVES][NBINS + 3];
     __shared__ float cb[LM_CB];              // the filterbank's non-zero spans, filter after filter (every bin lies in at most two triangles: ~1 030 weights)
     __shared__ int offs[129];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* y = ys[wave];
+    float* mag = mags[wave];
     float2 tw[R - 1][LM_NB];
 #pragma unroll
     for (int p = 1; p < R; ++p)
@@ -185,8 +187,8 @@ __global__ __launch_bounds__(64) void logmel_dit_fast_kernel(const float* __rest
             const int f = lane + 64 * i;
             tw[p - 1][i] = f < NBINS ? twiddle[p * NBINS + f] : make_float2(0.f, 0.f);
         }
-    // this lane's filters: m = lane and m = lane + 64; their weights go to LDS once per block (the mel sums were a chain of up to 40 dependent
-    // L2 reads per lane and row: the longest part of the kernel)
+    // this lane's filters: m = lane and m = lane + 64; the weights go to LDS once per block (the mel sums were a chain of up to 40 dependent
+    // L2 reads per lane and row: the longest part of the first version of this kernel)
     int flo[2], fhi[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -194,73 +196,95 @@ __global__ __launch_bounds__(64) void logmel_dit_fast_kernel(const float* __rest
         flo[h] = m < n_mels ? ranges[2 * m] : 0;
         fhi[h] = m < n_mels ? ranges[2 * m + 1] : 0;
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         int acc = 0;
         for (int m = 0; m < n_mels; ++m) { offs[m] = acc; acc += ranges[2 * m + 1] - ranges[2 * m]; }
         offs[n_mels] = acc;
     }
     __syncthreads();
     const bool in_lds = offs[n_mels] <= LM_CB;
-    if (in_lds) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int m = lane + 64 * h;
-            if (m < n_mels) {
-                const float* w = basis + (long)m * NBINS;
-                for (int k = flo[h]; k < fhi[h]; ++k) cb[offs[m] + k - flo[h]] = w[k];
-            }
-        }
+    if (in_lds && (int)threadIdx.x < n_mels) {
+        const int m = threadIdx.x, lo = ranges[2 * m], hi = ranges[2 * m + 1];
+        const float* w = basis + (long)m * NBINS;
+        for (int k = lo; k < hi; ++k) cb[offs[m] + k - lo] = w[k];
     }
-    for (int rr = 0; rr < LM_ROWS; ++rr) {
-        const int row = blockIdx.x * LM_ROWS + rr;
-        if (row >= rows_total) return;
+    // the rows of this wave: blockIdx.x * LM_ROWS + rr * LM_WAVES + wave; every wave passes every barrier (row-dependent work is predicated),
+    // the next row's spectrum is requested into registers before the current one is worked on
+    auto state = [&](int rr, int& row, bool& live, float*& o) {
+        row = blockIdx.x * LM_ROWS + rr * LM_WAVES + wave;
+        live = false; o = nullptr;
+        if (rr >= LM_RPW || row >= rows_total) return;
         const int b = row / Tp, t = row - b * Tp;
-        if (t >= T) continue;
-        float* o = out + ((long)b * T + t) * n_mels;
-        if (t >= frames[b]) {
-            for (int m = lane; m < n_mels; m += 64) o[m] = 0.f;
-            continue;
-        }
+        if (t >= T) return;
+        o = out + ((long)b * T + t) * n_mels;
+        live = t < frames[b];
+    };
+    float4 nx[N / 256];
+    int row; bool live; float* o;
+    state(0, row, live, o);
+    if (live) {
         const float4* src = (const float4*)(spec + (long)row * ld_spec);
-        __syncthreads();                                         // (the previous row's readers are done with y / mag)
 #pragma unroll
-        for (int i = 0; i < N / 256; ++i) ((float4*)y)[lane + 64 * i] = src[lane + 64 * i];
+        for (int i = 0; i < N / 256; ++i) nx[i] = src[lane + 64 * i];
+    }
+    for (int rr = 0; rr < LM_RPW; ++rr) {
+        __syncthreads();                                         // (the previous row's readers are done with y / mag; first pass: cb is written)
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < N / 256; ++i) ((float4*)y)[lane + 64 * i] = nx[i];
+        }
+        int row1; bool live1; float* o1;
+        state(rr + 1, row1, live1, o1);
+        if (live1) {
+            const float4* src = (const float4*)(spec + (long)row1 * ld_spec);
+#pragma unroll
+            for (int i = 0; i < N / 256; ++i) nx[i] = src[lane + 64 * i];
+        }
         __syncthreads();
+        if (live) {
 #pragma unroll
-        for (int i = 0; i < LM_NB; ++i) {
-            const int f = lane + 64 * i;
-            if (f < NBINS) {
-                int g = f & (M - 1);
-                float sgn = 1.f;
-                if (g > HALF) { g = M - g; sgn = -1.f; }
-                const bool real_only = g == 0 || g == HALF;
-                float xr = y[g], xi = real_only ? 0.f : sgn * y[HALF + g];          // p = 0: W^0 = 1
+            for (int i = 0; i < LM_NB; ++i) {
+                const int f = lane + 64 * i;
+                if (f < NBINS) {
+                    int g = f & (M - 1);
+                    float sgn = 1.f;
+                    if (g > HALF) { g = M - g; sgn = -1.f; }
+                    const bool real_only = g == 0 || g == HALF;
+                    float xr = y[g], xi = real_only ? 0.f : sgn * y[HALF + g];          // p = 0: W^0 = 1
 #pragma unroll
-                for (int p = 1; p < R; ++p) {
-                    const float yr = y[p * M + g], yi = real_only ? 0.f : sgn * y[p * M + HALF + g];
-                    const float2 w = tw[p - 1][i];
-                    xr += w.x * yr + w.y * yi;
-                    xi += w.x * yi - w.y * yr;
+                    for (int p = 1; p < R; ++p) {
+                        const float yr = y[p * M + g], yi = real_only ? 0.f : sgn * y[p * M + HALF + g];
+                        const float2 w = tw[p - 1][i];
+                        xr += w.x * yr + w.y * yi;
+                        xi += w.x * yi - w.y * yr;
+                    }
+                    mag[f] = sqrtf(xr * xr + xi * xi + 1e-9f);                            // meldataset.py:75
                 }
-                mag[f] = sqrtf(xr * xr + xi * xi + 1e-9f);
             }
         }
         __syncthreads();
+        if (o != nullptr) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int m = lane + 64 * h;
-            if (m < n_mels) {
-                float acc = 0.f;
-                if (in_lds) {
-                    const float* w = cb + offs[m] - flo[h];
-                    for (int k = flo[h]; k < fhi[h]; ++k) acc += w[k] * mag[k];
-                } else {
-                    const float* w = basis + (long)m * NBINS;
-                    for (int k = flo[h]; k < fhi[h]; ++k) acc += w[k] * mag[k];
+            for (int h = 0; h < 2; ++h) {
+                const int m = lane + 64 * h;
+                if (m < n_mels) {
+                    float acc = 0.f;
+                    if (!live) {
+                        o[m] = 0.f;                                                     // zero padding AFTER the log (taco2_data.py:122-134)
+                        continue;
+                    }
+                    if (in_lds) {
+                        const float* w = cb + offs[m] - flo[h];
+                        for (int k = flo[h]; k < fhi[h]; ++k) acc += w[k] * mag[k];
+                    } else {
+                        const float* w = basis + (long)m * NBINS;
+                        for (int k = flo[h]; k < fhi[h]; ++k) acc += w[k] * mag[k];
+                    }
+                    o[m] = logf(fmaxf(acc, 1e-5f));                                     // meldataset.py:27-28,78
                 }
-                o[m] = logf(fmaxf(acc, 1e-5f));
             }
         }
+        row = row1; live = live1; o = o1;
     }
 }
 
@@ -323,7 +347,7 @@ extern "C" int efts_logmel_dit(const float* spec, int64_t ld_spec, const float* 
     if (n_fft == 1024 && n_mels <= 128 && (ld_spec & 3) == 0 && ((uintptr_t)spec & 15) == 0 && (radix == 2 || radix == 4 || radix == 8)) {
         const int rows = B * Tp;
         const dim3 grid((rows + LM_ROWS - 1) / LM_ROWS);
-#define EFTS_LMF(R) hipLaunchKernelGGL(logmel_dit_fast_kernel<R>, grid, dim3(64), 0, (hipStream_t)stream, spec, (long)ld_spec, basis, ranges, frames, \
+#define EFTS_LMF(R) hipLaunchKernelGGL(logmel_dit_fast_kernel<R>, grid, dim3(64 * LM_WAVES), 0, (hipStream_t)stream, spec, (long)ld_spec, basis, ranges, frames, \
                                        (const float2*)twiddle, out, T, Tp, rows, n_mels)
         if (radix == 2) EFTS_LMF(2); else if (radix == 4) EFTS_LMF(4); else EFTS_LMF(8);
 #undef EFTS_LMF
