@@ -459,7 +459,7 @@ def run_logmel64(a, world, rank, dev):
     g = torch.Generator().manual_seed(1234 + rank)
     audio = (torch.rand(B, T2 * 256, generator=g) * 2 - 1).mul_(0.3).to(dev)
     lengths = torch.full((B,), T2 * 256)
-    fe = LogMelFrontend(dev, radix=int(os.environ.get("EFTS_LOGMEL_RADIX", "4")))       # (EFTS_LOGMEL_RADIX: A/B of the DFT split, tools/r06_call7.sh)
+    fe = LogMelFrontend(dev, radix=int(os.environ.get("EFTS_LOGMEL_RADIX", "0")))       # (EFTS_LOGMEL_RADIX: A/B: 0 = the fused FFT launch (default), 1 = the dense MFMA product, 2 / 4 / 8 = the split product)
     for _ in range(max(a.warmup, 1)):
         mel, frames = fe(audio, lengths)
     torch.cuda.synchronize()
@@ -478,6 +478,23 @@ def run_logmel64(a, world, rank, dev):
     # roofline (round 6): the three launches of a call are timed with HIP events on the launch stream (frame pack / the batched DFT product / logmel);
     # the pipeline's algorithmic bytes -- audio in, operand plane written and read, spectrum written and read, mel out -- against HBM, the product's
     # FLOPs against the MFMA peak; `roofline` is the product's line (still the longest launch), `pipeline` the whole call's
+    if fe.radix == 0:
+        # ONE launch (efts_logmel_fft): HIP events around it on the launch stream; algorithmic bytes = audio in + log-mels out (the step is HBM-bound)
+        evs = []
+        for _ in range(20):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fe(audio, lengths); e1.record()           # (the library launches on torch's current stream: efficient_tts_amd/ops.py `_stream`)
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        call = sorted(e0.elapsed_time(e1) for e0, e1 in evs)[len(evs) // 2] * 1e-3
+        nbytes = B * T2 * 256 * 4 + B * T2 * 80 * 4
+        fft_flop = B * T2 / 2 * (5.0 * 1024 * 10)                  # one complex 1024-point FFT per frame pair, 5 N log2 N
+        roof = dict(bound="hbm", kernel="logmel_fft_kernel (audio -> log-mel in one launch: reflect pad, hann window, fp32 FFT in registers / LDS, two real frames per complex "
+                                        "1024-point FFT, magnitude, mel filterbank, log)",
+                    achieved=nbytes / call / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", frac=nbytes / call / 1e9 / PEAK_HBM_GBS, traffic=None,
+                    avg_launch_us=call * 1e6, launches_measured=len(evs), algorithmic_bytes_per_launch=nbytes,
+                    valu_fft_gflop=fft_flop / 1e9, valu_tflops=fft_flop / call / 1e12,
+                    note="events around the whole call (one kernel + the output allocation); the MFMA pipeline it replaces (EFTS_LOGMEL_RADIX=4) moves 910 MB per call")
     rows = B * (T2 + 2)
     P.PROFILE, P.PROFILE_TAG = [], None
     evs = []
@@ -492,25 +509,26 @@ def run_logmel64(a, world, rank, dev):
     call = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs) * 1e-3
     P.PROFILE, P.PROFILE_TAG = None, None
     avg = sum(durs) / max(len(durs), 1)
-    flop = 2.0 * B * T2 * (1024 * 1026 if fe.radix == 1 else fe.radix * fe.sub * fe.sub)
-    plane_bytes = rows * 1024 * 4                      # bf16x3 operand plane: hi + lo
-    spec_bytes = rows * fe.ld_spec * 4
-    gemm_bytes = plane_bytes + spec_bytes
-    pipe_bytes = B * T2 * 256 * 4 + 2 * plane_bytes + 2 * spec_bytes + B * T2 * 80 * 4
-    roof = dict(bound="mfma", kernel=(f"gemm_kernel<taps=1,split=2>: {fe.radix} real DFTs of {1024 // fe.radix} points per frame as one batched MFMA product (decimation in time, radix {fe.radix})"
-                                      if fe.radix > 1 else "gemm_kernel<taps=1,split=2> (real DFT 1024 -> 513 re + 513 im as an MFMA product)"),
-                achieved=flop / avg / 1e12, peak=PEAK_MFMA_BF16_TFLOPS, unit="TFLOP/s", frac=flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS,
-                traffic=None, avg_launch_us=avg * 1e6, launches_measured=len(durs), algorithmic_flop_per_launch=flop,
-                mfma_issue_frac=3 * flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS,
-                algorithmic_bytes_per_launch=gemm_bytes, hbm_frac_algorithmic=gemm_bytes / avg / 1e9 / PEAK_HBM_GBS,
-                dense_product_flop=2.0 * B * T2 * 1024 * 1026,
-                pipeline=dict(bound="hbm", call_us=call * 1e6, algorithmic_bytes=pipe_bytes, achieved_gbs=pipe_bytes / call / 1e9,
-                              frac=pipe_bytes / call / 1e9 / PEAK_HBM_GBS,
-                              note="frame pack + product + logmel of one call (events around the call); bytes: audio in, operand plane written + read, spectrum written + read, mel out"))
+    if fe.radix:
+      flop = 2.0 * B * T2 * (1024 * 1026 if fe.radix == 1 else fe.radix * fe.sub * fe.sub)
+      plane_bytes = rows * 1024 * 4                      # bf16x3 operand plane: hi + lo
+      spec_bytes = rows * fe.ld_spec * 4
+      gemm_bytes = plane_bytes + spec_bytes
+      pipe_bytes = B * T2 * 256 * 4 + 2 * plane_bytes + 2 * spec_bytes + B * T2 * 80 * 4
+      roof = dict(bound="mfma", kernel=(f"gemm_kernel<taps=1,split=2>: {fe.radix} real DFTs of {1024 // fe.radix} points per frame as one batched MFMA product (decimation in time, radix {fe.radix})"
+                                        if fe.radix > 1 else "gemm_kernel<taps=1,split=2> (real DFT 1024 -> 513 re + 513 im as an MFMA product)"),
+                  achieved=flop / avg / 1e12, peak=PEAK_MFMA_BF16_TFLOPS, unit="TFLOP/s", frac=flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS,
+                  traffic=None, avg_launch_us=avg * 1e6, launches_measured=len(durs), algorithmic_flop_per_launch=flop,
+                  mfma_issue_frac=3 * flop / avg / 1e12 / PEAK_MFMA_BF16_TFLOPS,
+                  algorithmic_bytes_per_launch=gemm_bytes, hbm_frac_algorithmic=gemm_bytes / avg / 1e9 / PEAK_HBM_GBS,
+                  dense_product_flop=2.0 * B * T2 * 1024 * 1026,
+                  pipeline=dict(bound="hbm", call_us=call * 1e6, algorithmic_bytes=pipe_bytes, achieved_gbs=pipe_bytes / call / 1e9,
+                                frac=pipe_bytes / call / 1e9 / PEAK_HBM_GBS,
+                                note="frame pack + product + logmel of one call (events around the call); bytes: audio in, operand plane written + read, spectrum written + read, mel out"))
     if rank == 0:
         res = dict(metric="mel-frames/sec (on-device log-mel front-end, 64 x 800 frames, n_fft 1024 / hop 256 / 80 mel)",
                    value=world * B * T2 / dt, unit="mel-frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt * 1e3,
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16x3 (split-bf16 MFMA, fp32-class)", data="synthetic",
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32 (FFT in registers / LDS)" if fe.radix == 0 else "bf16x3 (split-bf16 MFMA, fp32-class)", data="synthetic",
                    config={"workload": "log-mel front-end B=64 x 204800 samples -> 800 frames x 80 mel", "batch_per_gpu": B, "mel_len": T2,
                            "parallelism": f"replicas x{world}"}, roofline=roof)
         if world == 1 and not a.no_cpu_baseline:

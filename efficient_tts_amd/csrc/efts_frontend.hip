@@ -288,6 +288,267 @@ __global__ __launch_bounds__(64 * LM_WAVES) void logmel_dit_fast_kernel(const fl
     }
 }
 
+
+// ----------------------------------------------------------------------------------------------------------------------------
+// The whole front-end as ONE launch for n_fft = 1024: audio -> log-mel, the STFT as a register / LDS FFT (no operand plane, no
+// spectrum in memory: 52 MB of audio in, 16 MB of log-mels out per 64 x 800 frames, where the MFMA pipeline above moves 910 MB).
+// One wave per PAIR of neighbouring frames: z = frame_a + i frame_b goes through one complex 1024-point FFT and the two real
+// spectra come apart by conjugate symmetry, X_a[f] = (Z[f] + conj Z[N - f]) / 2, X_b[f] = (Z[f] - conj Z[N - f]) / 2i.
+// The FFT is 1024 = 16 x (16 x 4), 16 complex values per lane:
+//   n = 64 n1 + n2, k = k1 + 16 k2:  X[k] = sum_n2 W1024^(n2 k1) W64^(n2 k2) [sum_n1 z[64 n1 + n2] W16^(n1 k1)]
+//   (1) lane n2 reads its 16 samples of both frames straight from the audio (for a fixed n1 the 64 lanes read 64 consecutive
+//       samples; frame b is frame a moved by one hop = 4 values of n1, so 20 loads serve both), a 16-point DFT in registers,
+//       the twiddles W1024^(n2 k1) (per-lane constants, computed once per wave);
+//   (2) ONE transpose through LDS (rows of 65 complex: the column reads of step 3 then spread over all banks);
+//   (3) lane (k1, q) holds n2 = 4 r + q: 16-point DFT over r, twiddles W64^(q s), and the last radix-4 across the four lanes of
+//       a quad with DPP moves -- lane (k1, q) ends up with X[k1 + 16 s + 256 u(q)], s = 0 .. 15;
+//   (4) Z in natural order through the same LDS region, magnitudes of both frames, the mel filterbank (its non-zero spans in LDS,
+//       filter m and m + 64 per lane), log, store.
+// fp32 throughout (the MFMA pipeline carried 16 mantissa bits).  meldataset.py:49-82, taco2_data.py:66-76, :122-139.
+// ----------------------------------------------------------------------------------------------------------------------------
+namespace fft {
+
+struct cf { float x, y; };
+__device__ __forceinline__ cf operator+(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cf operator-(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cf mul_mi(cf a) { return {a.y, -a.x}; }                 // a * (-i)
+
+// forward 4-point DFT in place (W4 = -i)
+__device__ __forceinline__ void dft4(cf& a, cf& b, cf& c, cf& d) {
+    const cf t0 = a + c, t1 = a - c, t2 = b + d, t3 = mul_mi(b - d);
+    a = t0 + t2; b = t1 + t3; c = t0 - t2; d = t1 - t3;
+}
+
+// forward 16-point DFT in place, natural order in and out: n = 4 a + b, k = c + 4 d
+__device__ __forceinline__ void dft16(cf* v) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);          // over a: v[4 c + b] = y_b[c]
+    // y_b[c] *= W16^(b c)
+    v[4 + 1] = cmul(v[4 + 1], {C1, -S1});  v[4 + 2] = cmul(v[4 + 2], {H, -H});     v[4 + 3] = cmul(v[4 + 3], {S1, -C1});
+    v[8 + 1] = cmul(v[8 + 1], {H, -H});    v[8 + 2] = mul_mi(v[8 + 2]);            v[8 + 3] = cmul(v[8 + 3], {-H, -H});
+    v[12 + 1] = cmul(v[12 + 1], {S1, -C1}); v[12 + 2] = cmul(v[12 + 2], {-H, -H}); v[12 + 3] = cmul(v[12 + 3], {-C1, S1});
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dft4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);   // over b: v[4 c + d] = X[c + 4 d]
+    // to natural order: X[k] sits at v[4 (k & 3) + (k >> 2)] -- a 4 x 4 transpose of the register names
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = c + 1; d < 4; ++d) { const cf t = v[4 * c + d]; v[4 * c + d] = v[4 * d + c]; v[4 * d + c] = t; }
+}
+
+template <int CTRL>
+__device__ __forceinline__ cf quad(cf a) {       // the value of the quad's lane selected by the DPP quad_perm control
+    cf r;
+    r.x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a.x), CTRL, 0xf, 0xf, false));
+    r.y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a.y), CTRL, 0xf, 0xf, false));
+    return r;
+}
+
+}  // namespace fft
+
+#ifndef FF_ABL
+#define FF_ABL 0
+#endif
+constexpr int FF_WAVES = 4, FF_PITCH = 65, FF_CB = 2560, FF_WIDE = 64;      // filters FF_WIDE .. run on four lanes each (they are the widest)
+__global__ __launch_bounds__(64 * FF_WAVES, 3) void logmel_fft_kernel(const float* __restrict__ audio, long ld_audio, const int* __restrict__ lengths,
+                                                                      const float* __restrict__ window, const float* __restrict__ basis,
+                                                                      const int* __restrict__ ranges, float* __restrict__ out, int B, int T,
+                                                                      int n_mels) {
+    using namespace fft;
+    constexpr int N = 1024, HOP = 256, NBINS = 513, PAD = (N - HOP) / 2;
+    __shared__ __attribute__((aligned(16))) cf zs[FF_WAVES][16 * FF_PITCH];   // transpose buffer, then Z in natural order, then (|X_a|, |X_b|) per bin in place
+    __shared__ __attribute__((aligned(16))) float cb[FF_CB];                  // the filterbank's non-zero spans, every span padded with zeros to whole 4-tap steps
+    __shared__ cf tw1s[15][64];                             // W1024^(n2 k), k = 1 .. 15
+    __shared__ cf tw2s[4][16];                              // W64^(q s)
+    __shared__ int nst[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    cf* zw = zs[wave];
+    // ---- per block (a block works through many frame pairs): twiddle tables, filterbank
+    for (int i = threadIdx.x; i < 15 * 64; i += 64 * FF_WAVES) {
+        const int k = i / 64 + 1, n2 = i & 63;
+        float sn, cs;
+        if (FF_ABL & 64) { sn = 0.f; cs = 1.f; } else sincospif(-(float)((n2 * k) & 1023) / 512.f, &sn, &cs);
+        tw1s[k - 1][n2] = {cs, sn};
+    }
+    if (threadIdx.x < 64) {
+        const int qq = threadIdx.x >> 4, ss = threadIdx.x & 15;
+        float sn, cs;
+        sincospif(-(float)((qq * ss) & 63) / 32.f, &sn, &cs);
+        tw2s[qq][ss] = {cs, sn};
+    }
+    // span of a filter in cb: filters below FF_WIDE run on one lane, the others on four (a quarter each); all spans of a kind have the length of
+    // the widest one (w0 / w1 4-tap steps, per lane), shorter ones are padded with zero weights -- so offsets are closed-form and a lane may run
+    // its own number of steps or the common one
+    if (threadIdx.x < 2) nst[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < FF_CB; i += 64 * FF_WAVES) cb[i] = 0.f;
+    __syncthreads();
+    if ((int)threadIdx.x < n_mels) {
+        const int m = threadIdx.x, n = ranges[2 * m + 1] - ranges[2 * m];
+        atomicMax(&nst[m < FF_WIDE ? 0 : 1], m < FF_WIDE ? (n + 3) >> 2 : (n + 15) >> 4);
+    }
+    __syncthreads();
+    const int w0 = nst[0], w1 = nst[1];
+    auto off_of = [&](int m) { return m < FF_WIDE ? 4 * w0 * m : 4 * w0 * min(n_mels, FF_WIDE) + 16 * w1 * (m - FF_WIDE); };
+    // (the padding steps of a span read zw behind the filter's last bin: they must stay inside the wave's 16 x 65 buffer)
+    const bool in_lds = off_of(n_mels) <= FF_CB && NBINS + 4 * w0 <= 16 * FF_PITCH && NBINS + 16 * w1 <= 16 * FF_PITCH;
+    if (in_lds) {
+        for (int m = wave; m < n_mels; m += FF_WAVES) {
+            const int lo = ranges[2 * m], hi = ranges[2 * m + 1];
+            for (int k = lo + lane; k < hi; k += 64) cb[off_of(m) + k - lo] = basis[(long)m * NBINS + k];
+        }
+    }
+    __syncthreads();
+    // this lane's filters: m0 = lane (all of it) and a quarter of filter m1 = FF_WIDE + lane / 4
+    const int k1 = lane >> 2, q = lane & 3;
+    const int m0 = lane, m1 = FF_WIDE + k1;
+    // (per-lane step counts: a lane stops behind its own filter's last bin -- measured faster than the common count with two steps in flight)
+    int lo0 = 0, lo1 = 0, o0 = 0, o1 = 0, ns0 = 0, ns1 = 0;
+    if (in_lds && m0 < n_mels && m0 < FF_WIDE) { lo0 = ranges[2 * m0]; o0 = off_of(m0); ns0 = (ranges[2 * m0 + 1] - lo0 + 3) >> 2; }
+    if (in_lds && m1 < n_mels) {
+        const int lo = ranges[2 * m1], hi = ranges[2 * m1 + 1];
+        lo1 = lo + 4 * w1 * q; o1 = off_of(m1) + 4 * w1 * q;
+        ns1 = max(0, min(w1, (hi - lo1 + 3) >> 2));
+    }
+    const float s1 = (q & 2) ? -1.f : 1.f, s2 = (q & 1) ? -1.f : 1.f;     // signs of the quad radix-4: r = partner + s * own
+    float win[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) win[n1] = window[64 * n1 + lane];
+    const int PT = (T + 1) >> 1;                                      // frame pairs per item
+    const int npairs = B * PT;
+    const int stride = gridDim.x * FF_WAVES;
+    for (int pair = blockIdx.x * FF_WAVES + wave; pair < ((FF_ABL & 32) ? 0 : npairs); pair += stride) {
+        const int b = pair / PT, t0 = 2 * (pair - b * PT);
+        const int L = lengths[b], nfr = L / HOP;
+        const bool va = t0 < nfr, vb = t0 + 1 < nfr && t0 + 1 < T;
+        float* oa = out + ((long)b * T + t0) * n_mels;
+        float* ob = oa + n_mels;
+        if (!va) {                                                   // zero padding AFTER the log (taco2_data.py:122-134); frame b is past the length too
+            for (int m = lane; m < n_mels; m += 64) { oa[m] = 0.f; if (t0 + 1 < T) ob[m] = 0.f; }
+            continue;
+        }
+        // (1) the samples of both frames: s[j] = audio[reflect(t0 * hop + 64 j + lane - pad)], j = 0 .. 19 (frame b = frame a moved by 4 j).
+        // Every load is issued, from a clamped address (a predicated load per sample compiled into twenty branches)
+        const float* a = audio + (long)b * ld_audio;
+        float sm[20];
+        const int s0 = t0 * HOP - PAD;                               // first sample of frame a in the un-padded signal
+        if (s0 >= 0 && s0 + 20 * 64 <= L) {                          // (wave-uniform) every sample of the pair lies inside the item: one base, constant offsets
+            const float* ab = a + s0 + lane;
+#pragma unroll
+            for (int j = 0; j < 20; ++j) sm[j] = (FF_ABL & 16) ? (float)j : ab[64 * j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 20; ++j) {
+                int s = s0 + 64 * j + lane;
+                s = s < 0 ? -s : s;                                  // reflect without edge repeat (meldataset.py:69)
+                s = s >= L ? 2 * (L - 1) - s : s;
+                s = min(max(s, 0), L - 1);                           // (out of range only for frame b past the item's length: dropped below)
+                sm[j] = (FF_ABL & 16) ? (float)s : a[s];
+            }
+        }
+        cf v[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = {sm[n1] * win[n1], vb ? sm[n1 + 4] * win[n1] : 0.f};
+#if !(FF_ABL & 2)
+        dft16(v);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tw1s[k - 1][lane]);
+#endif
+        // (2) transpose: row k1, column n2
+#pragma unroll
+        for (int k = 0; k < 16; ++k) zw[k * FF_PITCH + lane] = v[k];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // (3) lane (k1, q): n2 = 4 r + q
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = zw[k1 * FF_PITCH + 4 * r + q];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !(FF_ABL & 2)
+        dft16(v);
+#pragma unroll
+        for (int s = 1; s < 16; ++s) v[s] = cmul(v[s], tw2s[q][s]);
+#endif
+        // radix 4 across the quad: lanes hold x0 .. x3 (q = 0 .. 3); afterwards lane q holds X_u, u = bit-reversed q
+#if !(FF_ABL & 4)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            cf c = v[s];
+            const cf p = quad<0x4E>(c);                             // quad_perm [2, 3, 0, 1]
+            c = {c.x * s1 + p.x, c.y * s1 + p.y};                    // q0: x0 + x2, q1: x1 + x3, q2: x0 - x2, q3: x1 - x3
+            if (q == 3) c = mul_mi(c);
+            const cf p2 = quad<0xB1>(c);                            // quad_perm [1, 0, 3, 2]
+            v[s] = {c.x * s2 + p2.x, c.y * s2 + p2.y};               // q0: X0, q1: X2, q2: X1, q3: X3
+        }
+#endif
+        const int u = ((q & 1) << 1) | (q >> 1);
+        // (4) Z in natural order: f = k1 + 16 s + 256 u
+#pragma unroll
+        for (int s = 0; s < 16; ++s) zw[k1 + 16 * s + 256 * u] = v[s];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // magnitudes of both frames, IN PLACE: bin f of this lane reads Z[f] and Z[N - f] -- no other lane reads either -- and leaves
+        // (|X_a[f]|, |X_b[f]|) at zw[f]
+#pragma unroll
+        for (int i = 0; i < ((FF_ABL & 8) ? 2 : 9); ++i) {
+            const int f = lane + 64 * i;
+            if (f < NBINS) {
+                const cf zf = zw[f], zn = zw[(N - f) & (N - 1)];
+                const float ar = 0.5f * (zf.x + zn.x), ai = 0.5f * (zf.y - zn.y);
+                const float br = 0.5f * (zf.y + zn.y), bi = -0.5f * (zf.x - zn.x);
+                zw[f] = {__builtin_amdgcn_sqrtf(ar * ar + ai * ai + 1e-9f),       // meldataset.py:75 (v_sqrt_f32: 1 ulp)
+                         __builtin_amdgcn_sqrtf(br * br + bi * bi + 1e-9f)};
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the mel sums, four taps per step: one 16-byte read of weights, four 8-byte reads of magnitude pairs.  Steps past a filter's last
+        // bin meet zero weights (cb is padded) and whatever finite value lies behind bin 512 in zw.
+        auto span = [&](int off, int lo, int nsteps, float& ra, float& rb) {
+            float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+            for (int st = 0; st < nsteps; ++st) {
+                const float4 w = *(const float4*)(cb + off + 4 * st);
+                const cf x0 = zw[lo + 4 * st], x1 = zw[lo + 4 * st + 1], x2 = zw[lo + 4 * st + 2], x3 = zw[lo + 4 * st + 3];
+                a0 += w.x * x0.x; b0 += w.x * x0.y; a1 += w.y * x1.x; b1 += w.y * x1.y;
+                a0 += w.z * x2.x; b0 += w.z * x2.y; a1 += w.w * x3.x; b1 += w.w * x3.y;
+            }
+            ra = a0 + a1; rb = b0 + b1;
+        };
+        // (a filterbank that does not fit cb: the plain loops over the global basis)
+        auto span_global = [&](int m, int lo, int hi, float& ra, float& rb) {
+            float a0 = 0.f, b0 = 0.f;
+            const float* w = basis + (long)m * NBINS;
+            for (int k = lo; k < hi; ++k) { const cf x = zw[k]; a0 += w[k] * x.x; b0 += w[k] * x.y; }
+            ra = a0; rb = b0;
+        };
+        float sa0, sb0, sa1, sb1;
+#if FF_ABL & 1
+        sa0 = zw[lane].x; sb0 = zw[lane].y; sa1 = zw[lane + 64].x; sb1 = zw[lane + 64].y;
+#else
+        if (in_lds) {
+            span(o0, lo0, ns0, sa0, sb0);
+            span(o1, lo1, ns1, sa1, sb1);
+        } else {
+            sa0 = sb0 = sa1 = sb1 = 0.f;
+            if (m0 < n_mels && m0 < FF_WIDE) span_global(m0, ranges[2 * m0], ranges[2 * m0 + 1], sa0, sb0);
+            if (m1 < n_mels && q == 0) span_global(m1, ranges[2 * m1], ranges[2 * m1 + 1], sa1, sb1);
+        }
+#endif
+        // the four quarters of a wide filter
+        sa1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sa1), 0x4E, 0xf, 0xf, false));
+        sb1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sb1), 0x4E, 0xf, 0xf, false));
+        sa1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sa1), 0xB1, 0xf, 0xf, false));
+        sb1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sb1), 0xB1, 0xf, 0xf, false));
+        constexpr float LN2 = 0.69314718055994531f;
+        if (m0 < n_mels && m0 < FF_WIDE) {
+            oa[m0] = __builtin_amdgcn_logf(fmaxf(sa0, 1e-5f)) * LN2;              // meldataset.py:27-28, :78 (v_log_f32: log2, 1 ulp)
+            if (t0 + 1 < T) ob[m0] = vb ? __builtin_amdgcn_logf(fmaxf(sb0, 1e-5f)) * LN2 : 0.f;
+        }
+        if (m1 < n_mels && q == 0) {
+            oa[m1] = __builtin_amdgcn_logf(fmaxf(sa1, 1e-5f)) * LN2;
+            if (t0 + 1 < T) ob[m1] = vb ? __builtin_amdgcn_logf(fmaxf(sb1, 1e-5f)) * LN2 : 0.f;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the next pair's transpose overwrites zw
+    }
+}
+
 }  // namespace efts
 
 using namespace efts;
@@ -356,4 +617,19 @@ extern "C" int efts_logmel_dit(const float* spec, int64_t ld_spec, const float* 
     hipLaunchKernelGGL(logmel_dit_kernel, dim3(B * Tp), dim3(64), n_bins * sizeof(float), (hipStream_t)stream, spec, (long)ld_spec, basis,
                        ranges, frames, (const float2*)twiddle, out, T, Tp, n_bins, n_mels, radix);
     return efts_check_launch("efts_logmel_dit");
+}
+
+extern "C" int efts_logmel_fft(const float* audio, int64_t ld_audio, const int32_t* lengths, const float* window, const float* basis,
+                               const int32_t* ranges, float* out, int32_t B, int32_t T, int32_t n_fft, int32_t hop, int32_t n_mels, void* stream) {
+    if (!audio || !lengths || !window || !basis || !ranges || !out) return efts_fail(EFTS_EINVAL, "efts_logmel_fft: null pointer");
+    if (B <= 0 || T <= 0) return efts_fail(EFTS_ESHAPE, "efts_logmel_fft: bad B / T");
+    if (n_fft != 1024 || hop != 256 || n_mels <= 0 || n_mels > 128)
+        return efts_fail(EFTS_ESHAPE, "efts_logmel_fft: the fused kernel is built for n_fft 1024, hop 256, at most 128 mel bins (other configurations: efts_frame_pack_dit + efts_gemm + efts_logmel_dit)");
+    const long pairs = (long)B * ((T + 1) / 2);
+    long blocks = (pairs + FF_WAVES - 1) / FF_WAVES;
+    const long cap = 3L * efts_num_cus();                     // persistent: three workgroups per CU (LDS, registers), each wave works through pairs / (12 CUs) frame pairs
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(logmel_fft_kernel, dim3((unsigned)blocks), dim3(64 * FF_WAVES), 0, (hipStream_t)stream, audio, (long)ld_audio, lengths, window,
+                       basis, ranges, out, B, T, n_mels);
+    return efts_check_launch("efts_logmel_fft");
 }

@@ -319,6 +319,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
             if ((tid & 31) == 0 && rl < BM && row < p.m) so[row] = row < ql ? si / se : 0.f;
         }
     }
+    float part_sq = 0.f;
     if (pre) {
         const __amdgpu_buffer_rsrc_t ro = make_rsrc(of ? of + (long)m0 * p.ldo : nullptr, of ? (long)rows_out * p.ldo * 4 : 0);
         const __amdgpu_buffer_rsrc_t rb = make_rsrc(ob ? ob + (long)m0 * p.ldob : nullptr, ob ? (long)rows_out * p.ldob : 0);
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
         const unsigned vo = trow * (unsigned)p.ldo * 4 + col * 4, so = RPP * (unsigned)p.ldo * 4;
         const unsigned vb = trow * (unsigned)p.ldob + (unsigned)plane_off_hi(col, p.out_split), sb = RPP * (unsigned)p.ldob;
         const bool has_mask = rowmask != nullptr;
+        float sq = 0.f;                                      // p.sqerr: this thread's share of sum (out - target)^2, sweeps in ascending order
         const unsigned ld_sg = (unsigned)(p.n >> 3);
         const __amdgpu_buffer_rsrc_t rsg = make_rsrc(p.sign ? p.sign + (long)m0 * ld_sg : nullptr, p.sign ? (long)rows_out * ld_sg : 0);
 #pragma unroll
@@ -347,8 +349,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
             }
             const u32x4 x = rres[ps];
             const float rm = has_mask ? rmv[ps] : 1.f;
-            v.x = (v.x + __uint_as_float(x.x)) * rm; v.y = (v.y + __uint_as_float(x.y)) * rm;
-            v.z = (v.z + __uint_as_float(x.z)) * rm; v.w = (v.w + __uint_as_float(x.w)) * rm;
+            if (p.sqerr) {                                   // `resid` carries the loss target, not a residual (rows past the matrix: rm = 0)
+                v.x *= rm; v.y *= rm; v.z *= rm; v.w *= rm;
+                if (rm != 0.f) {
+                    const float d0 = v.x - __uint_as_float(x.x), d1 = v.y - __uint_as_float(x.y), d2 = v.z - __uint_as_float(x.z), d3 = v.w - __uint_as_float(x.w);
+                    sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+            } else {
+                v.x = (v.x + __uint_as_float(x.x)) * rm; v.y = (v.y + __uint_as_float(x.y)) * rm;
+                v.z = (v.z + __uint_as_float(x.z)) * rm; v.w = (v.w + __uint_as_float(x.w)) * rm;
+            }
             if (of) {
                 const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
                 { __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo, ps * so, EFTS_AUX_STF); asm volatile("s_nop 4" ::"v"(o)); }
@@ -372,6 +382,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
                 }
             }
         }
+        if (p.sqerr) part_sq = sq;
     } else if (col < p.n && !(dbg & 1)) {
 #pragma unroll 4
         for (int ps = 0; ps < NPS; ++ps) {
@@ -412,6 +423,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmKernelArgs p) {
                 }
             }
         }
+    }
+    if (p.sqerr) {   // every wave adds its 64 shares up the same way (xor butterfly) and owns one slot: no atomics, no run-to-run difference
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part_sq += __shfl_xor(part_sq, off, 64);
+        if (lane == 0) p.sqerr[((long)z * ntot + bid) * 4 + wave] = part_sq;
     }
     lds_barrier();   // the LDS tile is re-used by the next tile's operand ring; stores drain on their own
     if constexpr (DBG == 2) {
@@ -486,6 +502,7 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
     k.bias = a->bias; k.resid = a->resid; k.rowmask = a->rowmask;
     k.out_f32 = a->out_f32; k.out_bf16 = (char*)a->out_bf16; k.out_lo = (char*)a->out_bf16_lo; k.sign = (char*)a->sign_mask;
     k.sidx = a->soft_index; k.klen = a->key_len; k.qlen = a->query_len;
+    k.sqerr = a->sqerr_part;
     k.drop_thresh = 0; k.drop_seed_h = 0; k.drop_inv_keep = 1.f;
     if (a->drop_p > 0.f) {
         if (!(a->drop_p < 1.f)) return efts_fail(EFTS_EINVAL, "efts_gemm: drop_p must be in [0, 1)");
@@ -517,6 +534,13 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
         return efts_fail(EFTS_EINVAL, "efts_gemm: dropout needs batch 1, 16-byte aligned fp32 / plane rows, n % 4 == 0 and m * n < 2^32");
     if (a->sign_mask && (a->n % 128 || a->batch > 1 || nb2 > 1 || !k.vec_ok || ((uintptr_t)a->sign_mask & 15)))
         return efts_fail(EFTS_EINVAL, "efts_gemm: sign_mask needs n %% 128 == 0, batch 1, 16-byte aligned output rows and mask");
+    if (a->sqerr_part) {
+        if (!a->sqerr_target || !a->rowmask || a->resid || a->taps != 1 || a->n > BN || (a->n & 3) || nb2 > 1 || k.drop_thresh || a->out_bf16 || a->soft_index ||
+            (a->ld_target & 3) || (a->target_batch_stride & 3) || ((uintptr_t)a->sqerr_target & 15) || !k.vec_ok)
+            return efts_fail(EFTS_EINVAL, "efts_gemm: sqerr_part needs sqerr_target (16-byte aligned rows), rowmask, one tap, n <= 128, n %% 4 == 0, fp32 output only, no residual / dropout / batch2");
+        if (a->tiling > EFTS_TILING_GENERIC) return efts_fail(EFTS_EINVAL, "efts_gemm: sqerr_part needs the generic tiling");
+        k.resid = a->sqerr_target; k.ldr = a->ld_target; k.r_bs = a->target_batch_stride;      // the target travels where the residual would
+    }
     hipStream_t st = (hipStream_t)stream;
 
     // ---- which kernel.  `tiling` AUTO (0) applies the measured rules below; the explicit values exist for A/B runs and
@@ -533,7 +557,7 @@ extern "C" int efts_gemm(const efts_gemm_args* a, void* stream) {
         if (launch_smallm_any(a->split, a->taps, st, k)) return efts_check_launch("efts_gemm");
         return efts_fail(EFTS_ESHAPE, "efts_gemm: no small-M instantiation for taps %d", a->taps);
     }
-    const bool generic_only = a->out_bf16_lo != nullptr || nb2 > 1 || a->soft_index != nullptr;      // the remainder plane / the outer batch / the soft index: gemm_kernel only
+    const bool generic_only = a->out_bf16_lo != nullptr || nb2 > 1 || a->soft_index != nullptr || a->sqerr_part != nullptr;      // the remainder plane / the outer batch / the soft index: gemm_kernel only
     const bool no_narrow = generic_only || a->sign_mask != nullptr || k.drop_thresh != 0;      // sign words / dropout: gemm_kernel and conv5_kernel only
     if (generic_only && tiling > EFTS_TILING_GENERIC) return efts_fail(EFTS_EINVAL, "efts_gemm: out_bf16_lo / batch2 need the generic tiling");
     const dim3 grid(k.mtiles * k.ntiles, a->batch, nb2);                  // one workgroup per 124 x 128 tile, 2 resident per CU

@@ -30,6 +30,7 @@ struct GemmKernelArgs {
     float* sidx;                // soft index of the softmax over each output row (efts_abi.h `soft_index`), [batch][m], or null
     const int* klen;            // valid columns per batch item
     const int* qlen;            // valid rows per batch item
+    float* sqerr;               // squared-error partial sums against a target that travels in `resid` / ldr / r_bs (efts_abi.h `sqerr_part`), or null
     unsigned drop_thresh, drop_seed_h;   // train-mode dropout of the activated value (efts_abi.h drop_p): keep iff hash >= thresh; 0 = off
     float drop_inv_keep;
     long lda, ldb, b_tap_stride, ldr, ldo, ldob;

@@ -547,6 +547,56 @@ __global__ __launch_bounds__(256) void losses_stage2(const float* __restrict__ p
     }
 }
 
+// the losses from the squared-error partial sums of the mel head's launch (efts_gemm_args.sqerr_part): one workgroup of 1024 threads, fixed
+// order.  The duration term's loads are all issued before the first is used (a 256-thread loop of dependent loads took 32 memory latencies:
+// the fused form was 15 us SLOWER than the two loss launches until this was fixed)
+__global__ __launch_bounds__(1024) void losses_from_parts(const float* __restrict__ part, int n_part, const int* __restrict__ mlen,
+                                                          const float* __restrict__ dp, const float* __restrict__ lde,
+                                                          const int* __restrict__ tlen, float* __restrict__ out3, int B, int T1, int T1p,
+                                                          int T2, int odim) {
+    __shared__ float sh[4][16];
+    const int tid = threadIdx.x;
+    float sm = 0.f, sd = 0.f, nm = 0.f, nt = 0.f;
+    constexpr int U = 8;
+    const int nd = B * T1;
+    for (int base = 0; base < nd; base += 1024 * U) {
+        float a[U], l[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * 1024 + tid;
+            const int b = idx < nd ? idx / T1 : 0, i = idx - b * T1;
+            ok[u] = idx < nd && i < tlen[b];
+            a[u] = ok[u] ? dp[(long)b * T1p + i] : 0.f;
+            l[u] = ok[u] ? lde[idx] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) sd += fabsf(a[u] - l[u]);
+    }
+    for (int i = tid; i < n_part; i += 1024) sm += part[i];
+    for (int b = tid; b < B; b += 1024) {
+        nm += (float)min(mlen[b], T2);
+        nt += (float)min(tlen[b], T1);
+    }
+    sm = wave_sum(sm); sd = wave_sum(sd); nm = wave_sum(nm); nt = wave_sum(nt);
+    if ((tid & 63) == 0) { sh[0][tid >> 6] = sm; sh[1][tid >> 6] = sd; sh[2][tid >> 6] = nm; sh[3][tid >> 6] = nt; }
+    __syncthreads();
+    if (tid == 0) {
+        float t[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) acc += sh[q][w];
+            t[q] = acc;
+        }
+        const float ml = t[0] / (t[2] * (float)odim), dl = t[1] / t[3];
+        out3[0] = ml + dl;
+        out3[1] = ml;
+        out3[2] = dl;
+    }
+}
+
 }  // namespace efts
 
 using namespace efts;
@@ -693,4 +743,15 @@ extern "C" int efts_masked_losses(const float* mel_pred, int64_t ldm, const floa
                        (float*)workspace, B, T1, T1p, T2, T2p, odim);
     hipLaunchKernelGGL(losses_stage2, dim3(1), dim3(256), 0, ST, (const float*)workspace, mel_len, text_len, out3, B, T1, T2, odim);
     return efts_check_launch("efts_masked_losses");
+}
+
+extern "C" int efts_losses_from_parts(const float* sqerr_part, int32_t n_part, const int32_t* mel_len, const float* dur_pred,
+                                      const float* log_delta_e, const int32_t* text_len, float* out3, int32_t B, int32_t T1,
+                                      int32_t T1p, int32_t T2, int32_t odim, void* stream) {
+    if (!sqerr_part || !mel_len || !dur_pred || !log_delta_e || !text_len || !out3)
+        return efts_fail(EFTS_EINVAL, "efts_losses_from_parts: null pointer");
+    if (n_part <= 0 || B <= 0 || T1 <= 0 || T2 <= 0 || odim <= 0 || (long)B * T1 > 0x7fffffffL)
+        return efts_fail(EFTS_ESHAPE, "efts_losses_from_parts: bad shape");
+    hipLaunchKernelGGL(losses_from_parts, dim3(1), dim3(1024), 0, ST, sqerr_part, n_part, mel_len, dur_pred, log_delta_e, text_len, out3, B, T1, T1p, T2, odim);
+    return efts_check_launch("efts_losses_from_parts");
 }

@@ -5,9 +5,11 @@ Replaces, for a whole batch on the GPU, what the reference does per item on CPU 
 (nntts/datasets/taco2_data.py:66-76), plus the mel padding of `TextMelCollate` (:122-139).
 Pipeline (csrc/efts_frontend.hip): frame_pack (reflect pad + hann window -> bf16x3 operand planes)
 -> efts_gemm against a real-DFT plane (MFMA) -> logmel (magnitude, Slaney mel filterbank, log clamp).
-Round 6: the DFT is split by decimation in time (`radix`, default 4): one batched efts_gemm of `radix` real
+Round 6: the DFT is split by decimation in time (`radix` >= 2): one batched efts_gemm of `radix` real
 (n_fft / radix)-point DFTs -- radix times fewer FLOPs than the dense n_fft-point product (26.9 instead of 107.6 GFLOP per
-64 x 800 frames) -- recombined by `radix` complex multiply-adds per bin in the logmel kernel.
+64 x 800 frames) -- recombined by `radix` complex multiply-adds per bin in the logmel kernel.  And for the reference's own configuration
+(n_fft 1024, hop 256) the default is `radix=0`: ONE launch, `efts_logmel_fft`, audio in and log-mels out, the STFT as an fp32 FFT in
+registers and LDS (two real frames per complex 1024-point FFT) -- no operand plane, no spectrum in memory.
 No CPU fallback: the HIP library is required.
 """
 from __future__ import annotations
@@ -56,11 +58,16 @@ class LogMelFrontend:
     frame count, T = max frames) and frames [B] int64 -- the (speech, speech_lengths) of the model."""
 
     def __init__(self, device, sampling_rate: int = 22050, n_fft: int = 1024, hop_size: int = 256, win_size: int = 1024,
-                 num_mels: int = 80, fmin: float = 0.0, fmax: float = 8000.0, max_wav_value: float = 32768.0, radix: int = 4):
+                 num_mels: int = 80, fmin: float = 0.0, fmax: float = 8000.0, max_wav_value: float = 32768.0, radix: Optional[int] = None):
         if win_size != n_fft:
             raise ValueError("win_size must equal n_fft (the reference's configuration)")
-        if radix < 1 or n_fft % radix or (n_fft // radix) % 32:
-            raise ValueError("radix must divide n_fft into whole 32-sample operand chunks (1 = the dense n_fft-point product)")
+        fft_ok = n_fft == 1024 and hop_size == 256 and num_mels <= 128
+        if radix is None:
+            radix = 0 if fft_ok else 4
+        if radix == 0 and not fft_ok:
+            raise ValueError("radix 0 (the fused FFT launch) is built for n_fft 1024, hop 256, at most 128 mel bins")
+        if radix < 0 or (radix and (n_fft % radix or (n_fft // radix) % 32)):
+            raise ValueError("radix must divide n_fft into whole 32-sample operand chunks (1 = the dense n_fft-point product, 0 = the fused FFT launch)")
         self.radix = radix
         self.dev = torch.device(device)
         self.n_fft, self.hop, self.n_mels, self.n_bins = n_fft, hop_size, num_mels, n_fft // 2 + 1
@@ -75,7 +82,10 @@ class LogMelFrontend:
         self.basis = torch.from_numpy(fb).to(self.dev).contiguous()
         self.ranges = torch.from_numpy(rng).to(self.dev).contiguous()
         self.window = torch.hann_window(win_size, dtype=torch.float32).to(self.dev)           # periodic hann, meldataset.py:67
-        if radix == 1:
+        if radix == 0:
+            self.dft = self.twiddle = None
+            self.n_out = self.ld_spec = 0
+        elif radix == 1:
             # real DFT as a B operand plane: rows 0..n_bins-1 = cos(2 pi f k / N), rows n_bins.. = -sin
             k = np.arange(n_fft, dtype=np.float64)[None, :]
             f = np.arange(self.n_bins, dtype=np.float64)[:, None]
@@ -117,15 +127,25 @@ class LogMelFrontend:
         if audio.dtype == torch.int16:
             audio = audio.to(self.dev).to(torch.float32) / self.max_wav_value                  # taco2_data.py:70
         audio = audio.to(self.dev, torch.float32).contiguous()
-        lengths_h = lengths.detach().to("cpu", torch.int64)
-        if int(lengths_h.min()) <= (self.n_fft - self.hop) // 2:
+        # host side of a call: the checks on plain ints, ONE small host-to-device copy (lengths and frame counts together), one output allocation
+        # (three CPU-tensor reductions and three copies took 60 us per call -- as long as the fused launch itself)
+        lh = lengths.detach().to("cpu", torch.int64).tolist()
+        if min(lh) <= (self.n_fft - self.hop) // 2:
             raise ValueError("every item must be longer than the reflect padding (n_fft - hop) / 2")
-        if int(lengths_h.max()) > audio.shape[1]:
+        if max(lh) > audio.shape[1]:
             raise ValueError("lengths exceed the audio buffer")
-        frames_h = lengths_h // self.hop
-        T = int(frames_h.max()) if max_frames is None else int(max_frames)
-        li = lengths_h.to(torch.int32).to(self.dev)
-        fi = frames_h.to(torch.int32).to(self.dev)
+        fh = [l // self.hop for l in lh]
+        T = max(fh) if max_frames is None else int(max_frames)
+        both = torch.tensor([lh, fh], dtype=torch.int32).to(self.dev)
+        li, fi = both[0], both[1]
+        frames_d = fi.to(torch.int64)
+        if self.radix == 0:
+            out = torch.empty(B, T, self.n_mels, dtype=torch.float32, device=self.dev)
+            with O.stream_scope():
+                L.check(L.load().efts_logmel_fft(audio.data_ptr(), audio.shape[1], li.data_ptr(), self.window.data_ptr(), self.basis.data_ptr(),
+                                                 self.ranges.data_ptr(), out.data_ptr(), B, T, self.n_fft, self.hop, self.n_mels, O._stream()),
+                        "efts_logmel_fft")
+            return out, frames_d
         rs = Rows(B, T)
         key = (B, T)
         if key not in self._ws:
@@ -152,4 +172,4 @@ class LogMelFrontend:
                 L.check(lib.efts_logmel_dit(spec.ptr, self.ld_spec, self.basis.data_ptr(), self.ranges.data_ptr(), fi.data_ptr(),
                                             self.twiddle.data_ptr(), out.data_ptr(), B, T, rs.Tp, self.n_bins, self.n_mels, self.radix, O._stream()),
                             "efts_logmel_dit")
-        return out, frames_h.to(self.dev)
+        return out, frames_d

@@ -12,7 +12,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EFTS_LIB", os.path.join(HERE, "libefts_hip.so"))   # EFTS_LIB: kernel experiments only
 
-ABI_VERSION = 600         # EFTS_ABI_VERSION of the include/efts_abi.h this binding mirrors; load() refuses any other library
+ABI_VERSION = 601         # EFTS_ABI_VERSION of the include/efts_abi.h this binding mirrors; load() refuses any other library
 RC_PLAN_INTS = 42
 GAP = 2
 GUARD_LO = 8
@@ -67,6 +67,7 @@ class GemmArgs(C.Structure):
         ("a_batch2_stride", i64), ("b_batch2_stride", i64), ("out_batch2_stride", i64),
         ("dilation", i32), ("plane_act", i32), ("plane_slope", f32),
         ("out_bf16_lo", vp), ("tiling", i32), ("sign_mask", vp), ("soft_index", vp), ("key_len", vp), ("query_len", vp), ("drop_p", f32), ("drop_seed", C.c_uint32),
+        ("sqerr_target", vp), ("ld_target", i64), ("target_batch_stride", i64), ("sqerr_part", vp),
     ]
 
 
@@ -135,6 +136,7 @@ _SIGS = {
     "efts_layernorm_dot": (i32, [vp, vp, vp, f32, vp, vp, vp, i32, f32, vp, i32, i32, f32, C.c_uint32, vp, vp]),
     "efts_losses_workspace_bytes": (C.c_size_t, []),
     "efts_masked_losses": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "efts_losses_from_parts": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     # training step
     "efts_pack_weight_t": (i32, [vp, vp, i64, i32, i32, i32, i32, vp]),
     "efts_pack_weights_grouped": (i32, [vp, i32, vp, i64, i64, i32, i32, i32, i32, i32, vp]),
@@ -167,6 +169,7 @@ _SIGS = {
     "efts_logmel": (i32, [vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "efts_frame_pack_dit": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp]),
     "efts_logmel_dit": (i32, [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "efts_logmel_fft": (i32, [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     # vocoder
     "efts_mean_act_rows": (i32, [vp, vp, vp, i64, f32, f32, vp, i64, vp, i64, i32, i32, i32, vp]),
 }

@@ -11,6 +11,7 @@ fallback: without the library or a gfx950 device the model raises.
 from __future__ import annotations
 
 import dataclasses
+import os
 import logging
 from typing import Dict, Optional, Tuple
 
@@ -157,6 +158,8 @@ class LaunchOptions:
     fuse_soft_index: bool = True    # T1 <= 128: q.k^T, softmax and soft index in one launch (False: scores stored, efts_attn_soft_index)
     fuse_align: bool = True         # imv scan + aligned positions + duration target in one launch (efts_imv_align)
     fuse_expand: bool = True        # T1 <= 256: alpha' generated in registers inside the expand contraction (efts_expand)
+    fuse_mel_loss: bool = True      # the loss's mel term in the epilogue of the mel head's launch (efts_gemm_args.sqerr_part) where that launch fills the chip
+    fuse_mel_loss_min_wgs: int = 0  # ... i.e. from this many 128-row tiles on (0: the number of CUs; tests lower it)
     embed_conv: bool = True         # eval paths: embedding + text-encoder layer 0 as table look-ups (efts_embed_conv)
     small_m: bool = True            # free-running inference on short row spaces: the K-split small-M tiling of efts_gemm
     small_m_rows: int = 1024        # ... up to this many rows
@@ -652,7 +655,7 @@ class EfficientTTSCNN(torch.nn.Module):
         return self.fuse_expand and T1 <= 256 and self.n_channels % 128 == 0
 
     def _expand_decode(self, ws, pk, B, T1, rs1: Rows, rs2: Rows, val_f: F32Rows, e, tl, ml, ralpha, len2_ptr, gap2,
-                       vt: Optional[Plane] = None, rider=None, after=None):
+                       vt: Optional[Plane] = None, rider=None, after=None, loss_target: Optional[torch.Tensor] = None):
         """Gaussian re-alignment from e, bmm(V^T, alpha') -> decoder -> mel head (efficient_tts.py:184-200 / :270-284).
         `ralpha` [B, T1, T2] receives alpha' (the API tensor); tl / ml: int32 lengths or None (no masks, :270-274);
         `vt`: V^T already packed (unfused path only)."""
@@ -676,9 +679,19 @@ class EfficientTTSCNN(torch.nn.Module):
         # launch: no row-space copy of mel_pred, no clone)
         mel = torch.empty(B, rs2.T, self.odim, dtype=torch.float32, device=h_p.buf.device)
         wh = pk["head"]
+        loss_kw = {}
+        if loss_target is not None and self.fuse_mel_loss and self.use_masking and len2_ptr is not None and self.odim % 4 == 0 and self.odim <= 128:
+            # the mel term of the loss (:220, fastspeech_loss.py:54-67) in the head's epilogue: the tile is in LDS, the target frames arrive
+            # where a residual would, the row mask IS the loss mask -- one launch less at the end of every forward.  Only where AUTO picks the
+            # generic tiling anyway (one workgroup per CU or more): a short launch keeps its 64-column tiles and the separate loss launch
+            mt = (rs2.T + 127) // 128
+            if B * mt >= (self.fuse_mel_loss_min_wgs or torch.cuda.get_device_properties(mel.device).multi_processor_count):
+                part = ws.tensor("sqerr_part", (B * mt * 4,))
+                loss_kw = dict(sqerr_target=loss_target, sqerr_part=part)
+                object.__setattr__(self, "_sqerr_parts", (part, B * mt * 4))
         O.gemm(a=d_p, b_ptr=wh.ptr, ldb=wh.ld, m=rs2.T, n=self.odim, batch=B, a_batch_stride=rs2.Tp * d_p.ld, bias=self.mel_output_layer.bias,
                rowmask_ptr=len2_ptr if len2_ptr is not None else gap2.data_ptr(), rowmask_batch_stride=rs2.Tp,
-               out_f32_ptr=mel.data_ptr(), ldo=self.odim, out_batch_stride=rs2.T * self.odim)
+               out_f32_ptr=mel.data_ptr(), ldo=self.odim, out_batch_stride=rs2.T * self.odim, **loss_kw)
         return mel
 
     def _require(self, t: torch.Tensor):
@@ -821,10 +834,11 @@ class EfficientTTSCNN(torch.nn.Module):
             # prenet's grid is capped at half the CUs and the text layers are scheduled onto the other half.
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
             share = ns > (1 if self._te0_table(pk) is not None else 0) and cus >= 64
+            pre_cus = int(os.environ.get("EFTS_AB_PRENET_CUS", cus // 2))
             with O.on_stream(side):
-                pre = prenet(cus // 2 if share else 0)
+                pre = prenet(pre_cus if share else 0)
                 pre_ready.record(side)
-            te_plan = O.resconv5_plan_buf(rs1.rows, C, cus // 2 - 2) if share else None
+            te_plan = O.resconv5_plan_buf(rs1.rows, C, cus - pre_cus - 2) if share else None
             if not masks_done:
                 O.row_masks(tl, rs1, gap1, len1)                                  # :137
             tab = self._te0_table(pk)
@@ -893,8 +907,9 @@ class EfficientTTSCNN(torch.nn.Module):
         ralpha = torch.empty(B, T1, T2, dtype=torch.float32, device=dev)
 
         main.wait_event(v_ready)
+        object.__setattr__(self, "_sqerr_parts", None)
         mel = self._expand_decode(ws, pk, B, T1, rs1, rs2, val_f, e, tl, ml, ralpha, len2.data_ptr(), gap2, vt=vt,
-                                  )                                                                          # :184-200
+                                  loss_target=speech)                                                        # :184-200
         main.wait_stream(side)                                                     # duration predictor done
 
         out3 = torch.empty(3, dtype=torch.float32, device=dev)                     # :220-227
@@ -902,8 +917,11 @@ class EfficientTTSCNN(torch.nn.Module):
         # (mel_pred, dur_pred and log_delta_e are zero beyond each item's length, speech is whatever the caller padded with)
         ml_loss = ml if self.use_masking else torch.full_like(ml, T2)
         tl_loss = tl if self.use_masking else torch.full_like(tl, T1)
-        O.masked_losses(mel.data_ptr(), self.odim, speech, ml_loss, dur, lde, tl_loss, out3, ws.tensor("loss_ws", (1024,)), B, T1,
-                        rs1.Tp, T2, T2, self.odim)
+        if self._sqerr_parts is not None:                                          # the mel head left the squared-error partial sums
+            O.losses_from_parts(self._sqerr_parts[0], self._sqerr_parts[1], ml_loss, dur, lde, tl_loss, out3, B, T1, rs1.Tp, T2, self.odim)
+        else:
+            O.masked_losses(mel.data_ptr(), self.odim, speech, ml_loss, dur, lde, tl_loss, out3, ws.tensor("loss_ws", (1024,)), B, T1,
+                            rs1.Tp, T2, T2, self.odim)
         mel_pred = mel
         ret = (out3[0], LazyStats(out3), imv, ralpha, mel_pred, speech)
         extra = dict(e=e, log_delta_e=lde, dur_pred=dur.view(B, rs1.Tp)[:, :T1], ws=ws) if keep else None

@@ -131,7 +131,7 @@ def gemm(*, a: Plane, a_ptr: Optional[int] = None, b_ptr: int, ldb: int, b_tap_s
          out_batch2_stride: int = 0, dilation: int = 1, plane_act: bool = False, plane_slope: float = 0.0,
          out_plane_lo: Optional[Plane] = None, tiling: Optional[int] = None, sign_mask_ptr: Optional[int] = None,
          soft_index: Optional[torch.Tensor] = None, key_len: Optional[torch.Tensor] = None, query_len: Optional[torch.Tensor] = None,
-         drop_p: float = 0.0, drop_seed: int = 0) -> None:
+         drop_p: float = 0.0, drop_seed: int = 0, sqerr_target: Optional[torch.Tensor] = None, sqerr_part: Optional[torch.Tensor] = None) -> None:
     g = L.GemmArgs()
     g.a, g.lda, g.a_batch_stride = (a_ptr if a_ptr is not None else a.ptr), a.ld, a_batch_stride
     g.b, g.ldb, g.b_tap_stride, g.b_batch_stride = b_ptr, ldb, b_tap_stride, b_batch_stride
@@ -152,6 +152,8 @@ def gemm(*, a: Plane, a_ptr: Optional[int] = None, b_ptr: int, ldb: int, b_tap_s
     g.tiling = GEMM_TILING if tiling is None else tiling
     g.sign_mask = sign_mask_ptr
     g.drop_p, g.drop_seed = drop_p, drop_seed & 0xFFFFFFFF
+    if sqerr_part is not None:                  # sum (out - target)^2 per workgroup and wave in the epilogue; target: fp32 [batch][m][n] contiguous
+        g.sqerr_target, g.ld_target, g.target_batch_stride, g.sqerr_part = sqerr_target.data_ptr(), n, m * n, sqerr_part.data_ptr()
     if soft_index is not None:                  # expected key index of the row softmax, computed in the epilogue (int32 lengths per batch item)
         g.soft_index, g.key_len, g.query_len = soft_index.data_ptr(), key_len.data_ptr(), query_len.data_ptr()
     if PROFILE is not None and (PROFILE_TAG is None or PROFILE_TAG == (taps, m, n)):
@@ -478,6 +480,11 @@ def masked_losses(mel_pred_ptr, ldm, speech, ml, dur_pred, lde, tl, out3, ws, B,
     L.check(L.load().efts_masked_losses(mel_pred_ptr, ldm, speech.data_ptr(), ml.data_ptr(), dur_pred.data_ptr(),
                                         lde.data_ptr(), tl.data_ptr(), out3.data_ptr(), ws.data_ptr(),
                                         B, T1, T1p, T2, T2p, odim, _stream()), "efts_masked_losses")
+
+
+def losses_from_parts(part, n_part, ml, dur_pred, lde, tl, out3, B, T1, T1p, T2, odim) -> None:
+    L.check(L.load().efts_losses_from_parts(part.data_ptr(), n_part, ml.data_ptr(), dur_pred.data_ptr(), lde.data_ptr(), tl.data_ptr(),
+                                            out3.data_ptr(), B, T1, T1p, T2, odim, _stream()), "efts_losses_from_parts")
 
 
 INV_SQRT = lambda d: 1.0 / math.sqrt(float(d))  # noqa: E731

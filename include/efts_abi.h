@@ -62,8 +62,10 @@ extern "C" {
  *   100  rounds 1-4
  *   500  round 5: efts_resconv5_args grew by act_bwd_sign / act_bwd_bias_part / act_bwd_bias_rows / act_bwd_slope / kernel;
  *        efts_wgrad_tn, efts_wgrad_reduce_bias, efts_resconv5_kernel removed (efts_wgrad_tn_grouped / efts_wgrad_reduce_grouped instead)
- *   600  round 6 (this header): + efts_frame_pack_dit, efts_logmel_dit; efts_pack_item.plane may be NULL (dgrad plane only) */
-#define EFTS_ABI_VERSION 600
+ *   600  round 6: + efts_frame_pack_dit, efts_logmel_dit; efts_pack_item.plane may be NULL (dgrad plane only)
+ *   601  round 6 (this header): efts_gemm_args grew by sqerr_target / ld_target / target_batch_stride / sqerr_part;
+ *        + efts_losses_from_parts, efts_logmel_fft */
+#define EFTS_ABI_VERSION 601
 int efts_version(void);
 const char* efts_last_error(void);
 /* 0 when the current HIP device is gfx950. */
@@ -145,6 +147,16 @@ typedef struct efts_gemm_args {
      * torch's Philox stream: same distribution, different draws).  batch 1, generic / wide tiling, vector epilogue.  0: none. */
     float drop_p;
     uint32_t drop_seed;
+    /* the mel term of FastSpeechLoss in the epilogue of the mel head (nntts/losses/fastspeech_loss.py:54-67 behind
+     * nntts/models/efficient_tts.py:198-200, :220): per workgroup and wave, the sum of (out - target)^2 over the rows of the tile whose
+     * rowmask value is not zero -- sqerr_part[((batch item * row tiles) + row tile) * 4 + wave], row tiles = ceil(m / 128) --
+     * in a fixed order (deterministic; efts_losses_from_parts adds the partial sums up).  target: fp32 [batch][m][ld_target] (what the
+     * caller padded the frames with is never read past a zero rowmask value); needs rowmask, one tap, n <= 128, n % 4 == 0, no residual,
+     * no dropout, 16-byte aligned target rows, and runs on the generic tiling only.  NULL: not computed. */
+    const float* sqerr_target;
+    int64_t ld_target;           /* elements */
+    int64_t target_batch_stride; /* elements */
+    float* sqerr_part;
 } efts_gemm_args;
 
 #define EFTS_TILING_AUTO 0
@@ -421,6 +433,11 @@ int efts_masked_losses(const float* mel_pred, int64_t ldm, const float* speech, 
                        const float* dur_pred, const float* log_delta_e, const int32_t* text_len,
                        float* out3, void* workspace, int32_t B, int32_t T1, int32_t T1p, int32_t T2,
                        int32_t T2p, int32_t odim, void* stream);
+/* The same losses when the mel head's launch already left the squared-error partial sums (efts_gemm_args.sqerr_part, n_part of
+ * them): one single-workgroup launch adds them up in index order, takes the duration L1 itself and writes out[0..2] as above. */
+int efts_losses_from_parts(const float* sqerr_part, int32_t n_part, const int32_t* mel_len, const float* dur_pred,
+                           const float* log_delta_e, const int32_t* text_len, float* out3, int32_t B, int32_t T1,
+                           int32_t T1p, int32_t T2, int32_t odim, void* stream);
 
 /* ====================================================================================
  * Training step (backward + optimizer).  The reference backward is torch autograd of the
@@ -624,6 +641,14 @@ int efts_frame_pack_dit(const float* audio, int64_t ld_audio, const int32_t* len
 int efts_logmel_dit(const float* spec, int64_t ld_spec, const float* basis, const int32_t* ranges, const int32_t* frames,
                     const float* twiddle, float* out, int32_t B, int32_t T, int32_t Tp, int32_t n_bins, int32_t n_mels, int32_t radix,
                     void* stream);
+
+/* The whole front-end as ONE launch (round 6; n_fft 1024, hop 256, n_mels <= 128: the reference's configuration): audio in, log-mels out, the
+ * STFT as an fp32 FFT in registers and LDS -- one wave per pair of neighbouring frames (two real frames = one complex 1024-point FFT, taken apart
+ * by conjugate symmetry), no operand plane and no spectrum in memory.  Arguments as efts_frame_pack (audio, lengths, window) and efts_logmel
+ * (basis, ranges, out); the frame count of item b is lengths[b] / hop; out[b][t][:] = 0 for t past it.  Other configurations: the three-launch
+ * pipeline above. */
+int efts_logmel_fft(const float* audio, int64_t ld_audio, const int32_t* lengths, const float* window, const float* basis,
+                    const int32_t* ranges, float* out, int32_t B, int32_t T, int32_t n_fft, int32_t hop, int32_t n_mels, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * HiFi-GAN generator (nntts/vocoders/hifigan_model.py:95-136): every Conv1d /

@@ -43,7 +43,7 @@ def test_args_layouts_match_header():
     """sizeof and field offsets of every argument struct of the ABI as compiled by gcc == the ctypes mirrors."""
     import subprocess, tempfile, ctypes
     structs = {
-        "efts_gemm_args": (L.GemmArgs, ["out_bf16_lo", "tiling", "sign_mask", "soft_index", "key_len", "query_len", "drop_p", "drop_seed"]),
+        "efts_gemm_args": (L.GemmArgs, ["out_bf16_lo", "tiling", "sign_mask", "soft_index", "key_len", "query_len", "drop_p", "drop_seed", "sqerr_target", "ld_target", "target_batch_stride", "sqerr_part"]),
         "efts_resconv5_args": (L.ResConv5Args, ["x", "x_lo", "x_f32", "w", "split", "rowmask", "y_f32", "y", "y_lo", "y_split", "plan", "taps", "no_residual", "sign_bits", "act_bwd_sign", "act_bwd_bias_part", "act_bwd_bias_rows", "act_bwd_slope", "kernel"]),
         "efts_frame_linear_args": (L.FrameLinearArgs, ["x", "w", "bias", "act", "B", "n", "y_f32", "y", "y_lo", "ldy", "y_split", "max_workgroups"]),
         "efts_wgrad_item": (L.WgradItem, ["dz_plane", "ldz", "x_plane", "ldx", "v", "g", "dw_or_dv", "dg", "bias_part", "dbias", "nparts", "reserved"]),

@@ -118,7 +118,7 @@ def test_frontend_edge_cases_and_model_handoff():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("radix", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("radix", [0, 1, 2, 4, 8, 16])
 def test_frontend_radix_split_dft_equals_the_dense_product(radix):
     """round 6: the DFT split by decimation in time (`radix` real DFTs of 1024 / radix points as one batched contraction, recombined in the
     logmel kernel) against the oracle's torch.stft, for every radix incl. the dense 1024-point product (radix 1) -- same tolerance -- and

@@ -282,6 +282,38 @@ def test_odd_shapes_and_ragged_lengths_vs_oracle(model, B, T1, T2, tl, sl):
 
 
 @pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("B,T1,T2", [(3, 40, 300), (5, 128, 517)])
+def test_mel_loss_in_the_head_epilogue_equals_the_loss_launch(precision, B, T1, T2):
+    """efts_gemm_args.sqerr_part: the mel head's launch leaves sum (mel_pred - speech)^2 over the valid frames per workgroup and wave and
+    efts_losses_from_parts adds them up (fastspeech_loss.py:54-67 behind efficient_tts.py:198-200, :220).  Against the separate loss
+    launches on ragged lengths: the outputs of the head bit for bit, the three loss values to fp32 summation order, run-to-run identical."""
+    from efficient_tts_amd import EfficientTTSCNN
+    g = torch.Generator().manual_seed(B * 1000 + T2)
+    m = EfficientTTSCNN(num_symbols=76, dropout_rate=0.0, use_masking=True, sigma=0.01, precision=precision)
+    m.load_state_dict(O.fill_params())
+    m = m.cuda().eval()
+    m.graphs = False
+    text = torch.randint(0, 76, (B, T1), generator=g).cuda()
+    speech = torch.randn(B, T2, 80, generator=g).cuda()
+    tl = torch.randint(T1 // 2, T1 + 1, (B,), generator=g)
+    ml = torch.randint(T2 // 2, T2 + 1, (B,), generator=g)
+    tl[0], ml[0] = T1, T2
+    speech[1, int(ml[1]):] = float("nan")              # frames past an item's length are never read into the loss
+    outs = {}
+    with torch.no_grad():
+        for fused in (False, True, True):
+            m.fuse_mel_loss, m.fuse_mel_loss_min_wgs = fused, 1
+            o = m(text, tl.cuda(), speech, ml.cuda())
+            torch.cuda.synchronize()
+            assert (m._sqerr_parts is not None) == fused
+            outs.setdefault(fused, []).append((o[1]._t.clone().cpu(), o[4].clone()))       # (loss, mel_loss, duration_loss) as the device wrote them
+    (la, mela), (lb, melb), (lc, melc) = outs[False][0], outs[True][0], outs[True][1]
+    assert torch.equal(mela, melb) and torch.equal(melb, melc)
+    assert torch.equal(lb, lc)
+    assert torch.isfinite(la).all() and ((la - lb).abs() <= 2e-6 * la.abs()).all(), (la, lb)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
 def test_narrow_tiles_equal_gemm_kernel(golden_dir, precision):
     """Launches that leave most CUs idle (the text side of a 2-item batch: 260 rows) take 64-column tiles in the automatic
     tiling; forcing the generic 124 x 128 kernel for EVERY launch of the forward must give the same outputs to the last bits

@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 TAG=${1:-r01}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-BENCH="python $R/bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --parity-mode 0 --call-modes 0 --measure-traffic 0 --train-record 0 --precision ${PREC:-bf16} --workload ${WL:-fwd64} ${BARGS:-}"
+BENCH="python $R/bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --parity-mode 0 --call-modes 0 --measure-traffic 0 --train-record 0 --sub-records 0 --stock-gpu 0 --precision ${PREC:-bf16} --workload ${WL:-fwd64} ${BARGS:-}"
 # the trace pass runs long enough for the clock governor to settle (30 + 10 steps: short samples run 3-5 % slower, DESIGN.md 4a'); the
 # counter passes below keep the short run
 TBENCH=${BENCH/--steps ${STEPS:-5} --warmup 2/--steps ${TSTEPS:-30} --warmup ${TWARM:-10}}
