@@ -308,11 +308,12 @@ __global__ __launch_bounds__(64 * LM_WAVES) void logmel_dit_fast_kernel(const fl
 // ----------------------------------------------------------------------------------------------------------------------------
 namespace fft {
 
-struct cf { float x, y; };
-__device__ __forceinline__ cf operator+(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cf operator-(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ cf cmul(cf a, cf b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-__device__ __forceinline__ cf mul_mi(cf a) { return {a.y, -a.x}; }                 // a * (-i)
+// a complex value = one register pair: +, - and the two halves of a complex product are single packed instructions (v_pk_add_f32 /
+// v_pk_mul_f32 / v_pk_fma_f32 with op_sel picking the halves).  With a plain struct of two floats the vectoriser paired unrelated scalars
+// and spent a fifth of the loop on v_mov to assemble the pairs.
+typedef float cf __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf cmul(cf a, cf b) { const cf bp = {-b.y, b.x}; return a.xx * b + a.yy * bp; }
+__device__ __forceinline__ cf mul_mi(cf a) { const cf r = {a.y, -a.x}; return r; }                 // a * (-i)
 
 // forward 4-point DFT in place (W4 = -i)
 __device__ __forceinline__ void dft4(cf& a, cf& b, cf& c, cf& d) {
@@ -326,9 +327,9 @@ __device__ __forceinline__ void dft16(cf* v) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);          // over a: v[4 c + b] = y_b[c]
     // y_b[c] *= W16^(b c)
-    v[4 + 1] = cmul(v[4 + 1], {C1, -S1});  v[4 + 2] = cmul(v[4 + 2], {H, -H});     v[4 + 3] = cmul(v[4 + 3], {S1, -C1});
-    v[8 + 1] = cmul(v[8 + 1], {H, -H});    v[8 + 2] = mul_mi(v[8 + 2]);            v[8 + 3] = cmul(v[8 + 3], {-H, -H});
-    v[12 + 1] = cmul(v[12 + 1], {S1, -C1}); v[12 + 2] = cmul(v[12 + 2], {-H, -H}); v[12 + 3] = cmul(v[12 + 3], {-C1, S1});
+    v[4 + 1] = cmul(v[4 + 1], cf{C1, -S1});  v[4 + 2] = cmul(v[4 + 2], cf{H, -H});     v[4 + 3] = cmul(v[4 + 3], cf{S1, -C1});
+    v[8 + 1] = cmul(v[8 + 1], cf{H, -H});    v[8 + 2] = mul_mi(v[8 + 2]);            v[8 + 3] = cmul(v[8 + 3], cf{-H, -H});
+    v[12 + 1] = cmul(v[12 + 1], cf{S1, -C1}); v[12 + 2] = cmul(v[12 + 2], cf{-H, -H}); v[12 + 3] = cmul(v[12 + 3], cf{-C1, S1});
 #pragma unroll
     for (int c = 0; c < 4; ++c) dft4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);   // over b: v[4 c + d] = X[c + 4 d]
     // to natural order: X[k] sits at v[4 (k & 3) + (k >> 2)] -- a 4 x 4 transpose of the register names
@@ -370,13 +371,13 @@ __global__ __launch_bounds__(64 * FF_WAVES, 3) void logmel_fft_kernel(const floa
         const int k = i / 64 + 1, n2 = i & 63;
         float sn, cs;
         if (FF_ABL & 64) { sn = 0.f; cs = 1.f; } else sincospif(-(float)((n2 * k) & 1023) / 512.f, &sn, &cs);
-        tw1s[k - 1][n2] = {cs, sn};
+        tw1s[k - 1][n2] = cf{cs, sn};
     }
     if (threadIdx.x < 64) {
         const int qq = threadIdx.x >> 4, ss = threadIdx.x & 15;
         float sn, cs;
         sincospif(-(float)((qq * ss) & 63) / 32.f, &sn, &cs);
-        tw2s[qq][ss] = {cs, sn};
+        tw2s[qq][ss] = cf{cs, sn};
     }
     // span of a filter in cb: filters below FF_WIDE run on one lane, the others on four (a quarter each); all spans of a kind have the length of
     // the widest one (w0 / w1 4-tap steps, per lane), shorter ones are padded with zero weights -- so offsets are closed-form and a lane may run
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(64 * FF_WAVES, 3) void logmel_fft_kernel(const floa
         }
         cf v[16];
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) v[n1] = {sm[n1] * win[n1], vb ? sm[n1 + 4] * win[n1] : 0.f};
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = cf{sm[n1] * win[n1], vb ? sm[n1 + 4] * win[n1] : 0.f};
 #if !(FF_ABL & 2)
         dft16(v);
 #pragma unroll
@@ -474,10 +475,10 @@ __global__ __launch_bounds__(64 * FF_WAVES, 3) void logmel_fft_kernel(const floa
         for (int s = 0; s < 16; ++s) {
             cf c = v[s];
             const cf p = quad<0x4E>(c);                             // quad_perm [2, 3, 0, 1]
-            c = {c.x * s1 + p.x, c.y * s1 + p.y};                    // q0: x0 + x2, q1: x1 + x3, q2: x0 - x2, q3: x1 - x3
+            c = c * s1 + p;                                          // q0: x0 + x2, q1: x1 + x3, q2: x0 - x2, q3: x1 - x3
             if (q == 3) c = mul_mi(c);
             const cf p2 = quad<0xB1>(c);                            // quad_perm [1, 0, 3, 2]
-            v[s] = {c.x * s2 + p2.x, c.y * s2 + p2.y};               // q0: X0, q1: X2, q2: X1, q3: X3
+            v[s] = c * s2 + p2;                                      // q0: X0, q1: X2, q2: X1, q3: X3
         }
 #endif
         const int u = ((q & 1) << 1) | (q >> 1);
@@ -494,8 +495,8 @@ __global__ __launch_bounds__(64 * FF_WAVES, 3) void logmel_fft_kernel(const floa
                 const cf zf = zw[f], zn = zw[(N - f) & (N - 1)];
                 const float ar = 0.5f * (zf.x + zn.x), ai = 0.5f * (zf.y - zn.y);
                 const float br = 0.5f * (zf.y + zn.y), bi = -0.5f * (zf.x - zn.x);
-                zw[f] = {__builtin_amdgcn_sqrtf(ar * ar + ai * ai + 1e-9f),       // meldataset.py:75 (v_sqrt_f32: 1 ulp)
-                         __builtin_amdgcn_sqrtf(br * br + bi * bi + 1e-9f)};
+                zw[f] = cf{__builtin_amdgcn_sqrtf(ar * ar + ai * ai + 1e-9f),     // meldataset.py:75 (v_sqrt_f32: 1 ulp)
+                           __builtin_amdgcn_sqrtf(br * br + bi * bi + 1e-9f)};
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

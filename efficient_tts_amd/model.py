@@ -834,11 +834,10 @@ class EfficientTTSCNN(torch.nn.Module):
             # prenet's grid is capped at half the CUs and the text layers are scheduled onto the other half.
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
             share = ns > (1 if self._te0_table(pk) is not None else 0) and cus >= 64
-            pre_cus = int(os.environ.get("EFTS_AB_PRENET_CUS", cus // 2))
             with O.on_stream(side):
-                pre = prenet(pre_cus if share else 0)
+                pre = prenet(cus // 2 if share else 0)                             # (r6: 128 / 144 / 160 / 176 CUs for the prenet measured: no difference)
                 pre_ready.record(side)
-            te_plan = O.resconv5_plan_buf(rs1.rows, C, cus - pre_cus - 2) if share else None
+            te_plan = O.resconv5_plan_buf(rs1.rows, C, cus // 2 - 2) if share else None
             if not masks_done:
                 O.row_masks(tl, rs1, gap1, len1)                                  # :137
             tab = self._te0_table(pk)
