@@ -624,8 +624,8 @@ extern "C" int efts_logmel_fft(const float* audio, int64_t ld_audio, const int32
                                const int32_t* ranges, float* out, int32_t B, int32_t T, int32_t n_fft, int32_t hop, int32_t n_mels, void* stream) {
     if (!audio || !lengths || !window || !basis || !ranges || !out) return efts_fail(EFTS_EINVAL, "efts_logmel_fft: null pointer");
     if (B <= 0 || T <= 0) return efts_fail(EFTS_ESHAPE, "efts_logmel_fft: bad B / T");
-    if (n_fft != 1024 || hop != 256 || n_mels <= 0 || n_mels > 128)
-        return efts_fail(EFTS_ESHAPE, "efts_logmel_fft: the fused kernel is built for n_fft 1024, hop 256, at most 128 mel bins (other configurations: efts_frame_pack_dit + efts_gemm + efts_logmel_dit)");
+    if (n_fft != 1024 || hop != 256 || n_mels <= 0 || n_mels > FF_WIDE + 16)
+        return efts_fail(EFTS_ESHAPE, "efts_logmel_fft: the fused kernel is built for n_fft 1024, hop 256, at most 80 mel bins (64 filters on one lane each + 16 on four lanes each; other configurations: efts_frame_pack_dit + efts_gemm + efts_logmel_dit)");
     const long pairs = (long)B * ((T + 1) / 2);
     long blocks = (pairs + FF_WAVES - 1) / FF_WAVES;
     const long cap = 3L * efts_num_cus();                     // persistent: three workgroups per CU (LDS, registers), each wave works through pairs / (12 CUs) frame pairs

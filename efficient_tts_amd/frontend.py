@@ -61,11 +61,11 @@ class LogMelFrontend:
                  num_mels: int = 80, fmin: float = 0.0, fmax: float = 8000.0, max_wav_value: float = 32768.0, radix: Optional[int] = None):
         if win_size != n_fft:
             raise ValueError("win_size must equal n_fft (the reference's configuration)")
-        fft_ok = n_fft == 1024 and hop_size == 256 and num_mels <= 128
+        fft_ok = n_fft == 1024 and hop_size == 256 and num_mels <= 80
         if radix is None:
             radix = 0 if fft_ok else 4
         if radix == 0 and not fft_ok:
-            raise ValueError("radix 0 (the fused FFT launch) is built for n_fft 1024, hop 256, at most 128 mel bins")
+            raise ValueError("radix 0 (the fused FFT launch) is built for n_fft 1024, hop 256, at most 80 mel bins")
         if radix < 0 or (radix and (n_fft % radix or (n_fft // radix) % 32)):
             raise ValueError("radix must divide n_fft into whole 32-sample operand chunks (1 = the dense n_fft-point product, 0 = the fused FFT launch)")
         self.radix = radix

@@ -642,7 +642,7 @@ int efts_logmel_dit(const float* spec, int64_t ld_spec, const float* basis, cons
                     const float* twiddle, float* out, int32_t B, int32_t T, int32_t Tp, int32_t n_bins, int32_t n_mels, int32_t radix,
                     void* stream);
 
-/* The whole front-end as ONE launch (round 6; n_fft 1024, hop 256, n_mels <= 128: the reference's configuration): audio in, log-mels out, the
+/* The whole front-end as ONE launch (round 6; n_fft 1024, hop 256, n_mels <= 80: the reference's configuration): audio in, log-mels out, the
  * STFT as an fp32 FFT in registers and LDS -- one wave per pair of neighbouring frames (two real frames = one complex 1024-point FFT, taken apart
  * by conjugate symmetry), no operand plane and no spectrum in memory.  Arguments as efts_frame_pack (audio, lengths, window) and efts_logmel
  * (basis, ranges, out); the frame count of item b is lengths[b] / hop; out[b][t][:] = 0 for t past it.  Other configurations: the three-launch

@@ -142,3 +142,34 @@ def test_frontend_radix_split_dft_equals_the_dense_product(radix):
     mel, frames = LogMelFrontend("cuda:0", radix=radix)(audio, lengths)
     ref, rfr = LO.batch_logmel(audio, lengths)
     assert frames.tolist() == rfr.tolist() and float((mel.cpu() - ref).abs().max()) < LOGMEL_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_mels,fmax", [(80, 8000.0), (64, 11025.0), (40, 4000.0), (72, 7600.0)])
+def test_fused_fft_launch_on_other_filterbanks_and_frame_counts(num_mels, fmax):
+    """efts_logmel_fft (radix 0) against the MFMA pipeline (radix 4, itself pinned to the oracle above) on filterbanks whose span lengths differ
+    from the reference's -- fewer than 64 filters (no four-lane filters at all), wider triangles, a lower fmax -- and on odd / even frame counts,
+    a batch padded past every item's length (`max_frames`), one item.  n_mels > 80 is refused by the fused launch (the front-end then takes the
+    split MFMA product by itself)."""
+    from efficient_tts_amd.frontend import LogMelFrontend
+    gen = torch.Generator().manual_seed(num_mels)
+    lengths = torch.tensor([256 * 9, 256 * 12 + 17, 700, 256 * 31])
+    audio = (torch.rand(4, int(lengths.max()), generator=gen) * 2 - 1) * 0.4
+    for b, l in enumerate(lengths):
+        audio[b, int(l):] = float("nan")                          # never read past an item's length
+    f0 = LogMelFrontend("cuda:0", num_mels=num_mels, fmax=fmax)
+    f4 = LogMelFrontend("cuda:0", num_mels=num_mels, fmax=fmax, radix=4)
+    assert f0.radix == 0
+    for mf in (None, 35):
+        m0, fr0 = f0(audio, lengths, max_frames=mf)
+        m4, fr4 = f4(audio, lengths, max_frames=mf)
+        assert m0.shape == m4.shape and fr0.tolist() == fr4.tolist() == [9, 12, 2, 31]
+        assert torch.isfinite(m0).all()
+        assert float((m0 - m4).abs().max()) < LOGMEL_TOL
+        for b, n in enumerate(fr0.tolist()):
+            assert float(m0[b, n:].abs().max() if n < m0.shape[1] else 0.0) == 0.0
+    one, _ = f0(audio[:1], lengths[:1])
+    assert torch.equal(one[0], f0(audio, lengths)[0][0, :9])
+    assert LogMelFrontend("cuda:0", num_mels=96).radix == 4      # the fused launch holds at most 80 filters
+    with pytest.raises(ValueError):
+        LogMelFrontend("cuda:0", num_mels=96, radix=0)
