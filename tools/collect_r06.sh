@@ -56,8 +56,11 @@ python bench.py --workload train32 --precision bf16x3 --no-cpu-baseline > $O/ben
 python bench.py --workload infer64 > $O/bench_infer64_bf16_$TAGR.json 2> $O/bench_infer.err
 python bench.py --workload infer_lj > $O/bench_infer_lj_bf16_$TAGR.json 2>> $O/bench_infer.err
 python bench.py --workload logmel64 > $O/bench_logmel64_$TAGR.json 2>> $O/bench_infer.err
+python bench.py --workload vocoder --no-cpu-baseline > $O/bench_vocoder_$TAGR.json 2>> $O/bench_infer.err
+# launch-skipping bounds of the forward (what removing a group of launches could return at most), both precisions
+( timeout 300 python tools/gpu_probe_fwd_skip.py bf16; timeout 300 python tools/gpu_probe_fwd_skip.py bf16x3 ) 2>&1 | grep BOUND > $O/fwd_skip_bounds_$TAGR.txt
 # the forward on the one-wave-per-SIMD kernel (where it is eligible), interleaved with the default for an in-situ comparison
-for k in 0 2 0 2; do python bench.py --rc-kernel $k --no-cpu-baseline --parity-mode 0 --call-modes 0 --measure-traffic 0 --train-record 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('rc-kernel $k', 'ms_per_step', round(d['ms_per_step'], 4), 'roofline', d['roofline']['achieved'], d['roofline']['frac'])"; done > $O/bench_rc_kernel_ab_$TAGR.txt 2>&1
+for k in 0 2 0 2; do python bench.py --rc-kernel $k --no-cpu-baseline --parity-mode 0 --call-modes 0 --measure-traffic 0 --train-record 0 --sub-records 0 --stock-gpu 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('rc-kernel $k', 'ms_per_step', round(d['ms_per_step'], 4), 'roofline', d['roofline']['achieved'], d['roofline']['frac'])"; done > $O/bench_rc_kernel_ab_$TAGR.txt 2>&1
 for f in $O/bench_*_$TAGR.json; do test -s $f || { echo "BENCH FAILED: $f"; exit 1; }; done
 fi
 ls -la $O
