@@ -12,7 +12,7 @@ sample() {  # label, seconds
 }
 rocm-smi --showmaxpower 2>/dev/null | grep -i "max\|cap" | head -4
 sample idle 3
-for k in 1 2; do
+for k in 0 2; do
   RCK=$k PCHECK=0 PREF=0 PMODES=planes PSHAPES=64x800 PSPLIT=1 PLOOP=30000 timeout 120 python tools/gpu_probe_rc.py > /tmp/pw_$k.log 2>&1 &
   pid=$!
   sleep 6
@@ -20,7 +20,7 @@ for k in 1 2; do
   wait $pid
   grep "us$" /tmp/pw_$k.log
 done
-RCK=1 PCHECK=0 PREF=0 PMODES=planes PSHAPES=64x800 PSPLIT=2 PLOOP=15000 timeout 120 python tools/gpu_probe_rc.py > /tmp/pw_x3.log 2>&1 &
+RCK=0 PCHECK=0 PREF=0 PMODES=planes PSHAPES=64x800 PSPLIT=2 PLOOP=15000 timeout 120 python tools/gpu_probe_rc.py > /tmp/pw_x3.log 2>&1 &
 pid=$!
 sleep 6
 sample "resconv5 bf16x3 (B=64 layer in a loop)" 6
