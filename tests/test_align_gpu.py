@@ -242,3 +242,30 @@ def test_row_masks_pair_equals_two_row_masks_launches(dtype):
     assert o1.dtype == torch.int32 and torch.equal(o1, l1.to(torch.int32)) and torch.equal(o2, l2.to(torch.int32))
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,C", [(2, 800, 512), (3, 70, 128), (1, 128, 64), (2, 97, 192), (2, 40, 512), (2, 300, 80)])
+def test_pack_vt_layout_both_kernels(B, T, C):
+    """efts_pack_vt: x [B][T][C] fp32 in a row space -> the split-2 plane of x^T ([B * C] rows, K = T: 32 hi + 32 lo bf16 per 128-byte chunk), byte for
+    byte against the same layout built with torch -- the 64 x 64 form (C % 64 == 0, T >= 64: 16-byte stores; round 6, the training step's mel-length
+    transposes) and the 32 x 32 form (everything else); positions past T inside the last chunk are zero, nothing is written past the row's chunks."""
+    from efficient_tts_amd import ops as P
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 100 + T + C)
+    x = torch.randn(B, T, C, generator=g) * torch.logspace(-3, 1, C)          # a wide range of magnitudes per channel
+    rs = P.Rows(B, T)
+    xf = P.F32Rows(rs, C, dev)
+    xf.view().copy_(x.to(dev))
+    pl = P.Plane(B * C, T, 2, dev)
+    pl.buf.fill_(0xAB)                                                       # (the kernel owns every byte of a row's chunks)
+    P.pack_vt(xf, pl, B, T, rs.Tp, C)
+    torch.cuda.synchronize()
+    nchunk = (T + 31) // 32
+    xt = torch.zeros(B, C, nchunk * 32)
+    xt[:, :, :T] = x.transpose(1, 2)
+    hi = xt.to(torch.bfloat16)
+    lo = (xt - hi.float()).to(torch.bfloat16)
+    want = torch.stack([hi.view(B, C, nchunk, 32), lo.view(B, C, nchunk, 32)], dim=3).reshape(B * C, nchunk * 64)
+    got = pl.buf.view(torch.bfloat16).view(B * C, -1)[:, :nchunk * 64].cpu()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
