@@ -44,6 +44,7 @@ _WGRAD_STREAM = 3            # the mel-length weight gradients (mel head, decode
                              # on the dgrad chain waits for them, and they fill what that chain leaves idle -- above all the backward of the alignment block,
                              # 0.25 ms of small latency-bound launches that use neither the matrix pipes nor the power budget.  Joined in front of a gradient
                              # bucket's hand-over (data parallel) or of the optimizer.  Bit 0: decoder group, bit 1: head, mel-encoder group, prenet (A/B)
+_GV_ON_SIDE = 1              # eager steps: the dV branch of the alignment backward (pack_vt of dH + one batched product) on the text-side stream beside the d alpha' -> ... -> dK chain
 _FUSE_ACT_BWD = 1            # stacks whose dgrad runs on efts_resconv5: the activation backward of layer l - 1 in the epilogue of layer l's dgrad launch
                              # (csrc/efts_resconv_bwd.hip) instead of an efts_act_bwd launch of its own (0: separate launches; tests compare)
 _WGRAD_GROUP_WGS = 384       # workgroups of a grouped launch (0: two per CU).  Swept 256..512 on the graphed B = 32 step: 3.27-3.32 ms at 384 against 3.33-3.34 at 512,
@@ -674,13 +675,31 @@ class TrainEngine:
         O.gemm(a=val_p2, b_ptr=dH_p.ptr, ldb=dH_p.ld, m=T1, n=T2, batch=B, a_batch_stride=rs1.Tp * val_p2.ld,
                b_batch_stride=rs2.Tp * dH_p.ld, out_f32_ptr=dAp.data_ptr(), ldo=T2, out_batch_stride=T1 * T2)
         dHt = ws.raw_plane("BdHt", B * C + 136, T2, 2)              # dH^T per item: [B][C][K = j]
-        O.pack_vt(dH, dHt, B, T2, rs2.Tp, C)
         GV = ws.f32("BGV", rs1, C)
         GV_p = ws.plane("BGV_p", rs1, C, split)
-        main.wait_event(ev_durb)                                    # dV of the duration predictor (and its gradients: bucket 1)
-        O.gemm(a=ra1_p, b_ptr=dHt.ptr, ldb=dHt.ld, m=T1, n=C, batch=B, a_batch_stride=rs1.Tp * ra1_p.ld, b_batch_stride=C * dHt.ld,
-               resid_ptr=dV_dur.ptr, ldr=C, resid_batch_stride=rs1.Tp * C, rowmask_ptr=len1.data_ptr(), rowmask_batch_stride=rs1.Tp,
-               out_f32_ptr=GV.ptr, ldo=C, out_batch_stride=rs1.Tp * C, out_plane=GV_p, outb_batch_stride=rs1.Tp * GV_p.ld)
+
+        def dv_branch():                                             # dV = alpha' . dH (+ the duration predictor's dV): transpose of dH + one batched product
+            O.pack_vt(dH, dHt, B, T2, rs2.Tp, C)
+            O.gemm(a=ra1_p, b_ptr=dHt.ptr, ldb=dHt.ld, m=T1, n=C, batch=B, a_batch_stride=rs1.Tp * ra1_p.ld, b_batch_stride=C * dHt.ld,
+                   resid_ptr=dV_dur.ptr, ldr=C, resid_batch_stride=rs1.Tp * C, rowmask_ptr=len1.data_ptr(), rowmask_batch_stride=rs1.Tp,
+                   out_f32_ptr=GV.ptr, ldo=C, out_batch_stride=rs1.Tp * C, out_plane=GV_p, outb_batch_stride=rs1.Tp * GV_p.ld)
+
+        ev_gv = None
+        if _GV_ON_SIDE and m.side_stream and not torch.cuda.is_current_stream_capturing():
+            # nothing between here and dK reads dV: the branch runs on the text-side stream (idle until dK / dV exist, and the consumer of both)
+            # beside the chain d alpha' -> e -> pi -> soft index -> scores -> dQ, dK instead of in front of it.  Eager launches only: 3.51-3.63 -> 3.46-3.56 ms per
+            # step; captured into the step's hipGraph the extra branch costs 0.1 ms (3.41 vs 3.30 ms, bf16x3 6.55 vs 6.27: the replayed graph's stream
+            # assignment loses the overlap of the weight-gradient stream), so a capturing pass keeps the branch on the main stream
+            ev_dh = torch.cuda.Event()
+            ev_dh.record(main)
+            side.wait_event(ev_dh)
+            with O.on_stream(side):
+                dv_branch()                                          # (dV_dur and alpha' as an operand were produced on this stream)
+                ev_gv = torch.cuda.Event()
+                ev_gv.record(side)
+        else:
+            main.wait_event(ev_durb)                                 # dV of the duration predictor (and its gradients: bucket 1)
+            dv_branch()
 
         # ---- alpha' -> e -> pi -> soft index -> scores
         de, dpi, dsx = ws.tensor("Bde", (B, T1)), ws.tensor("Bdpi", (B, T2)), ws.tensor("Bdsx", (B, T2))
@@ -703,6 +722,8 @@ class TrainEngine:
         GK = ws.f32("BGK", rs1, C)
         GK_p = ws.plane("BGK_p", rs1, C, split)
         shared = m.share_text_encoder_key_value                     # value = key projection: its gradient joins dK here (residual)
+        if ev_gv is not None:
+            main.wait_event(ev_gv)                                   # (shared: dV is the residual of the next launch; else: one join for everything behind)
         O.gemm(a=dSt, b_ptr=qt.ptr, ldb=qt.ld, m=T1, n=C, batch=B, a_batch_stride=T1 * dSt.ld, b_batch_stride=C * qt.ld, alpha=scale,
                resid_ptr=GV.ptr if shared else None, ldr=C, resid_batch_stride=rs1.Tp * C,
                rowmask_ptr=len1.data_ptr(), rowmask_batch_stride=rs1.Tp, out_f32_ptr=GK.ptr, ldo=C, out_batch_stride=rs1.Tp * C,
