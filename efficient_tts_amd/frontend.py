@@ -115,6 +115,32 @@ class LogMelFrontend:
                 self.dft = PackedWeight(M, M, 1, 2, self.dev)
                 self.dft.pack(torch.from_numpy(dft).to(self.dev).contiguous())
         self._ws = {}
+        self._pins = {}
+
+    _RING = 8
+
+    def _to_device_async(self, lh, fh) -> torch.Tensor:
+        """lengths and frame counts as ONE int32 [2, B] device tensor, copied from a pinned staging buffer without blocking the host (a pageable
+        copy waits for the kernels queued in front of it: the host could never run ahead of the fused launch).  A ring of staging buffers per
+        batch size, each guarded by the event of the copy that last read it."""
+        B = len(lh)
+        ring = self._pins.setdefault(B, dict(next=0, slots=[]))
+        if len(ring["slots"]) < self._RING:
+            ring["slots"].append([torch.empty(2, B, dtype=torch.int32).pin_memory(), None])
+            slot = ring["slots"][-1]
+        else:
+            slot = ring["slots"][ring["next"]]
+            ring["next"] = (ring["next"] + 1) % self._RING
+            if slot[1] is not None:
+                slot[1].synchronize()
+        buf = slot[0]
+        buf[0] = torch.tensor(lh, dtype=torch.int32)
+        buf[1] = torch.tensor(fh, dtype=torch.int32)
+        dev_t = buf.to(self.dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        slot[1] = ev
+        return dev_t
 
     def frames_of(self, lengths: torch.Tensor) -> torch.Tensor:
         return torch.div(lengths.to(torch.int64), self.hop, rounding_mode="floor")
@@ -136,7 +162,7 @@ class LogMelFrontend:
             raise ValueError("lengths exceed the audio buffer")
         fh = [l // self.hop for l in lh]
         T = max(fh) if max_frames is None else int(max_frames)
-        both = torch.tensor([lh, fh], dtype=torch.int32).to(self.dev)
+        both = self._to_device_async(lh, fh)
         li, fi = both[0], both[1]
         frames_d = fi.to(torch.int64)
         if self.radix == 0:
