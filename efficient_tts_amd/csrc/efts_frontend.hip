@@ -353,10 +353,13 @@ __device__ __forceinline__ cf quad(cf a) {       // the value of the quad's lane
 #define FF_ABL 0
 #endif
 constexpr int FF_WAVES = 4, FF_PITCH = 65, FF_CB = 2560, FF_WIDE = 64;      // filters FF_WIDE .. run on four lanes each (they are the widest)
-__global__ __launch_bounds__(64 * FF_WAVES, 3) void logmel_fft_kernel(const float* __restrict__ audio, long ld_audio, const int* __restrict__ lengths,
+// SAMPLE: float (audio in [-1, 1]) or short (int16 PCM as TextMelLoader.get_mel reads it, scaled by `pcm_scale` = 1 / max_wav_value at the load:
+// taco2_data.py:70 -- exact in fp32 for a power of two, so both forms give the same bits; the int16 form saves the conversion pass over the batch)
+template <typename SAMPLE>
+__global__ __launch_bounds__(64 * FF_WAVES, 3) void logmel_fft_kernel(const SAMPLE* __restrict__ audio, long ld_audio, const int* __restrict__ lengths,
                                                                       const float* __restrict__ window, const float* __restrict__ basis,
                                                                       const int* __restrict__ ranges, float* __restrict__ out, int B, int T,
-                                                                      int n_mels) {
+                                                                      int n_mels, float pcm_scale) {
     using namespace fft;
     constexpr int N = 1024, HOP = 256, NBINS = 513, PAD = (N - HOP) / 2;
     __shared__ __attribute__((aligned(16))) cf zs[FF_WAVES][16 * FF_PITCH];   // transpose buffer, then Z in natural order, then (|X_a|, |X_b|) per bin in place
@@ -431,13 +434,13 @@ __global__ __launch_bounds__(64 * FF_WAVES, 3) void logmel_fft_kernel(const floa
         }
         // (1) the samples of both frames: s[j] = audio[reflect(t0 * hop + 64 j + lane - pad)], j = 0 .. 19 (frame b = frame a moved by 4 j).
         // Every load is issued, from a clamped address (a predicated load per sample compiled into twenty branches)
-        const float* a = audio + (long)b * ld_audio;
+        const SAMPLE* a = audio + (long)b * ld_audio;
         float sm[20];
         const int s0 = t0 * HOP - PAD;                               // first sample of frame a in the un-padded signal
         if (s0 >= 0 && s0 + 20 * 64 <= L) {                          // (wave-uniform) every sample of the pair lies inside the item: one base, constant offsets
-            const float* ab = a + s0 + lane;
+            const SAMPLE* ab = a + s0 + lane;
 #pragma unroll
-            for (int j = 0; j < 20; ++j) sm[j] = (FF_ABL & 16) ? (float)j : ab[64 * j];
+            for (int j = 0; j < 20; ++j) sm[j] = (FF_ABL & 16) ? (float)j : (float)ab[64 * j] * pcm_scale;
         } else {
 #pragma unroll
             for (int j = 0; j < 20; ++j) {
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(64 * FF_WAVES, 3) void logmel_fft_kernel(const floa
                 s = s < 0 ? -s : s;                                  // reflect without edge repeat (meldataset.py:69)
                 s = s >= L ? 2 * (L - 1) - s : s;
                 s = min(max(s, 0), L - 1);                           // (out of range only for frame b past the item's length: dropped below)
-                sm[j] = (FF_ABL & 16) ? (float)s : a[s];
+                sm[j] = (FF_ABL & 16) ? (float)s : (float)a[s] * pcm_scale;
             }
         }
         cf v[16];
@@ -620,17 +623,31 @@ extern "C" int efts_logmel_dit(const float* spec, int64_t ld_spec, const float* 
     return efts_check_launch("efts_logmel_dit");
 }
 
-extern "C" int efts_logmel_fft(const float* audio, int64_t ld_audio, const int32_t* lengths, const float* window, const float* basis,
-                               const int32_t* ranges, float* out, int32_t B, int32_t T, int32_t n_fft, int32_t hop, int32_t n_mels, void* stream) {
-    if (!audio || !lengths || !window || !basis || !ranges || !out) return efts_fail(EFTS_EINVAL, "efts_logmel_fft: null pointer");
-    if (B <= 0 || T <= 0) return efts_fail(EFTS_ESHAPE, "efts_logmel_fft: bad B / T");
+static int logmel_fft_launch(const void* audio, bool pcm16, float pcm_scale, int64_t ld_audio, const int32_t* lengths, const float* window, const float* basis,
+                             const int32_t* ranges, float* out, int32_t B, int32_t T, int32_t n_fft, int32_t hop, int32_t n_mels, void* stream, const char* who) {
+    if (!audio || !lengths || !window || !basis || !ranges || !out) return efts_fail(EFTS_EINVAL, "%s: null pointer", who);
+    if (B <= 0 || T <= 0) return efts_fail(EFTS_ESHAPE, "%s: bad B / T", who);
     if (n_fft != 1024 || hop != 256 || n_mels <= 0 || n_mels > FF_WIDE + 16)
-        return efts_fail(EFTS_ESHAPE, "efts_logmel_fft: the fused kernel is built for n_fft 1024, hop 256, at most 80 mel bins (64 filters on one lane each + 16 on four lanes each; other configurations: efts_frame_pack_dit + efts_gemm + efts_logmel_dit)");
+        return efts_fail(EFTS_ESHAPE, "%s: the fused kernel is built for n_fft 1024, hop 256, at most 80 mel bins (64 filters on one lane each + 16 on four lanes each; other configurations: efts_frame_pack_dit + efts_gemm + efts_logmel_dit)", who);
     const long pairs = (long)B * ((T + 1) / 2);
     long blocks = (pairs + FF_WAVES - 1) / FF_WAVES;
     const long cap = 3L * efts_num_cus();                     // persistent: three workgroups per CU (LDS, registers), each wave works through pairs / (12 CUs) frame pairs
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(logmel_fft_kernel, dim3((unsigned)blocks), dim3(64 * FF_WAVES), 0, (hipStream_t)stream, audio, (long)ld_audio, lengths, window,
-                       basis, ranges, out, B, T, n_mels);
-    return efts_check_launch("efts_logmel_fft");
+    if (pcm16)
+        hipLaunchKernelGGL(logmel_fft_kernel<short>, dim3((unsigned)blocks), dim3(64 * FF_WAVES), 0, (hipStream_t)stream, (const short*)audio, (long)ld_audio, lengths, window,
+                           basis, ranges, out, B, T, n_mels, pcm_scale);
+    else
+        hipLaunchKernelGGL(logmel_fft_kernel<float>, dim3((unsigned)blocks), dim3(64 * FF_WAVES), 0, (hipStream_t)stream, (const float*)audio, (long)ld_audio, lengths, window,
+                           basis, ranges, out, B, T, n_mels, 1.f);
+    return efts_check_launch(who);
+}
+
+extern "C" int efts_logmel_fft(const float* audio, int64_t ld_audio, const int32_t* lengths, const float* window, const float* basis,
+                               const int32_t* ranges, float* out, int32_t B, int32_t T, int32_t n_fft, int32_t hop, int32_t n_mels, void* stream) {
+    return logmel_fft_launch(audio, false, 1.f, ld_audio, lengths, window, basis, ranges, out, B, T, n_fft, hop, n_mels, stream, "efts_logmel_fft");
+}
+
+extern "C" int efts_logmel_fft_pcm16(const int16_t* audio, int64_t ld_audio, float pcm_scale, const int32_t* lengths, const float* window, const float* basis,
+                                     const int32_t* ranges, float* out, int32_t B, int32_t T, int32_t n_fft, int32_t hop, int32_t n_mels, void* stream) {
+    return logmel_fft_launch(audio, true, pcm_scale, ld_audio, lengths, window, basis, ranges, out, B, T, n_fft, hop, n_mels, stream, "efts_logmel_fft_pcm16");
 }

@@ -150,9 +150,13 @@ class LogMelFrontend:
         if audio.dim() != 2:
             raise ValueError("audio must be [B, L]")
         B = audio.shape[0]
-        if audio.dtype == torch.int16:
-            audio = audio.to(self.dev).to(torch.float32) / self.max_wav_value                  # taco2_data.py:70
-        audio = audio.to(self.dev, torch.float32).contiguous()
+        pcm16 = audio.dtype == torch.int16 and self.radix == 0
+        if pcm16:
+            audio = audio.to(self.dev).contiguous()             # the fused launch scales int16 PCM at its loads (taco2_data.py:70): no conversion pass
+        else:
+            if audio.dtype == torch.int16:
+                audio = audio.to(self.dev).to(torch.float32) / self.max_wav_value              # taco2_data.py:70
+            audio = audio.to(self.dev, torch.float32).contiguous()
         # host side of a call: the checks on plain ints, ONE small host-to-device copy (lengths and frame counts together), one output allocation
         # (three CPU-tensor reductions and three copies took 60 us per call -- as long as the fused launch itself)
         lh = lengths.detach().to("cpu", torch.int64).tolist()
@@ -168,9 +172,14 @@ class LogMelFrontend:
         if self.radix == 0:
             out = torch.empty(B, T, self.n_mels, dtype=torch.float32, device=self.dev)
             with O.stream_scope():
-                L.check(L.load().efts_logmel_fft(audio.data_ptr(), audio.shape[1], li.data_ptr(), self.window.data_ptr(), self.basis.data_ptr(),
-                                                 self.ranges.data_ptr(), out.data_ptr(), B, T, self.n_fft, self.hop, self.n_mels, O._stream()),
-                        "efts_logmel_fft")
+                if pcm16:
+                    L.check(L.load().efts_logmel_fft_pcm16(audio.data_ptr(), audio.shape[1], 1.0 / self.max_wav_value, li.data_ptr(), self.window.data_ptr(),
+                                                           self.basis.data_ptr(), self.ranges.data_ptr(), out.data_ptr(), B, T, self.n_fft, self.hop, self.n_mels,
+                                                           O._stream()), "efts_logmel_fft_pcm16")
+                else:
+                    L.check(L.load().efts_logmel_fft(audio.data_ptr(), audio.shape[1], li.data_ptr(), self.window.data_ptr(), self.basis.data_ptr(),
+                                                     self.ranges.data_ptr(), out.data_ptr(), B, T, self.n_fft, self.hop, self.n_mels, O._stream()),
+                            "efts_logmel_fft")
             return out, frames_d
         rs = Rows(B, T)
         key = (B, T)

@@ -170,6 +170,7 @@ _SIGS = {
     "efts_frame_pack_dit": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp]),
     "efts_logmel_dit": (i32, [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "efts_logmel_fft": (i32, [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "efts_logmel_fft_pcm16": (i32, [vp, i64, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     # vocoder
     "efts_mean_act_rows": (i32, [vp, vp, vp, i64, f32, f32, vp, i64, vp, i64, i32, i32, i32, vp]),
 }

@@ -64,7 +64,7 @@ extern "C" {
  *        efts_wgrad_tn, efts_wgrad_reduce_bias, efts_resconv5_kernel removed (efts_wgrad_tn_grouped / efts_wgrad_reduce_grouped instead)
  *   600  round 6: + efts_frame_pack_dit, efts_logmel_dit; efts_pack_item.plane may be NULL (dgrad plane only)
  *   601  round 6 (this header): efts_gemm_args grew by sqerr_target / ld_target / target_batch_stride / sqerr_part;
- *        + efts_losses_from_parts, efts_logmel_fft */
+ *        + efts_losses_from_parts, efts_logmel_fft, efts_logmel_fft_pcm16 */
 #define EFTS_ABI_VERSION 601
 int efts_version(void);
 const char* efts_last_error(void);
@@ -649,6 +649,10 @@ int efts_logmel_dit(const float* spec, int64_t ld_spec, const float* basis, cons
  * pipeline above. */
 int efts_logmel_fft(const float* audio, int64_t ld_audio, const int32_t* lengths, const float* window, const float* basis,
                     const int32_t* ranges, float* out, int32_t B, int32_t T, int32_t n_fft, int32_t hop, int32_t n_mels, void* stream);
+/* ... straight from int16 PCM, as TextMelLoader.get_mel reads a waveform (taco2_data.py:66-76): every sample is multiplied by pcm_scale
+ * (1 / max_wav_value = 1 / 32768: exact in fp32) at the load -- the same bits as converting the batch first, without the conversion pass. */
+int efts_logmel_fft_pcm16(const int16_t* audio, int64_t ld_audio, float pcm_scale, const int32_t* lengths, const float* window, const float* basis,
+                          const int32_t* ranges, float* out, int32_t B, int32_t T, int32_t n_fft, int32_t hop, int32_t n_mels, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * HiFi-GAN generator (nntts/vocoders/hifigan_model.py:95-136): every Conv1d /
