@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64 * LM_WAVES) void logmel_dit_fast_kernel(const fl
 //   (1) lane n2 reads its 16 samples of both frames straight from the audio (for a fixed n1 the 64 lanes read 64 consecutive
 //       samples; frame b is frame a moved by one hop = 4 values of n1, so 20 loads serve both), a 16-point DFT in registers,
 //       the twiddles W1024^(n2 k1) (per-lane constants, computed once per wave);
-//   (2) ONE transpose through LDS (rows of 65 complex: the column reads of step 3 then spread over all banks);
+//   (2) ONE transpose through LDS (rows of 68 complex: the column reads of step 3 then spread over all banks);
 //   (3) lane (k1, q) holds n2 = 4 r + q: 16-point DFT over r, twiddles W64^(q s), and the last radix-4 across the four lanes of
 //       a quad with DPP moves -- lane (k1, q) ends up with X[k1 + 16 s + 256 u(q)], s = 0 .. 15;
 //   (4) Z in natural order through the same LDS region, magnitudes of both frames, the mel filterbank (its non-zero spans in LDS,
@@ -352,7 +352,7 @@ __device__ __forceinline__ cf quad(cf a) {       // the value of the quad's lane
 #ifndef FF_ABL
 #define FF_ABL 0
 #endif
-constexpr int FF_WAVES = 4, FF_PITCH = 65, FF_CB = 2560, FF_WIDE = 64;      // filters FF_WIDE .. run on four lanes each (they are the widest)
+constexpr int FF_WAVES = 4, FF_PITCH = 68, FF_CB = 2560, FF_WIDE = 64;      // filters FF_WIDE .. run on four lanes each (they are the widest)
 // SAMPLE: float (audio in [-1, 1]) or short (int16 PCM as TextMelLoader.get_mel reads it, scaled by `pcm_scale` = 1 / max_wav_value at the load:
 // taco2_data.py:70 -- exact in fp32 for a power of two, so both forms give the same bits; the int16 form saves the conversion pass over the batch)
 template <typename SAMPLE>
@@ -394,13 +394,19 @@ __global__ __launch_bounds__(64 * FF_WAVES, 3) void logmel_fft_kernel(const SAMP
     }
     __syncthreads();
     const int w0 = nst[0], w1 = nst[1];
-    auto off_of = [&](int m) { return m < FF_WIDE ? 4 * w0 * m : 4 * w0 * min(n_mels, FF_WIDE) + 16 * w1 * (m - FF_WIDE); };
+    // strides in cb: odd multiples of four floats, so that the 16-byte weight reads of 64 lanes (one filter / one quarter each) spread over all banks
+    // (a stride of 16 floats put 32 lanes on the same four banks: two thirds of the kernel's LDS cycles were bank conflicts, rocprofv3 SQ_LDS_BANK_CONFLICT)
+    const int S0 = 4 * (w0 | 1), SQ = 4 * (w1 | 1);
+    auto off_of = [&](int m) { return m < FF_WIDE ? S0 * m : S0 * min(n_mels, FF_WIDE) + 4 * SQ * (m - FF_WIDE); };
     // (the padding steps of a span read zw behind the filter's last bin: they must stay inside the wave's 16 x 65 buffer)
     const bool in_lds = off_of(n_mels) <= FF_CB && NBINS + 4 * w0 <= 16 * FF_PITCH && NBINS + 16 * w1 <= 16 * FF_PITCH;
     if (in_lds) {
         for (int m = wave; m < n_mels; m += FF_WAVES) {
             const int lo = ranges[2 * m], hi = ranges[2 * m + 1];
-            for (int k = lo + lane; k < hi; k += 64) cb[off_of(m) + k - lo] = basis[(long)m * NBINS + k];
+            for (int k = lo + lane; k < hi; k += 64) {
+                const int t = k - lo;
+                cb[off_of(m) + (m < FF_WIDE ? t : SQ * (t / (4 * w1)) + t % (4 * w1))] = basis[(long)m * NBINS + k];      // (wide filters: quarter after quarter)
+            }
         }
     }
     __syncthreads();
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(64 * FF_WAVES, 3) void logmel_fft_kernel(const SAMP
     if (in_lds && m0 < n_mels && m0 < FF_WIDE) { lo0 = ranges[2 * m0]; o0 = off_of(m0); ns0 = (ranges[2 * m0 + 1] - lo0 + 3) >> 2; }
     if (in_lds && m1 < n_mels) {
         const int lo = ranges[2 * m1], hi = ranges[2 * m1 + 1];
-        lo1 = lo + 4 * w1 * q; o1 = off_of(m1) + 4 * w1 * q;
+        lo1 = lo + 4 * w1 * q; o1 = off_of(m1) + SQ * q;
         ns1 = max(0, min(w1, (hi - lo1 + 3) >> 2));
     }
     const float s1 = (q & 2) ? -1.f : 1.f, s2 = (q & 1) ? -1.f : 1.f;     // signs of the quad radix-4: r = partner + s * own
@@ -486,16 +492,18 @@ __global__ __launch_bounds__(64 * FF_WAVES, 3) void logmel_fft_kernel(const SAMP
 #endif
         const int u = ((q & 1) << 1) | (q >> 1);
         // (4) Z in natural order: f = k1 + 16 s + 256 u
+        // (bin f sits at f + 4 (f / 256): the four lanes of a quad hold the same k1, and without the shift their stores meet in the same banks)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) zw[k1 + 16 * s + 256 * u] = v[s];
+        for (int s = 0; s < 16; ++s) zw[k1 + 16 * s + 260 * u] = v[s];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // magnitudes of both frames, IN PLACE: bin f of this lane reads Z[f] and Z[N - f] -- no other lane reads either -- and leaves
-        // (|X_a[f]|, |X_b[f]|) at zw[f]
+        // (|X_a[f]|, |X_b[f]|) at zw[f] (unshifted: what sits there belongs to a bin at or below f, read in this or an earlier step)
 #pragma unroll
         for (int i = 0; i < ((FF_ABL & 8) ? 2 : 9); ++i) {
             const int f = lane + 64 * i;
             if (f < NBINS) {
-                const cf zf = zw[f], zn = zw[(N - f) & (N - 1)];
+                const int fn = (N - f) & (N - 1);
+                const cf zf = zw[f + 4 * (f >> 8)], zn = zw[fn + 4 * (fn >> 8)];
                 const float ar = 0.5f * (zf.x + zn.x), ai = 0.5f * (zf.y - zn.y);
                 const float br = 0.5f * (zf.y + zn.y), bi = -0.5f * (zf.x - zn.x);
                 zw[f] = cf{__builtin_amdgcn_sqrtf(ar * ar + ai * ai + 1e-9f),     // meldataset.py:75 (v_sqrt_f32: 1 ulp)
